@@ -1,0 +1,171 @@
+/*
+ * rtc_oracle.h -- C API of the CPU ORACLE.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C++ restatement of the per-pixel
+ * render path of garfieldnate/ray_tracer_challenge (Rust, f32).  It exists so
+ * that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can
+ * check (and time) the HIP path against the reference's arithmetic.  Nothing
+ * in the product path (ray_tracer_challenge_amd/, include/) may include, link
+ * or call anything in this directory.
+ *
+ * Parity status: the reference cannot be compiled here (no Rust toolchain), so
+ * the oracle is pinned by the reference's own known-answer unit tests,
+ * transcribed as data under tests/golden/ (see tests/test_oracle_*.py).
+ *
+ * All citations are file:line in /root/reference/lib/src.
+ */
+#ifndef RTC_ORACLE_H
+#define RTC_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { RTCO_SPHERE = 0, RTCO_PLANE = 1, RTCO_CUBE = 2, RTCO_CYLINDER = 3,
+       RTCO_TEST_SHAPE = 100 /* shape/test_shape.rs: no hits, local normal (2x,3y,4z) */ };
+enum { RTCO_LIGHT_POINT = 0, RTCO_LIGHT_RECT = 1 };
+/* jitter sources for RectangleLight (light/rectangle_light.rs:44-47, test/utils.rs:15-24) */
+enum { RTCO_JITTER_CONSTANT = 0, RTCO_JITTER_CYCLE = 1, RTCO_JITTER_HASHED = 2 };
+
+/* material.rs:18-51 (pattern is out of scope) */
+typedef struct rtco_material {
+    float color[3];
+    float ambient, diffuse, specular, shininess;
+    float reflective, transparency, refractive_index;
+} rtco_material;
+
+/* shape/base_shape.rs:13-20 + cylinder.rs:14-19.  `transform` is the FORWARD
+ * object->world matrix (row-major); the oracle inverts it itself. */
+typedef struct rtco_shape {
+    int32_t kind;
+    int32_t casts_shadow;
+    int32_t closed;
+    float min_y, max_y;
+    float transform[16];
+    rtco_material material;
+} rtco_shape;
+
+/* light/point_light.rs:7-10, light/rectangle_light.rs:12-31.  u_vec/v_vec are
+ * the FULL edge vectors as passed to RectangleLight::new. */
+typedef struct rtco_light {
+    int32_t kind;
+    float intensity[3];
+    float position[4]; /* point light position */
+    float corner[4];
+    float u_vec[4];
+    int32_t u_steps;
+    float v_vec[4];
+    int32_t v_steps;
+    int32_t jitter_mode;
+    float jitter_const;
+    uint32_t jitter_seed;
+    const float* jitter_seq; /* RTCO_JITTER_CYCLE: copied at world creation */
+    int32_t jitter_seq_len;
+} rtco_light;
+
+/* camera.rs:8-21 after Camera::new */
+typedef struct rtco_camera {
+    uint32_t width, height;
+    float field_of_view;
+    float half_width, half_height, pixel_size;
+    float transform_inverse[16];
+} rtco_camera;
+
+/* world.rs:165-182 */
+typedef struct rtco_comps {
+    float distance;
+    int32_t object;
+    float point[4], eye[4], reflectv[4], normal[4], over_point[4], under_point[4];
+    int32_t inside;
+    float n1, n2;
+} rtco_comps;
+
+typedef struct rtco_world rtco_world;
+
+/* ---- tuple.rs / ray.rs ---- */
+float rtco_magnitude(const float v[4]);
+void rtco_norm(const float v[4], float out[4]);
+float rtco_dot(const float a[4], const float b[4]);
+void rtco_cross(const float a[4], const float b[4], float out[4]);
+void rtco_reflect(const float in[4], const float n[4], float out[4]);
+void rtco_position(const float o[4], const float d[4], float t, float out[4]);
+
+/* ---- matrix.rs (n = 2,3,4; row-major n*n) ---- */
+void rtco_mat_mul(const float a[16], const float b[16], float out[16]);
+void rtco_mat_vec(const float a[16], const float v[4], float out[4]);
+void rtco_mat_transpose(const float* a, int n, float* out);
+float rtco_mat_determinant(const float* a, int n);
+void rtco_mat_submatrix(const float* a, int n, int row, int col, float* out);
+float rtco_mat_minor(const float* a, int n, int row, int col);
+float rtco_mat_cofactor(const float* a, int n, int row, int col);
+void rtco_mat_inverse(const float* a, int n, float* out);
+
+/* ---- transformations.rs ---- */
+void rtco_translation(float x, float y, float z, float out[16]);
+void rtco_scaling(float x, float y, float z, float out[16]);
+void rtco_rotation_x(float r, float out[16]);
+void rtco_rotation_y(float r, float out[16]);
+void rtco_rotation_z(float r, float out[16]);
+void rtco_shearing(float xy, float xz, float yx, float yz, float zx, float zy, float out[16]);
+void rtco_view_transform(const float from[4], const float to[4], const float up[4], float out[16]);
+
+/* ---- camera.rs ---- */
+void rtco_camera_new(uint32_t w, uint32_t h, float fov, const float transform[16], rtco_camera* out);
+void rtco_ray_for_pixel(const rtco_camera* c, uint32_t x, uint32_t y, float o[4], float d[4]);
+
+/* ---- shapes ---- */
+int rtco_local_intersect(const rtco_shape* s, const float o[4], const float d[4], float ts[4]);
+void rtco_local_normal_at(const rtco_shape* s, const float p[4], float out[4]);
+int rtco_shape_intersect(const rtco_shape* s, const float o[4], const float d[4], float ts[4],
+                         float obj_o[4], float obj_d[4]);
+void rtco_normal_at(const rtco_shape* s, const float world_point[4], float out[4]);
+int rtco_aabb_intersection(const float o[4], const float d[4], const float mn[4], const float mx[4],
+                           float out_t[2]);
+/* intersection.rs:30-35; returns index or -1 */
+int rtco_hit(const float* ts, int n);
+
+/* ---- world.rs / lights ---- */
+rtco_world* rtco_world_new(const rtco_shape* shapes, int n, const rtco_light* light);
+void rtco_world_free(rtco_world* w);
+void rtco_world_set_pixel(rtco_world* w, uint32_t pixel_index); /* key for hashed jitter */
+uint64_t rtco_world_ray_count(const rtco_world* w);
+void rtco_world_shape_inverse(const rtco_world* w, int i, float inv[16], float inv_t[16]);
+void rtco_light_info(const rtco_world* w, float position[4], float u_vec[4], float v_vec[4], int* cells);
+int rtco_intersect(rtco_world* w, const float o[4], const float d[4], float* ts, int* objs, int cap);
+void rtco_color_at(rtco_world* w, const float o[4], const float d[4], int depth, float out[3]);
+int rtco_is_shadowed(rtco_world* w, const float light_pos[4], const float p[4]);
+float rtco_intensity_at(rtco_world* w, const float p[4]);
+void rtco_point_on_light(rtco_world* w, int u, int v, float out[4]);
+void rtco_precompute(rtco_world* w, const float o[4], const float d[4], int hit, const float* ts,
+                     const int* objs, int n, rtco_comps* out);
+void rtco_shade_hit(rtco_world* w, const rtco_comps* c, int depth, float out[3]);
+void rtco_reflected_color(rtco_world* w, const rtco_comps* c, int depth, float out[3]);
+void rtco_refracted_color(rtco_world* w, const rtco_comps* c, int depth, float out[3]);
+float rtco_schlick(const rtco_comps* c);
+/* light/phong_lighting.rs:12-63; light taken from the world */
+void rtco_phong(rtco_world* w, const rtco_material* m, const float p[4], const float eye[4],
+                const float n[4], float light_intensity, float out[3]);
+
+/* ---- camera.rs:76-91 render + canvas.rs ---- */
+/* out_rgb: w*h*3 f32 row-major, fully written (last row/column black).
+ * threads<=1: the reference's serial loop.  Returns rays traced. */
+uint64_t rtco_render(rtco_world* w, const rtco_camera* c, int depth, int threads, float* out_rgb);
+/* renders rows [y0,y1) only (still skipping the last row/column), for bounded CPU timing */
+uint64_t rtco_render_rows(rtco_world* w, const rtco_camera* c, int depth, int threads,
+                          uint32_t y0, uint32_t y1, float* out_rgb);
+uint8_t rtco_scale_color(float c);
+void rtco_quantize(const float* rgb, uint64_t n, uint8_t* out);
+/* canvas.rs:58-96; returns malloc'd NUL-terminated text, length in *len; free with rtco_free */
+char* rtco_to_ppm(const float* rgb, uint32_t w, uint32_t h, uint64_t* len);
+void rtco_free(void* p);
+
+/* jitter spec shared (by specification, not by code) with the HIP kernel */
+uint32_t rtco_jitter_hash(uint32_t seed, uint32_t pixel, uint32_t path, uint32_t cell, uint32_t draw);
+float rtco_jitter_value(uint32_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

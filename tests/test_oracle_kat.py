@@ -1,0 +1,378 @@
+"""Pins the CPU oracle to the reference's own known-answer tests for the
+render hot path (shapes, intersection, world, lights, Phong, canvas).
+Vectors: tests/golden/reference_kat.json (transcribed from the reference's
+inline #[test] functions; each block cites file:line).  No GPU needed.
+"""
+import numpy as np
+
+from oracle import oracle as O
+from tests import kat as K
+
+f32 = np.float32
+S2 = K.CONSTS["FRAC_1_SQRT_2"]
+SQRT_2 = K.CONSTS["SQRT_2"]
+
+
+# ------------------------------------------------------------------ shapes
+def test_sphere_intersections(kat):  # ray.rs:75-120
+    s = O.Sphere()
+    for o, d, expected in kat["sphere"]["intersect"]["cases"]:
+        ts, _, _ = s.intersect(K.point(o), K.vector(d))
+        K.assert_exact(ts, expected)
+    c = kat["sphere"]["scaled"]
+    s2 = O.Sphere(O.scaling(2.0, 2.0, 2.0))
+    K.assert_exact(s2.local_intersect(K.point(c["ray"][0]), K.vector(c["ray"][1])), c["expect_exact"])
+    c = kat["sphere"]["translated_miss"]
+    s3 = O.Sphere(O.translation(5.0, 0.0, 0.0))
+    assert s3.local_intersect(K.point(c["ray"][0]), K.vector(c["ray"][1])) == []
+
+
+def test_sphere_normals(kat):  # shape/sphere.rs:114-145
+    s = O.Sphere()
+    for p, n in kat["sphere"]["normals"]["cases"]:
+        K.assert_exact(s.local_norm_at(K.point(p)), K.vec(n))
+    q = f32(1.0) / np.sqrt(f32(3.0))
+    K.assert_eps(s.local_norm_at(K.point([q, q, q])), np.array([q, q, q, 0], dtype=f32))
+
+
+def test_plane(kat):  # shape/plane.rs:74-116
+    p = O.Plane()
+    for pt in kat["plane"]["normal_points"]:
+        K.assert_exact(p.local_norm_at(K.point(pt)), [0, 1, 0, 0])
+    for o, d, expected in kat["plane"]["intersect"]:
+        K.assert_exact(p.local_intersect(K.point(o), K.vector(d)), expected)
+
+
+def test_cube(kat):  # shape/cube.rs:136-230
+    c = O.Cube()
+    for o, d, t0, t1 in kat["cube"]["hits"]["cases"]:
+        K.assert_exact(c.local_intersect(K.point(o), K.vector(d)), [t0, t1])
+    for o, d in kat["cube"]["misses"]["cases"]:
+        assert c.local_intersect(K.point(o), K.vector(d)) == []
+    for p, n in kat["cube"]["normals"]["cases"]:
+        K.assert_exact(c.local_norm_at(K.point(p)), K.vector(n))
+
+
+def test_aabb_intersection(kat):  # bounding_box.rs:199-247
+    for key in ("at_origin", "off_origin"):
+        blk = kat["aabb"][key]
+        for o, d, expected in blk["cases"]:
+            got = O.aabb_intersection(K.point(o), O.norm(K.vector(d)), K.point(blk["min"]), K.point(blk["max"]))
+            assert (got is not None) == expected, (key, o, d)
+
+
+def test_cylinder(kat):  # shape/cylinder.rs:161-363
+    cy = kat["cylinder"]
+    c = O.Cylinder()
+    for o, d in cy["misses"]["cases"]:
+        assert c.local_intersect(K.point(o), O.norm(K.vector(d))) == []
+    for o, d, t0, t1 in cy["sides"]["cases"]:
+        ts = c.local_intersect(K.point(o), O.norm(K.vector(d)))
+        assert len(ts) == 2
+        K.assert_eps(ts, [t0, t1])
+    for key in ("constrained", "caps"):
+        blk = cy[key]
+        cc = O.Cylinder(minimum_y=blk["min"], maximum_y=blk["max"], closed=blk["closed"])
+        for o, d, count in blk["cases"]:
+            assert len(cc.local_intersect(K.point(o), O.norm(K.vector(d)))) == count, (key, o, d)
+    for p, n in cy["side_normals"]["cases"]:
+        K.assert_exact(c.local_norm_at(K.point(p)), K.vector(n))
+    blk = cy["cap_normals"]
+    cc = O.Cylinder(minimum_y=blk["min"], maximum_y=blk["max"], closed=blk["closed"])
+    for p, n in blk["cases"]:
+        K.assert_exact(cc.local_norm_at(K.point(p)), K.vector(n))
+
+
+def test_shape_object_space_ray_and_normals(kat):  # shape/shape.rs:203-243
+    sh = kat["shape"]
+    c = sh["scaled_ray"]
+    _, oo, od = O.Sphere(O.scaling(*c["scaling"])).intersect(K.point(c["ray"][0]), K.vector(c["ray"][1]))
+    K.assert_exact(oo, c["object_ray"][0])
+    K.assert_exact(od, c["object_ray"][1])
+    c = sh["translated_ray"]
+    _, oo, od = O.Sphere(O.translation(*c["translation"])).intersect(K.point(c["ray"][0]), K.vector(c["ray"][1]))
+    K.assert_exact(oo, c["object_ray"][0])
+    K.assert_exact(od, c["object_ray"][1])
+    c = sh["normal_translated"]
+    n = O.TestShape(O.translation(*c["translation"])).normal_at(K.point(c["point"]))
+    K.assert_eps(n, c["expect_eps"])
+    c = sh["normal_transformed"]
+    t = O.mat_mul(O.scaling(1.0, 0.5, 1.0), O.rotation_z(K.CONSTS["PI"] / f32(5.0)))
+    n = O.TestShape(t).normal_at(K.point(c["point"]))
+    K.assert_eps(n, c["expect_eps"])
+    n = O.TestShape().normal_at(K.point([1, 5, 10]))  # normal_is_normalized_vector
+    K.assert_eps(n, O.norm(n))
+
+
+def test_hit_selection(kat):  # intersection.rs:53-95
+    for ts, expected in kat["intersection_hit"]["cases"]:
+        assert O.hit(ts) == expected
+    assert O.hit([f32(-0.0), 1.0]) == 0          # -0.0 >= 0.0 is true
+    assert O.hit([2.0, 1.0, 1.0]) == 1           # first of equal minima
+
+
+def test_ray_position(kat):  # ray.rs:67-73
+    c = kat["ray"]["position"]
+    for t, expected in c["cases"]:
+        K.assert_exact(O.position(K.point(c["ray"][0]), K.vector(c["ray"][1]), t), expected)
+
+
+# ------------------------------------------------------------------- world
+def test_intersect_world_with_ray(kat):  # world.rs:322-332
+    c = kat["world"]["intersect_world_with_ray"]
+    ts, objs = O.default_world().intersect(K.point(c["ray"][0]), K.vector(c["ray"][1]))
+    K.assert_exact(ts, c["expect_exact"])
+    assert list(objs) == [0, 1, 1, 0]
+
+
+def test_precompute(kat):  # world.rs:334-381
+    w = O.World([O.Sphere()], O.PointLight(O.point(0, 0, 0), O.color(1, 1, 1)))
+    for key in ("precompute_state", "precompute_inside"):
+        c = kat["world"][key]
+        comps = w.precompute_values(K.point(c["ray"][0]), K.vector(c["ray"][1]), 0, [(c["t"], 0)])
+        K.assert_exact(O.arr4(comps.point), c["point"])
+        K.assert_exact(O.arr4(comps.eye), c["eye"])
+        K.assert_exact(O.arr4(comps.normal), c["normal"])
+        assert bool(comps.inside) == c["inside"]
+        assert comps.distance == c["t"]
+    c = kat["world"]["precompute_reflection_vector"]
+    w = O.World([O.Plane()], O.PointLight(O.point(0, 0, 0), O.color(1, 1, 1)))
+    comps = w.precompute_values(K.point(c["ray"][0]), K.vector(c["ray"][1]), 0, [(K.val(c["t"]), 0)])
+    K.assert_exact(O.arr4(comps.reflectv), K.vec(c["reflectv"]))
+
+
+def _glass(transform, ri):
+    return O.Sphere(transform, O.Material(transparency=1.0, refractive_index=ri))
+
+
+def test_find_n1_and_n2(kat):  # world.rs:396-451
+    c = kat["world"]["find_n1_and_n2"]
+    w = O.World([_glass(O.scaling(2.0, 2.0, 2.0), 1.5), _glass(O.translation(0.0, 0.0, -0.25), 2.0),
+                 _glass(O.translation(0.0, 0.0, 0.25), 2.5)], O.PointLight(O.point(0, 0, 0), O.color(1, 1, 1)))
+    xs = [tuple(x) for x in c["xs"]]
+    for i, (n1, n2) in enumerate(c["expect_exact"]):
+        comps = w.precompute_values(K.point(c["ray"][0]), K.vector(c["ray"][1]), i, xs)
+        assert comps.n1 == n1 and comps.n2 == n2, (i, comps.n1, comps.n2)
+
+
+def test_over_and_under_point_offsets():  # world.rs:453-466, 633-643
+    eps = f32(1.1920929e-7) * f32(10000.0)
+    w = O.World([_glass(O.translation(0.0, 0.0, 1.0), 1.5)], O.PointLight(O.point(0, 0, 0), O.color(1, 1, 1)))
+    comps = w.precompute_values(O.point(0, 0, -5), O.vector(0, 0, 1), 0, [(5.0, 0)])
+    assert comps.under_point[2] > eps / f32(2.0)
+    assert comps.point[2] < comps.under_point[2]
+    assert comps.over_point[2] < -eps / f32(2.0)
+    assert comps.over_point[2] > -eps * f32(2.0)
+    assert comps.point[2] > comps.over_point[2]
+
+
+def _reflective_plane_world():
+    w = O.default_world()
+    w.objects.append(O.Plane(O.translation(0.0, -1.0, 0.0), O.Material(reflective=0.5)))
+    return w
+
+
+def test_reflection(kat):  # world.rs:469-537
+    W = kat["world"]
+    w = O.default_world()
+    w.objects[1].material = w.objects[1].material.copy(ambient=1.0)
+    c = W["reflected_color_nonreflective"]
+    comps = w.precompute_values(K.point(c["ray"][0]), K.vector(c["ray"][1]), 0, [tuple(c["hit"])])
+    K.assert_exact(w.reflected_color(comps, c["depth"]), c["expect_exact"])
+
+    w = _reflective_plane_world()
+    o, d = O.point(0, 0, -3), np.array([0, -S2, S2, 0], dtype=f32)
+    comps = w.precompute_values(o, d, 0, [(SQRT_2, 2)])
+    K.assert_eps(w.reflected_color(comps, 1), W["reflected_color_reflective"]["expect_eps"])
+    K.assert_eps(w.shade_hit(comps, 1), W["shade_hit_reflective"]["expect_eps"])
+    K.assert_eps(w.reflected_color(comps, 0), W["reflected_color_at_max_depth"]["expect_eps"])
+
+
+def test_mutually_reflective_surfaces_terminate():  # world.rs:511-523
+    m = O.Material(reflective=1.0)
+    w = O.World([O.Plane(O.translation(0.0, -1.0, 0.0), m), O.Plane(O.translation(0.0, 1.0, 0.0), m)],
+                O.PointLight(O.point(0, 0, 0), O.color(0, 0, 0)))
+    w.color_at(O.point(0, 0, 0), O.vector(0, 1, 0), 1)
+
+
+def test_shading(kat):  # world.rs:540-590, 646-658
+    W = kat["world"]
+    w = O.default_world()
+    c = W["shade_intersection"]
+    comps = w.precompute_values(K.point(c["ray"][0]), K.vector(c["ray"][1]), 0, [tuple(c["hit"])])
+    K.assert_eps(w.shade_hit(comps, c["depth"]), c["expect_eps"])
+
+    c = W["shade_intersection_from_inside"]
+    w = O.default_world()
+    w.light = O.PointLight(K.point(c["light"]), O.color(1, 1, 1))
+    comps = w.precompute_values(K.point(c["ray"][0]), K.vector(c["ray"][1]), 0, [tuple(c["hit"])])
+    K.assert_eps(w.shade_hit(comps, c["depth"]), c["expect_eps"])
+
+    w = O.default_world()
+    c = W["color_when_ray_misses"]
+    K.assert_exact(w.color_at(K.point(c["ray"][0]), K.vector(c["ray"][1]), c["depth"]), c["expect_exact"])
+    c = W["color_when_ray_hits"]
+    K.assert_eps(w.color_at(K.point(c["ray"][0]), K.vector(c["ray"][1]), c["depth"]), c["expect_eps"])
+
+    c = W["color_when_intersection_behind_ray"]
+    w = O.default_world()
+    w.objects[0].material = O.Material(ambient=1.0)
+    w.objects[1].material = O.Material(ambient=1.0)
+    K.assert_exact(w.color_at(K.point(c["ray"][0]), K.vector(c["ray"][1]), c["depth"]), c["expect_exact"])
+
+    c = W["shade_hit_in_shadow"]
+    w = O.World([O.Sphere(), O.Sphere(O.translation(*c["s2_translation"]))],
+                O.PointLight(K.point(c["light"]), O.color(1, 1, 1)))
+    comps = w.precompute_values(K.point(c["ray"][0]), K.vector(c["ray"][1]), 0, [tuple(c["hit"])])
+    K.assert_exact(w.shade_hit(comps, c["depth"]), K.vec(c["expect_exact"]))
+
+
+def test_shadows_and_point_light_intensity(kat):  # world.rs:593-630
+    w = O.default_world()
+    c = kat["world"]["is_shadowed"]
+    for p, expected in c["cases"]:
+        assert w.is_shadowed(K.point(c["light_position"]), K.point(p)) == expected, p
+    for p, expected in kat["world"]["point_light_intensity_at"]["cases"]:
+        K.assert_eps(w.intensity_at(K.point(p)), expected)
+
+
+def _transparent_sphere_world():
+    w = O.default_world()
+    w.objects[0].material = w.objects[0].material.copy(transparency=1.0, refractive_index=1.5)
+    return w
+
+
+def test_refraction(kat):  # world.rs:661-713
+    W = kat["world"]
+    c = W["refracted_color_opaque"]
+    w = O.default_world()
+    comps = w.precompute_values(K.point(c["ray"][0]), K.vector(c["ray"][1]), c["hit_index"], [tuple(x) for x in c["xs"]])
+    K.assert_eps(w.refracted_color(comps, c["depth"]), c["expect_eps"])
+    w = _transparent_sphere_world()
+    comps = w.precompute_values(K.point(c["ray"][0]), K.vector(c["ray"][1]), c["hit_index"], [tuple(x) for x in c["xs"]])
+    K.assert_eps(w.refracted_color(comps, 0), W["refracted_color_max_depth"]["expect_eps"])
+    c = W["refracted_color_tir"]
+    xs = [(K.val(t), o) for t, o in c["xs"]]
+    comps = w.precompute_values(K.point(c["ray"][0]), K.vector(c["ray"][1]), c["hit_index"], xs)
+    K.assert_eps(w.refracted_color(comps, c["depth"]), c["expect_eps"])
+
+
+def _floor_and_ball_world(floor_material):
+    w = O.default_world()
+    w.objects.append(O.Plane(O.translation(0.0, -1.0, 0.0), floor_material))
+    w.objects.append(O.Sphere(O.translation(0.0, -3.5, -0.5), O.Material(color=(1, 0, 0), ambient=0.5)))
+    return w
+
+
+def test_transparent_and_schlick_shading(kat):  # world.rs:747-844
+    W = kat["world"]
+    o, d = O.point(0, 0, -3), np.array([0, -S2, S2, 0], dtype=f32)
+    w = _floor_and_ball_world(O.Material(transparency=0.5, refractive_index=1.5))
+    comps = w.precompute_values(o, d, 0, [(SQRT_2, 2)])
+    K.assert_eps(w.shade_hit(comps, 5), W["shade_hit_transparent"]["expect_eps"])
+    w = _floor_and_ball_world(O.Material(reflective=0.5, transparency=0.5, refractive_index=1.5))
+    comps = w.precompute_values(o, d, 0, [(SQRT_2, 2)])
+    K.assert_eps(w.shade_hit(comps, 5), W["shade_hit_reflective_transparent"]["expect_eps"])
+
+
+def test_schlick(kat):  # world.rs:780-812
+    W = kat["world"]
+    w = O.World([_glass(O.identity_4x4(), 1.5)], O.PointLight(O.point(0, 0, 0), O.color(1, 1, 1)))
+    comps = w.precompute_values(np.array([0, 0, S2, 1], dtype=f32), O.vector(0, 1, 0), 1, [(-S2, 0), (S2, 0)])
+    assert O.schlick_reflectance(comps) == W["schlick_tir"]["expect_exact"]
+    comps = w.precompute_values(O.point(0, 0, 0), O.vector(0, 1, 0), 1, [(-1.0, 0), (1.0, 0)])
+    K.assert_eps(O.schlick_reflectance(comps), W["schlick_perpendicular"]["expect_eps"])
+    c = W["schlick_small_angle"]
+    comps = w.precompute_values(K.point(c["ray"][0]), K.vector(c["ray"][1]), 0, [tuple(x) for x in c["xs"]])
+    K.assert_eps(O.schlick_reflectance(comps), c["expect_eps"])
+
+
+# ------------------------------------------------------------------ lights
+def test_rectangle_light(kat):  # light/rectangle_light.rs:99-166
+    R = kat["rectangle_light"]
+    c = R["construction"]
+    w = O.World([], O.RectangleLight(O.color(1, 1, 1), K.point(c["corner"]), K.vector(c["u"]), c["u_steps"],
+                                     K.vector(c["v"]), c["v_steps"], ("constant", 0.5)))
+    pos, u, v, cells = w.light_info()
+    K.assert_exact(u, c["u_vec"])
+    K.assert_exact(v, c["v_vec"])
+    K.assert_exact(pos, c["position"])
+    assert cells == c["cells"]
+
+    p = R["point_on_light"]
+    for u_i, v_i, expected in p["cases"]:
+        w = O.World([], O.RectangleLight(O.color(1, 1, 1), K.point(c["corner"]), K.vector(c["u"]), 4,
+                                         K.vector(c["v"]), 2, ("cycle", p["jitter_cycle"])))
+        K.assert_exact(w.point_on_light(u_i, v_i), expected)
+
+    c = R["intensity_at"]
+    for pt, expected in c["cases"]:
+        w = O.default_world()
+        w.light = O.RectangleLight(O.color(1, 1, 1), K.point(c["corner"]), K.vector(c["u"]), c["steps"],
+                                   K.vector(c["v"]), c["steps"], ("cycle", c["jitter_cycle"]))
+        K.assert_exact(w.intensity_at(K.point(pt)), expected)
+
+
+def test_phong_lighting(kat):  # light/phong_lighting.rs:78-194, 238-271
+    P = kat["phong"]
+    m = O.Material()
+    for c in P["cases"]:
+        w = O.World([], O.PointLight(K.point(c["light"]), O.color(1, 1, 1)))
+        got = w.phong_lighting(m, O.point(0, 0, 0), K.vector(c["eye"]), K.vector(c["normal"]), c["intensity"])
+        if "expect_exact" in c:
+            e = c["expect_exact"]
+            e = [K.val(e)] * 3 if isinstance(e, str) else e
+            K.assert_exact(got, K.vec(e))
+        else:
+            K.assert_eps(got, c["expect_eps"])
+    a = P["attenuation"]
+    w = O.World([], O.PointLight(K.point(a["light"]), O.color(1, 1, 1)))
+    m = O.Material(ambient=0.1, diffuse=0.9, specular=0.0, color=(1, 1, 1))
+    for intensity, expected in a["cases"]:
+        K.assert_eps(w.phong_lighting(m, K.point(a["point"]), K.vector(a["eye"]), K.vector(a["normal"]), intensity),
+                     expected)
+
+
+def test_hashed_jitter_is_in_open_closed_unit_interval():
+    vals = [O.jitter_value(O.jitter_hash(0x5EED5EED, p, 1, c, d)) for p in range(50) for c in range(20) for d in (0, 1)]
+    assert min(vals) > 0.0 and max(vals) <= 1.0
+    assert O.jitter_value(0xFFFFFFFF) == f32(1.0)
+    assert O.jitter_value(0) == f32(2.0 ** -23)
+    assert abs(float(np.mean(vals)) - 0.5) < 0.02
+
+
+# ------------------------------------------------------------------ camera
+def test_render_world(kat):  # camera.rs:156-167
+    c = kat["camera"]["render_world"]
+    cam = O.Camera(*c["size"], K.CONSTS["PI"] / f32(2.0),
+                   O.view_transform(K.point(c["from"]), K.point(c["to"]), K.vector(c["up"])))
+    img, rays = cam.render(O.default_world(), c["depth"])
+    K.assert_eps(img[c["pixel"][1], c["pixel"][0]], c["expect_eps"])
+    # camera.rs:80-81: the last row and column are never traced
+    assert np.all(img[-1, :, :] == 0) and np.all(img[:, -1, :] == 0)
+    assert rays >= 100
+    img4, rays4 = cam.render(O.default_world(), c["depth"], threads=4)
+    assert np.array_equal(img, img4) and rays == rays4
+
+
+# ------------------------------------------------------------------ canvas
+def test_scale_color_and_ppm(kat):  # canvas.rs:218-278
+    C = kat["canvas"]
+    for v, expected in C["scale_color"]["cases"]:
+        assert O.scale_color(v) == expected
+    c = C["pixel_data"]
+    w, h = c["size"]
+    img = np.zeros((h, w, 3), dtype=f32)
+    for x, y, col in c["pixels"]:
+        img[y, x] = col
+    assert O.to_ppm(img).decode().split("\n")[:-1] == c["lines"]
+    c = C["long_lines"]
+    w, h = c["size"]
+    img = np.zeros((h, w, 3), dtype=f32)
+    img[:, :] = np.array(c["fill"], dtype=f32)
+    text = O.to_ppm(img).decode()
+    assert text.endswith("\n")
+    assert text.split("\n")[:-1] == c["lines"]
+    c = C["header"]
+    w, h = c["size"]
+    assert O.to_ppm(np.zeros((h, w, 3), dtype=f32)).decode().split("\n")[:3] == c["lines"]
