@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline workload on MI355X.
+
+A "step" is one Camera::render of BASELINE.json's metric configuration: the
+soft_shadows demo scene (area light 10x10, 4 objects, depth 5) at 4096x4096
+("C3"), with the pinned hashed jitter.  On N GPUs (one process per GPU) the
+image's 64-row bands are dealt round-robin to the ranks, each rank renders its
+bands with the HIP kernel, and the bands are gathered to rank 0 over RCCL --
+strong scaling: the job is one image whatever N is.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  value = rays traced by all ranks / wall time.
+`roofline` is the contractual HBM figure of SURVEY.md 8(d) (algorithmic bytes =
+rays x n_objects x 64 B + 48 B per shaded hit + 12 B per pixel) over the render
+kernel's mean HIP-event duration; `cpu_baseline` is the CPU oracle timed on a
+bounded row sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=4096, help="image edge in pixels (metric config: 4096)")
+    ap.add_argument("--scene", default="soft_shadows", help="scene function in ray_tracer_challenge_amd.scenes")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU oracle sample (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the sampled-row parity check before timing")
+    return ap.parse_args()
+
+
+def cpu_baseline(world, camera, depth, budget_s):
+    """Times the CPU oracle (a port of the reference's serial loop) on sampled row blocks of the same frame."""
+    from oracle import oracle as O
+    from tests import helpers as H
+    cores = len(os.sched_getaffinity(0))
+    ow, oc = H.oracle_world(world), H.oracle_camera(camera)
+    h = camera.height
+    # calibrate on one row in the busy part of the image, single thread
+    t0 = time.perf_counter()
+    _, rays1 = oc.render(ow, depth, threads=1, rows=(h * 5 // 8, h * 5 // 8 + 1))
+    t1 = time.perf_counter() - t0
+    single = rays1 / t1 / 1e6 if t1 > 0 else 0.0
+    # row blocks spread evenly over the image so the sample sees sky, floor and spheres in proportion
+    rows_affordable = max(cores, int(budget_s / max(t1, 1e-6) * cores * 0.8))
+    n_blocks = 16
+    block = max(1, min(h // n_blocks, rows_affordable // n_blocks))
+    total_rays, total_t, sampled = 0, 0.0, 0
+    for b in range(n_blocks):
+        y0 = (h * b) // n_blocks + (h // n_blocks - block) // 2
+        t0 = time.perf_counter()
+        _, r = oc.render(ow, depth, threads=cores, rows=(y0, y0 + block))
+        total_t += time.perf_counter() - t0
+        total_rays += r
+        sampled += block
+    return {
+        "value": round(total_rays / total_t / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": "%d rows (16 blocks of %d rows spread over the %dx%d frame), %d rays, %.1f s wall; "
+                  "row-parallel C++ oracle (no per-ray heap allocation or dyn dispatch: an upper bound on the Rust "
+                  "reference)" % (sampled, block, camera.width, h, total_rays, total_t),
+        "single_thread_value": round(single, 3),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import ray_tracer_challenge_amd as P
+    from ray_tracer_challenge_amd import scenes
+    from ray_tracer_challenge_amd.dist import BandGather
+    from ray_tracer_challenge_amd.renderer import Renderer
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world_size, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    world, camera, depth = getattr(scenes, args.scene)(args.size, args.size)
+    renderer = Renderer(world, camera, device=local_rank)
+    part = Renderer.partition(64, world_size, rank)
+    gather = BandGather(camera.height, camera.width, 3, torch.float32, device, rank, world_size)
+    out = gather.local_view()
+    assert out.shape[0] == renderer.rows(part)
+
+    def step():
+        renderer.render(depth, out=out, part=part)
+        return gather.gather()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    renderer.stats()  # drain the event ring so the timed launches are averaged alone
+
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        image = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    st = renderer.stats()  # counters of the last launch + mean kernel time over the K timed launches
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    counts = torch.tensor([st["rays"], st["shaded_hits"], st["pixels"]], dtype=torch.float64, device=device)
+    kern = torch.tensor([st["kernel_ms"]], dtype=torch.float64, device=device)
+    if world_size > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(kern, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    rays, shaded, pixels = (int(v) for v in counts.tolist())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        n_obj = len(world.objects)
+        # roofline of the dominant kernel (render_kernel) on THIS rank: per-launch algorithmic bytes / mean duration
+        algo_bytes = st["rays"] * n_obj * 64 + st["shaded_hits"] * 48 + st["pixels"] * 12
+        achieved = algo_bytes / (st["kernel_ms"] * 1e-3) / 1e9 if st["kernel_ms"] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath) and world_size == 1 and args.size == 4096 and args.scene == "soft_shadows":
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        verify = None
+        if not args.no_verify:
+            verify = verify_rows(image, world, camera, depth)
+        line = {
+            "metric": "Mrays/s", "value": round(rays / (elapsed / args.steps) / 1e6, 2), "unit": "Mrays/s",
+            "mpixels_per_s": round(pixels / (elapsed / args.steps) / 1e6, 3),
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: soft_shadows demo scene (10x10 area light, 4 objects, depth 5), %dx%d, hashed "
+                                   "jitter seed 0x5EED5EED" % (args.size, args.size) if args.scene == "soft_shadows"
+                       else "%s %dx%d" % (args.scene, args.size, args.size),
+                       "rays_per_frame": rays, "shaded_hits_per_frame": shaded, "pixels_per_frame": pixels,
+                       "partition": "64-row bands round-robin over %d rank(s)%s" % (
+                           world_size, ", RCCL gather of f32 rows to rank 0" if world_size > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "render_kernel", "kernel_ms": round(st["kernel_ms"], 4),
+                         "algorithmic_bytes": algo_bytes,
+                         "note": "contractual figure (SURVEY.md 8d): rays x n_objects x 64 B + 48 B/shaded hit + "
+                                 "12 B/pixel; the scene is SGPR/cache resident so physical HBM traffic is ~ the "
+                                 "canvas store and frac may exceed 1; the physical limiter is FP32 VALU issue"},
+            "parity_check": verify,
+        }
+        if args.cpu_seconds > 0 and world_size == 1:
+            line["cpu_baseline"] = cpu_baseline(world, camera, depth, args.cpu_seconds)
+        elif world_size > 1:
+            line["cpu_baseline"] = None  # measured on rank 0 at N=1 only
+        print(json.dumps(line), flush=True)
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def verify_rows(image, world, camera, depth):
+    """Before reporting a number: a few full rows of the timed frame against the CPU oracle, bit-exact."""
+    import numpy as np
+
+    from tests import helpers as H
+    ow, oc = H.oracle_world(world), H.oracle_camera(camera)
+    h = camera.height
+    cores = len(os.sched_getaffinity(0))
+    checked = []
+    for y in sorted({h // 3, (h * 5) // 8, h - 2}):
+        if y < 0 or y >= h:
+            continue
+        exp, _ = oc.render(ow, depth, threads=cores, rows=(y, y + 1))
+        got = image[y].cpu().numpy()
+        if not np.array_equal(got == exp[y], np.ones_like(got, dtype=bool)):
+            raise SystemExit("parity check FAILED on row %d: refusing to report a throughput number" % y)
+        checked.append(y)
+    return {"rows_checked_bit_exact_vs_oracle": checked}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,237 @@
+/*
+ * rtc.h -- C ABI of the MI355X-native render path (librtc_amd.so).
+ *
+ * This is the drop-in boundary for ONE hot path of
+ * garfieldnate/ray_tracer_challenge: the body of
+ *
+ *     pub fn render(&self, world: World, reflection_recursion_depth: i16) -> Canvas
+ *                                                  (lib/src/camera.rs:76-91)
+ *
+ * and everything it calls per pixel (ray_for_pixel, World::color_at / intersect /
+ * shade_hit / is_shadowed / reflected_color / refracted_color, the Sphere /
+ * Plane / Cube / Cylinder intersectors, phong_lighting).  The reference has no
+ * FFI of its own; INTEGRATION.md shows the `extern "C"` block a maintainer
+ * would add to camera.rs to bind these entry points.
+ *
+ * Plain C: POD structs, pointers and sizes only.  No C++ or torch types cross
+ * this boundary.  The library owns all device memory it allocates; the caller
+ * owns every buffer it passes in.  All matrices are row-major 4x4 f32.
+ *
+ * File:line citations are relative to /root/reference/lib/src.
+ */
+#ifndef RTC_H
+#define RTC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTC_ABI_VERSION 1
+/* maximum reflection_recursion_depth accepted (reference default: 5, constants.rs:4) */
+#define RTC_MAX_DEPTH 8
+
+typedef enum rtc_status {
+    RTC_OK = 0,
+    RTC_ERR_INVALID_ARG = -1, /* null pointer, zero size, depth out of range ...        */
+    RTC_ERR_UNSUPPORTED = -2, /* unknown shape kind, projective transform, closure jitter */
+    RTC_ERR_NO_LIGHT = -3,    /* world.rs:66 "World light should be set"                 */
+    RTC_ERR_DEVICE = -4,      /* HIP runtime error; text via rtc_last_error()            */
+    RTC_ERR_NO_DEVICE = -5    /* no gfx950 device visible: there is NO CPU fallback      */
+} rtc_status;
+
+/* shape/{sphere,plane,cube,cylinder}.rs */
+enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3 };
+/* light/{point_light,rectangle_light}.rs */
+enum { RTC_LIGHT_POINT = 0, RTC_LIGHT_RECT = 1 };
+/* RectangleLight jitter source.  The reference takes an arbitrary closure
+ * (rectangle_light.rs:27,44-47); a device cannot call one, so two pinned
+ * sources are offered: the constant of test/utils.rs:15-17, and a counter-based
+ * hash (DESIGN.md "Jitter") standing in for thread_rng(). */
+enum { RTC_JITTER_CONSTANT = 0, RTC_JITTER_HASHED = 2 };
+
+/* material.rs:18-51 (pattern: out of scope) */
+typedef struct rtc_material {
+    float color[3];
+    float ambient;
+    float diffuse;
+    float specular;
+    float shininess;
+    float reflective;
+    float transparency;
+    float refractive_index;
+} rtc_material;
+
+/* One entry of World.objects (world.rs:19), flattened.  `inv` is exactly
+ * BaseShape.t_inverse (shape/base_shape.rs:17,58); the inverse-transpose is
+ * its transpose and is not stored.  Object order is World.objects order: hit
+ * tie-breaking depends on it (world.rs:58, intersection.rs:30-35). */
+typedef struct rtc_object {
+    int32_t kind;         /* RTC_SPHERE ... */
+    int32_t casts_shadow; /* BaseShape.casts_shadow, base_shape.rs:14 */
+    int32_t closed;       /* Cylinder.closed,  cylinder.rs:18 */
+    float min_y;          /* Cylinder.minimum_y (ignored for other kinds) */
+    float max_y;          /* Cylinder.maximum_y */
+    float inv[16];
+    rtc_material material;
+} rtc_object;
+
+/* light/point_light.rs:7-10 and light/rectangle_light.rs:12-31 AFTER
+ * RectangleLight::new: u_vec/v_vec are the per-cell vectors (already divided by
+ * the step counts, :51-52) and `position` is the rectangle centre (:57) or the
+ * point light's position.  Build with rtc_point_light()/rtc_rectangle_light(). */
+typedef struct rtc_light {
+    int32_t kind;
+    float intensity[3];
+    float position[4];
+    float corner[4];
+    float u_vec[4];
+    float v_vec[4];
+    int32_t u_steps;
+    int32_t v_steps;
+    int32_t jitter_mode;
+    float jitter_const;
+    uint32_t jitter_seed;
+} rtc_light;
+
+/* world.rs:18-21 */
+typedef struct rtc_scene {
+    uint32_t n_objects;
+    const rtc_object* objects;
+    const rtc_light* light; /* NULL -> RTC_ERR_NO_LIGHT */
+} rtc_scene;
+
+/* camera.rs:8-21 after Camera::new.  Build with rtc_camera_new(). */
+typedef struct rtc_camera {
+    uint32_t width;
+    uint32_t height;
+    float field_of_view;
+    float half_width;
+    float half_height;
+    float pixel_size;
+    float inv[16]; /* transform_inverse */
+} rtc_camera;
+
+/* Row partition of one image over several devices (one process per GPU).
+ * The image is cut into bands of `band_rows` rows; band b belongs to part
+ * (b mod n_parts).  A part's rows are stored compactly, band after band. */
+typedef struct rtc_partition {
+    uint32_t band_rows; /* 0 -> 64 */
+    uint32_t n_parts;   /* 0 -> 1  */
+    uint32_t part;
+} rtc_partition;
+
+typedef struct rtc_stats {
+    uint64_t rays;        /* World::intersect evaluations of the last launch (primary, shadow, reflect, refract) */
+    uint64_t shaded_hits; /* shade_hit evaluations of the last launch (world.rs:62)                           */
+    uint64_t pixels;      /* traced pixels: (w-1)*(h-1) restricted to the rows rendered                        */
+    float kernel_ms;      /* mean HIP-event time of the render kernel over `launches`                          */
+    uint32_t launches;    /* render launches since the previous rtc_ctx_stats call                             */
+    uint32_t rows;        /* rows written to the output buffer                                                 */
+} rtc_stats;
+
+typedef struct rtc_ctx rtc_ctx;
+
+/* ------------------------------------------------------------------------
+ * Host-side scene math.  Restates matrix.rs / transformations.rs /
+ * tuple.rs / camera.rs:23-74 operation for operation so that the flattened
+ * scene handed to the kernel is bit-identical to what the Rust structs hold.
+ * Pure host code; usable without a GPU.
+ * ---------------------------------------------------------------------- */
+void rtc_translation(float x, float y, float z, float out[16]);                 /* transformations.rs:4-6   */
+void rtc_scaling(float x, float y, float z, float out[16]);                     /* :8-10  */
+void rtc_rotation_x(float radians, float out[16]);                              /* :12-21 */
+void rtc_rotation_y(float radians, float out[16]);                              /* :23-32 */
+void rtc_rotation_z(float radians, float out[16]);                              /* :34-43 */
+void rtc_shearing(float xy, float xz, float yx, float yz, float zx, float zy, float out[16]); /* :46-53 */
+void rtc_view_transform(const float from[4], const float to[4], const float up[4], float out[16]); /* :57-68 */
+void rtc_mat_mul(const float a[16], const float b[16], float out[16]);          /* matrix.rs:86-103  */
+void rtc_mat_vec(const float a[16], const float v[4], float out[4]);            /* matrix.rs:73-84   */
+void rtc_mat_transpose(const float* a, int n, float* out);                      /* matrix.rs:134-143 */
+float rtc_mat_determinant(const float* a, int n);                               /* matrix.rs:145-160 */
+void rtc_mat_submatrix(const float* a, int n, int row, int col, float* out);    /* matrix.rs:163-182 */
+float rtc_mat_minor(const float* a, int n, int row, int col);                   /* matrix.rs:194-196 */
+float rtc_mat_cofactor(const float* a, int n, int row, int col);                /* matrix.rs:184-192 */
+rtc_status rtc_mat_inverse(const float* a, int n, float* out);                  /* matrix.rs:201-212 */
+float rtc_magnitude(const float v[4]);                                          /* tuple.rs:29-33 */
+void rtc_norm(const float v[4], float out[4]);                                  /* tuple.rs:34-43 */
+float rtc_dot(const float a[4], const float b[4]);                              /* tuple.rs:44-46 */
+void rtc_cross(const float a[4], const float b[4], float out[4]);               /* tuple.rs:47-55 */
+void rtc_reflect(const float in[4], const float normal[4], float out[4]);       /* ray.rs:42-44   */
+
+/* Material::default(), material.rs:53-57 */
+void rtc_material_default(rtc_material* out);
+/* Shape::build(transform, material): stores transform.inverse() (base_shape.rs:56-60).
+ * Cylinder bounds default to -inf/+inf, open (cylinder.rs:34-43). */
+rtc_status rtc_object_init(rtc_object* out, int32_t kind, const float transform[16], const rtc_material* m);
+void rtc_point_light(const float position[4], const float intensity[3], rtc_light* out);   /* point_light.rs:12-19 */
+rtc_status rtc_rectangle_light(const float intensity[3], const float corner[4], const float u_vec[4],
+                               int32_t u_steps, const float v_vec[4], int32_t v_steps, int32_t jitter_mode,
+                               float jitter_const, uint32_t jitter_seed, rtc_light* out); /* rectangle_light.rs:33-58 */
+rtc_status rtc_camera_new(uint32_t width, uint32_t height, float field_of_view, const float transform[16],
+                          rtc_camera* out);                                               /* camera.rs:23-56 */
+void rtc_ray_for_pixel(const rtc_camera* c, uint32_t x, uint32_t y, float origin[4], float direction[4]); /* camera.rs:60-74 */
+
+/* ------------------------------------------------------------------------
+ * Device path.  Every function below needs a gfx950 GPU and fails with
+ * RTC_ERR_NO_DEVICE otherwise.
+ * ---------------------------------------------------------------------- */
+
+/* Camera::render (camera.rs:76-91) in one call: uploads the scene, renders the
+ * whole image on device `device`, copies it back.  out_rgb: caller-owned host
+ * buffer of width*height*3 f32, row-major [y][x][rgb], fully written -- the
+ * last row and last column stay black exactly as in the reference
+ * (camera.rs:80-81).  stats may be NULL. */
+rtc_status rtc_render(const rtc_scene* scene, const rtc_camera* camera, int32_t depth, int32_t device,
+                      float* out_rgb, rtc_stats* stats);
+
+/* Persistent context: scene resident in HBM, output left on the device. */
+rtc_status rtc_ctx_create(int32_t device, rtc_ctx** out);
+void rtc_ctx_destroy(rtc_ctx* ctx);
+/* Flattens the scene to structure-of-arrays records and uploads it. */
+rtc_status rtc_ctx_set_scene(rtc_ctx* ctx, const rtc_scene* scene, const rtc_camera* camera);
+/* Rows this partition produces (sum of its bands' heights). */
+uint32_t rtc_partition_rows(uint32_t height, const rtc_partition* part);
+/* Launches the render kernel on `stream` (a hipStream_t; NULL = default
+ * stream) and returns without synchronising.  d_out_rgb: DEVICE pointer to
+ * rtc_partition_rows()*width*3 f32.  part may be NULL (whole image). */
+rtc_status rtc_ctx_render(rtc_ctx* ctx, int32_t depth, const rtc_partition* part, void* d_out_rgb, void* stream);
+/* Waits for every rtc_ctx_render issued on this context so far and reports the
+ * last launch's counters plus the mean kernel time since the previous call. */
+rtc_status rtc_ctx_stats(rtc_ctx* ctx, rtc_stats* out);
+/* canvas.rs:39-43 scale_color on the device: n f32 channel values -> n bytes
+ * ((c*255).min(255).max(0) as u8).  Both pointers are device pointers. */
+rtc_status rtc_ctx_quantize(rtc_ctx* ctx, const void* d_rgb, uint64_t n, void* d_out_u8, void* stream);
+
+/* Batched World::color_at (world.rs:88-101) for caller-supplied rays; ray i
+ * uses pixel index i as its jitter key.  Host buffers: origins/directions
+ * n*4 f32, out n*3 f32. */
+rtc_status rtc_color_at(const rtc_scene* scene, const float* origins, const float* directions, uint32_t n,
+                        int32_t depth, int32_t device, float* out_rgb);
+/* Batched Light::intensity_at (light.rs:10) for n world points (n*4 f32). */
+rtc_status rtc_intensity_at(const rtc_scene* scene, const float* points, uint32_t n, int32_t device,
+                            float* out);
+/* Batched World::is_shadowed (world.rs:104-119): light_positions, points n*4 f32; out n int32 (0/1). */
+rtc_status rtc_is_shadowed(const rtc_scene* scene, const float* light_positions, const float* points, uint32_t n,
+                           int32_t device, int32_t* out);
+/* f32::powf as the reference's Linux build computes it (phong_lighting.rs:56),
+ * evaluated on the device; host buffers of n f32. */
+rtc_status rtc_powf(const float* x, const float* y, uint32_t n, int32_t device, float* out);
+
+/* Canvas::to_ppm (canvas.rs:58-96) on an f32 image already on the host:
+ * returns a malloc'd buffer (free with rtc_free) holding the P3 text. */
+rtc_status rtc_to_ppm(const float* rgb, uint32_t width, uint32_t height, char** out_text, uint64_t* out_len);
+void rtc_free(void* p);
+
+/* Thread-local text of the last error returned on this thread. */
+const char* rtc_last_error(void);
+int32_t rtc_abi_version(void);
+/* Number of usable gfx950 devices (0 if none / no HIP runtime). */
+int32_t rtc_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTC_H */

@@ -1,0 +1,13 @@
+"""ray_tracer_challenge_amd -- MI355X-native render path for garfieldnate/ray_tracer_challenge.
+
+Scope: Camera::render and everything it calls per pixel, as a
+hand-written HIP kernel for gfx950 behind the C ABI in include/rtc.h, plus the
+host-side scene math needed to feed it bit-identical inputs.  This package is
+the Python mirror of the reference's World/Shape/Material/Camera/Canvas API on
+top of that ABI.  The shared library must be built first
+(`python -m ray_tracer_challenge_amd.build`); there is no fallback path.
+"""
+from ._lib import RtcError, lib  # noqa: F401
+from .api import *  # noqa: F401,F403
+from .api import (Camera, Canvas, Cube, Cylinder, Material, Plane, PointLight, RectangleLight, Shape, Sphere,  # noqa: F401
+                  World, default_world, device_count, glass, metal, powf, powf_host)

@@ -1,0 +1,141 @@
+"""ctypes declarations for librtc_amd.so -- a 1:1 transcription of include/rtc.h.
+
+The library must have been built (python -m ray_tracer_challenge_amd.build, or
+__graft_entry__.build()).  There is no Python or CPU fallback: if the shared
+object is missing the import fails, and every device entry point returns
+RTC_ERR_NO_DEVICE when no GPU is visible.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librtc_amd.so")
+
+RTC_OK = 0
+RTC_ERR_INVALID_ARG, RTC_ERR_UNSUPPORTED, RTC_ERR_NO_LIGHT, RTC_ERR_DEVICE, RTC_ERR_NO_DEVICE = -1, -2, -3, -4, -5
+RTC_SPHERE, RTC_PLANE, RTC_CUBE, RTC_CYLINDER = 0, 1, 2, 3
+RTC_LIGHT_POINT, RTC_LIGHT_RECT = 0, 1
+RTC_JITTER_CONSTANT, RTC_JITTER_HASHED = 0, 2
+RTC_MAX_DEPTH = 8
+
+FP = C.POINTER(C.c_float)
+
+
+class rtc_material(C.Structure):
+    _fields_ = [("color", C.c_float * 3), ("ambient", C.c_float), ("diffuse", C.c_float),
+                ("specular", C.c_float), ("shininess", C.c_float), ("reflective", C.c_float),
+                ("transparency", C.c_float), ("refractive_index", C.c_float)]
+
+
+class rtc_object(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("casts_shadow", C.c_int32), ("closed", C.c_int32),
+                ("min_y", C.c_float), ("max_y", C.c_float), ("inv", C.c_float * 16),
+                ("material", rtc_material)]
+
+
+class rtc_light(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("intensity", C.c_float * 3), ("position", C.c_float * 4),
+                ("corner", C.c_float * 4), ("u_vec", C.c_float * 4), ("v_vec", C.c_float * 4),
+                ("u_steps", C.c_int32), ("v_steps", C.c_int32), ("jitter_mode", C.c_int32),
+                ("jitter_const", C.c_float), ("jitter_seed", C.c_uint32)]
+
+
+class rtc_scene(C.Structure):
+    _fields_ = [("n_objects", C.c_uint32), ("objects", C.POINTER(rtc_object)),
+                ("light", C.POINTER(rtc_light))]
+
+
+class rtc_camera(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("field_of_view", C.c_float),
+                ("half_width", C.c_float), ("half_height", C.c_float), ("pixel_size", C.c_float),
+                ("inv", C.c_float * 16)]
+
+
+class rtc_partition(C.Structure):
+    _fields_ = [("band_rows", C.c_uint32), ("n_parts", C.c_uint32), ("part", C.c_uint32)]
+
+
+class rtc_stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("shaded_hits", C.c_uint64), ("pixels", C.c_uint64),
+                ("kernel_ms", C.c_float), ("launches", C.c_uint32), ("rows", C.c_uint32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/rtc.h
+SIGNATURES = {
+    "rtc_translation": (None, [C.c_float] * 3 + [FP]),
+    "rtc_scaling": (None, [C.c_float] * 3 + [FP]),
+    "rtc_rotation_x": (None, [C.c_float, FP]),
+    "rtc_rotation_y": (None, [C.c_float, FP]),
+    "rtc_rotation_z": (None, [C.c_float, FP]),
+    "rtc_shearing": (None, [C.c_float] * 6 + [FP]),
+    "rtc_view_transform": (None, [FP, FP, FP, FP]),
+    "rtc_mat_mul": (None, [FP, FP, FP]),
+    "rtc_mat_vec": (None, [FP, FP, FP]),
+    "rtc_mat_transpose": (None, [FP, C.c_int, FP]),
+    "rtc_mat_determinant": (C.c_float, [FP, C.c_int]),
+    "rtc_mat_submatrix": (None, [FP, C.c_int, C.c_int, C.c_int, FP]),
+    "rtc_mat_minor": (C.c_float, [FP, C.c_int, C.c_int, C.c_int]),
+    "rtc_mat_cofactor": (C.c_float, [FP, C.c_int, C.c_int, C.c_int]),
+    "rtc_mat_inverse": (C.c_int, [FP, C.c_int, FP]),
+    "rtc_magnitude": (C.c_float, [FP]),
+    "rtc_norm": (None, [FP, FP]),
+    "rtc_dot": (C.c_float, [FP, FP]),
+    "rtc_cross": (None, [FP, FP, FP]),
+    "rtc_reflect": (None, [FP, FP, FP]),
+    "rtc_material_default": (None, [C.POINTER(rtc_material)]),
+    "rtc_object_init": (C.c_int, [C.POINTER(rtc_object), C.c_int32, FP, C.POINTER(rtc_material)]),
+    "rtc_point_light": (None, [FP, FP, C.POINTER(rtc_light)]),
+    "rtc_rectangle_light": (C.c_int, [FP, FP, FP, C.c_int32, FP, C.c_int32, C.c_int32, C.c_float, C.c_uint32,
+                                      C.POINTER(rtc_light)]),
+    "rtc_camera_new": (C.c_int, [C.c_uint32, C.c_uint32, C.c_float, FP, C.POINTER(rtc_camera)]),
+    "rtc_ray_for_pixel": (None, [C.POINTER(rtc_camera), C.c_uint32, C.c_uint32, FP, FP]),
+    "rtc_render": (C.c_int, [C.POINTER(rtc_scene), C.POINTER(rtc_camera), C.c_int32, C.c_int32, FP,
+                             C.POINTER(rtc_stats)]),
+    "rtc_ctx_create": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)]),
+    "rtc_ctx_destroy": (None, [C.c_void_p]),
+    "rtc_ctx_set_scene": (C.c_int, [C.c_void_p, C.POINTER(rtc_scene), C.POINTER(rtc_camera)]),
+    "rtc_partition_rows": (C.c_uint32, [C.c_uint32, C.POINTER(rtc_partition)]),
+    "rtc_ctx_render": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(rtc_partition), C.c_void_p, C.c_void_p]),
+    "rtc_ctx_stats": (C.c_int, [C.c_void_p, C.POINTER(rtc_stats)]),
+    "rtc_ctx_quantize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "rtc_color_at": (C.c_int, [C.POINTER(rtc_scene), FP, FP, C.c_uint32, C.c_int32, C.c_int32, FP]),
+    "rtc_intensity_at": (C.c_int, [C.POINTER(rtc_scene), FP, C.c_uint32, C.c_int32, FP]),
+    "rtc_is_shadowed": (C.c_int, [C.POINTER(rtc_scene), FP, FP, C.c_uint32, C.c_int32, C.POINTER(C.c_int32)]),
+    "rtc_powf": (C.c_int, [FP, FP, C.c_uint32, C.c_int32, FP]),
+    "rtc_to_ppm": (C.c_int, [FP, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "rtc_free": (None, [C.c_void_p]),
+    "rtc_last_error": (C.c_char_p, []),
+    "rtc_abi_version": (C.c_int32, []),
+    "rtc_device_count": (C.c_int32, []),
+}
+# diagnostic export, not in rtc.h: host compile of the device powf restatement
+EXTRA = {"rtc_powf_host": (None, [FP, FP, C.c_uint32, FP])}
+
+_lib = None
+
+
+class RtcError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("rtc status %d: %s" % (status, message))
+        self.status = status
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -m ray_tracer_challenge_amd.build` "
+                "(there is no CPU/Python fallback for the render path)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in list(SIGNATURES.items()) + list(EXTRA.items()):
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != RTC_OK:
+        raise RtcError(status, lib().rtc_last_error().decode(errors="replace"))

@@ -1,0 +1,483 @@
+"""Host-side mirror of the reference's scene API for the render hot path.
+
+Names, argument meaning and defaults follow the Rust crate
+(lib/src/{tuple,matrix,transformations,material,world,camera,canvas}.rs and
+lib/src/{shape,light}/*.rs) so scenes and tests written against the reference
+carry over:  World{objects, light}, Sphere/Plane/Cube/Cylinder::build(transform,
+material), Material builder defaults, PointLight::new, RectangleLight::new,
+Camera::new, camera.render(world, depth) -> Canvas, canvas.to_ppm().
+
+Everything numeric happens behind the C ABI (include/rtc.h): scene math on the
+host in librtc_amd.so, rendering on the MI355X.  There is no fallback path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+f32 = np.float32
+
+
+def _a(x, n=None):
+    arr = np.ascontiguousarray(np.asarray(x, dtype=f32).reshape(-1))
+    if n is not None and arr.size != n:
+        raise ValueError("expected %d values, got %d" % (n, arr.size))
+    return arr
+
+
+def _p(arr):
+    return arr.ctypes.data_as(L.FP)
+
+
+# ------------------------------------------------------------- tuple.rs, color.rs
+def point(x, y, z):
+    """point!(x, y, z) -- tuple.rs:72-77"""
+    return np.array([x, y, z, 1.0], dtype=f32)
+
+
+def vector(x, y, z):
+    """vector!(x, y, z) -- tuple.rs:80-85"""
+    return np.array([x, y, z, 0.0], dtype=f32)
+
+
+def color(r, g, b):
+    """color!(r, g, b) -- color.rs:27-31"""
+    return np.array([r, g, b], dtype=f32)
+
+
+def magnitude(v):
+    x = _a(v, 4)
+    return f32(L.lib().rtc_magnitude(_p(x)))
+
+
+def norm(v):
+    x, out = _a(v, 4), np.zeros(4, dtype=f32)
+    L.lib().rtc_norm(_p(x), _p(out))
+    return out
+
+
+def dot(a, b):
+    x, y = _a(a, 4), _a(b, 4)
+    return f32(L.lib().rtc_dot(_p(x), _p(y)))
+
+
+def cross(a, b):
+    x, y, out = _a(a, 4), _a(b, 4), np.zeros(4, dtype=f32)
+    L.lib().rtc_cross(_p(x), _p(y), _p(out))
+    return out
+
+
+def reflect(in_vector, normal_vector):
+    """Ray::reflect -- ray.rs:42-44"""
+    x, y, out = _a(in_vector, 4), _a(normal_vector, 4), np.zeros(4, dtype=f32)
+    L.lib().rtc_reflect(_p(x), _p(y), _p(out))
+    return out
+
+
+# ------------------------------------------------- matrix.rs, transformations.rs
+def identity_4x4():
+    return np.eye(4, dtype=f32)
+
+
+def _mat(fn, *args):
+    out = np.zeros(16, dtype=f32)
+    fn(*args, _p(out))
+    return out.reshape(4, 4)
+
+
+def translation(x, y, z):
+    return _mat(L.lib().rtc_translation, float(f32(x)), float(f32(y)), float(f32(z)))
+
+
+def scaling(x, y, z):
+    return _mat(L.lib().rtc_scaling, float(f32(x)), float(f32(y)), float(f32(z)))
+
+
+def rotation_x(radians):
+    return _mat(L.lib().rtc_rotation_x, float(f32(radians)))
+
+
+def rotation_y(radians):
+    return _mat(L.lib().rtc_rotation_y, float(f32(radians)))
+
+
+def rotation_z(radians):
+    return _mat(L.lib().rtc_rotation_z, float(f32(radians)))
+
+
+def shearing(x_y, x_z, y_x, y_z, z_x, z_y):
+    return _mat(L.lib().rtc_shearing, *[float(f32(v)) for v in (x_y, x_z, y_x, y_z, z_x, z_y)])
+
+
+def view_transform(frm, to, approximate_up):
+    a, b, c = _a(frm, 4), _a(to, 4), _a(approximate_up, 4)
+    return _mat(L.lib().rtc_view_transform, _p(a), _p(b), _p(c))
+
+
+def mat_mul(a, b):
+    x, y = _a(a, 16), _a(b, 16)
+    return _mat(L.lib().rtc_mat_mul, _p(x), _p(y))
+
+
+def chain(*ms):
+    """`a * b * c` as Rust evaluates it: ((a*b)*c)."""
+    out = ms[0]
+    for m in ms[1:]:
+        out = mat_mul(out, m)
+    return out
+
+
+def mat_vec(a, v):
+    x, y, out = _a(a, 16), _a(v, 4), np.zeros(4, dtype=f32)
+    L.lib().rtc_mat_vec(_p(x), _p(y), _p(out))
+    return out
+
+
+def _sq(a):
+    a = np.asarray(a, dtype=f32)
+    return a.shape[0], _a(a)
+
+
+def transpose(a):
+    n, x = _sq(a)
+    out = np.zeros(n * n, dtype=f32)
+    L.lib().rtc_mat_transpose(_p(x), n, _p(out))
+    return out.reshape(n, n)
+
+
+def determinant(a):
+    n, x = _sq(a)
+    return f32(L.lib().rtc_mat_determinant(_p(x), n))
+
+
+def submatrix(a, row, col):
+    n, x = _sq(a)
+    out = np.zeros((n - 1) * (n - 1), dtype=f32)
+    L.lib().rtc_mat_submatrix(_p(x), n, row, col, _p(out))
+    return out.reshape(n - 1, n - 1)
+
+
+def minor(a, row, col):
+    n, x = _sq(a)
+    return f32(L.lib().rtc_mat_minor(_p(x), n, row, col))
+
+
+def cofactor(a, row, col):
+    n, x = _sq(a)
+    return f32(L.lib().rtc_mat_cofactor(_p(x), n, row, col))
+
+
+def inverse(a):
+    n, x = _sq(a)
+    out = np.zeros(n * n, dtype=f32)
+    L.check(L.lib().rtc_mat_inverse(_p(x), n, _p(out)))
+    return out.reshape(n, n)
+
+
+# ------------------------------------------------------------------ material.rs
+class Material:
+    """Material::builder() with the reference's defaults (material.rs:18-51)."""
+
+    FIELDS = ("ambient", "diffuse", "specular", "shininess", "reflective", "transparency", "refractive_index")
+
+    def __init__(self, color=(1.0, 1.0, 1.0), ambient=0.1, diffuse=0.9, specular=0.9, shininess=200.0,
+                 reflective=0.0, transparency=0.0, refractive_index=1.0):
+        self.color = tuple(float(c) for c in color)
+        self.ambient, self.diffuse, self.specular, self.shininess = ambient, diffuse, specular, shininess
+        self.reflective, self.transparency, self.refractive_index = reflective, transparency, refractive_index
+
+    def copy(self, **changes):
+        m = Material(self.color, *[getattr(self, k) for k in self.FIELDS])
+        for k, v in changes.items():
+            setattr(m, k, v)
+        return m
+
+    def _c(self):
+        m = L.rtc_material()
+        m.color[:] = [float(f32(c)) for c in self.color]
+        for k in self.FIELDS:
+            setattr(m, k, float(f32(getattr(self, k))))
+        return m
+
+
+def glass():
+    """constants.rs:12-17"""
+    return Material(transparency=1.0, refractive_index=1.52)
+
+
+def metal():
+    """constants.rs:50-62"""
+    return Material(color=(0.5, 0.5, 0.5), ambient=1.0, diffuse=0.6, reflective=0.1, specular=0.4, shininess=10.0)
+
+
+# ------------------------------------------------------------------- shape/*.rs
+class Shape:
+    """BaseShape + concrete kind (shape/base_shape.rs:13-20)."""
+
+    def __init__(self, kind, transform=None, material=None, casts_shadow=True, minimum_y=-np.inf,
+                 maximum_y=np.inf, closed=False):
+        self.kind = kind
+        self.transform = identity_4x4() if transform is None else np.asarray(transform, dtype=f32).reshape(4, 4)
+        self.material = Material() if material is None else material
+        self.casts_shadow = casts_shadow
+        self.minimum_y, self.maximum_y, self.closed = minimum_y, maximum_y, closed
+
+    # reference setter names
+    def set_transformation(self, t):
+        self.transform = np.asarray(t, dtype=f32).reshape(4, 4)
+
+    def set_material(self, m):
+        self.material = m
+
+    def set_casts_shadow(self, flag):
+        self.casts_shadow = flag
+
+    def transformation_inverse(self):
+        return np.array(list(self._c().inv), dtype=f32).reshape(4, 4)
+
+    def _c(self):
+        o = L.rtc_object()
+        t = _a(self.transform, 16)
+        m = self.material._c()
+        L.check(L.lib().rtc_object_init(C.byref(o), self.kind, _p(t), C.byref(m)))
+        o.casts_shadow = int(bool(self.casts_shadow))
+        o.closed = int(bool(self.closed))
+        o.min_y = float(f32(self.minimum_y))
+        o.max_y = float(f32(self.maximum_y))
+        return o
+
+
+def Sphere(transform=None, material=None, **kw):
+    """Sphere::build(transform, material) -- shape/sphere.rs:23-28"""
+    return Shape(L.RTC_SPHERE, transform, material, **kw)
+
+
+def Plane(transform=None, material=None, **kw):
+    """Plane::build -- shape/plane.rs:21-26"""
+    return Shape(L.RTC_PLANE, transform, material, **kw)
+
+
+def Cube(transform=None, material=None, **kw):
+    """Cube::build -- shape/cube.rs:31-36"""
+    return Shape(L.RTC_CUBE, transform, material, **kw)
+
+
+def Cylinder(transform=None, material=None, **kw):
+    """Cylinder::build; minimum_y / maximum_y / closed are its pub fields (shape/cylinder.rs:14-19)"""
+    return Shape(L.RTC_CYLINDER, transform, material, **kw)
+
+
+# ------------------------------------------------------------------- light/*.rs
+class PointLight:
+    """PointLight::new(position, intensity) -- light/point_light.rs:12-19"""
+
+    def __init__(self, position, intensity):
+        self.position, self.intensity = _a(position, 4), _a(intensity, 3)
+
+    def _c(self):
+        l = L.rtc_light()
+        L.lib().rtc_point_light(_p(self.position), _p(self.intensity), C.byref(l))
+        return l
+
+
+class RectangleLight:
+    """RectangleLight::new(intensity, corner, u_vec, u_steps, v_vec, v_steps, jitter_fn_opt)
+    -- light/rectangle_light.rs:33-58.
+
+    jitter: ("constant", c) mirrors test/utils.rs constant_jitter();
+            ("hashed", seed) stands in for jitter_fn_opt = None (thread_rng).
+            A Python callable (the closure form) cannot run on the device -> RtcError(UNSUPPORTED).
+    """
+
+    def __init__(self, intensity, corner, u_vec, u_steps, v_vec, v_steps, jitter=("hashed", 0x5EED5EED)):
+        self.intensity, self.corner = _a(intensity, 3), _a(corner, 4)
+        self.u_vec, self.v_vec = _a(u_vec, 4), _a(v_vec, 4)
+        self.u_steps, self.v_steps, self.jitter = int(u_steps), int(v_steps), jitter
+
+    def _c(self):
+        l = L.rtc_light()
+        if callable(self.jitter):
+            mode, const, seed = 1, 0.0, 0  # closure: rejected by the library
+        else:
+            kind, arg = self.jitter
+            if kind == "constant":
+                mode, const, seed = L.RTC_JITTER_CONSTANT, float(f32(arg)), 0
+            elif kind == "hashed":
+                mode, const, seed = L.RTC_JITTER_HASHED, 0.0, int(arg) & 0xFFFFFFFF
+            else:
+                mode, const, seed = 1, 0.0, 0
+        L.check(L.lib().rtc_rectangle_light(_p(self.intensity), _p(self.corner), _p(self.u_vec), self.u_steps,
+                                            _p(self.v_vec), self.v_steps, mode, const, seed, C.byref(l)))
+        return l
+
+    # fields the reference exposes after construction
+    @property
+    def position(self):
+        return np.array(list(self._c().position), dtype=f32)
+
+    @property
+    def cell_u_vec(self):
+        return np.array(list(self._c().u_vec), dtype=f32)
+
+    @property
+    def cell_v_vec(self):
+        return np.array(list(self._c().v_vec), dtype=f32)
+
+    @property
+    def cells(self):
+        return self.u_steps * self.v_steps
+
+
+# --------------------------------------------------------------------- world.rs
+class _CScene:
+    """Keeps the ctypes arrays alive for the lifetime of a call."""
+
+    def __init__(self, world):
+        n = len(world.objects)
+        self.objects = (L.rtc_object * max(n, 1))()
+        for i, o in enumerate(world.objects):
+            self.objects[i] = o._c()
+        self.light = world.light._c() if world.light is not None else None
+        self.scene = L.rtc_scene()
+        self.scene.n_objects = n
+        self.scene.objects = C.cast(self.objects, C.POINTER(L.rtc_object))
+        self.scene.light = C.pointer(self.light) if self.light is not None else None
+
+
+class World:
+    """World { objects, light } -- world.rs:18-21"""
+
+    def __init__(self, objects=(), light=None):
+        self.objects = list(objects)
+        self.light = light
+
+    def _c(self):
+        return _CScene(self)
+
+    def color_at(self, origins, directions, depth, device=0):
+        """World::color_at for a batch of rays (world.rs:88-101); (n,4),(n,4) -> (n,3)."""
+        o = np.ascontiguousarray(np.asarray(origins, dtype=f32).reshape(-1, 4))
+        d = np.ascontiguousarray(np.asarray(directions, dtype=f32).reshape(-1, 4))
+        out = np.zeros((o.shape[0], 3), dtype=f32)
+        cs = self._c()
+        L.check(L.lib().rtc_color_at(C.byref(cs.scene), _p(o), _p(d), o.shape[0], int(depth), device, _p(out)))
+        return out
+
+    def intensity_at(self, points, device=0):
+        """Light::intensity_at for a batch of points (light/light.rs:10)."""
+        p = np.ascontiguousarray(np.asarray(points, dtype=f32).reshape(-1, 4))
+        out = np.zeros(p.shape[0], dtype=f32)
+        cs = self._c()
+        L.check(L.lib().rtc_intensity_at(C.byref(cs.scene), _p(p), p.shape[0], device, _p(out)))
+        return out
+
+    def is_shadowed(self, light_positions, points, device=0):
+        """World::is_shadowed for a batch (world.rs:104-119)."""
+        l = np.ascontiguousarray(np.asarray(light_positions, dtype=f32).reshape(-1, 4))
+        p = np.ascontiguousarray(np.asarray(points, dtype=f32).reshape(-1, 4))
+        out = np.zeros(p.shape[0], dtype=np.int32)
+        cs = self._c()
+        L.check(L.lib().rtc_is_shadowed(C.byref(cs.scene), _p(l), _p(p), p.shape[0], device,
+                                        out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out.astype(bool)
+
+
+def default_world():
+    """World::default() -- world.rs:32-48"""
+    s1 = Sphere(identity_4x4(), Material(color=(0.8, 1.0, 0.6), diffuse=0.7, specular=0.2))
+    s2 = Sphere(scaling(0.5, 0.5, 0.5), Material())
+    return World([s1, s2], PointLight(point(-10.0, 10.0, -10.0), color(1, 1, 1)))
+
+
+# -------------------------------------------------------------------- canvas.rs
+class Canvas:
+    """Canvas (canvas.rs:6-10) over an (h, w, 3) float32 array."""
+
+    def __init__(self, width, height, data=None):
+        self.width, self.height = int(width), int(height)
+        self.data = np.zeros((self.height, self.width, 3), dtype=f32) if data is None else data
+
+    def write_pixel(self, x, y, c):
+        if x <= self.width and y <= self.height:  # canvas.rs:27 (sic)
+            self.data[y, x] = c
+
+    def pixel_at(self, x, y):
+        return self.data[y, x]
+
+    def to_ppm(self):
+        """Canvas::to_ppm (canvas.rs:58-96) -> bytes."""
+        img = np.ascontiguousarray(self.data, dtype=f32)
+        text, n = C.c_void_p(), C.c_uint64()
+        L.check(L.lib().rtc_to_ppm(_p(img), self.width, self.height, C.byref(text), C.byref(n)))
+        try:
+            return C.string_at(text, n.value)
+        finally:
+            L.lib().rtc_free(text)
+
+
+# -------------------------------------------------------------------- camera.rs
+class Camera:
+    """Camera::new(width_pixels, height_pixels, field_of_view, transform) -- camera.rs:23-56"""
+
+    def __init__(self, width_pixels, height_pixels, field_of_view, transform):
+        t = _a(transform, 16)
+        self._cam = L.rtc_camera()
+        L.check(L.lib().rtc_camera_new(int(width_pixels), int(height_pixels), float(f32(field_of_view)), _p(t),
+                                       C.byref(self._cam)))
+        self.width, self.height = int(width_pixels), int(height_pixels)
+        self.field_of_view = f32(field_of_view)
+        self.transform = np.asarray(transform, dtype=f32).reshape(4, 4).copy()
+        self.last_stats = None
+
+    @property
+    def pixel_size(self):
+        return f32(self._cam.pixel_size)
+
+    @property
+    def half_width(self):
+        return f32(self._cam.half_width)
+
+    @property
+    def half_height(self):
+        return f32(self._cam.half_height)
+
+    @property
+    def transform_inverse(self):
+        return np.array(list(self._cam.inv), dtype=f32).reshape(4, 4)
+
+    def ray_for_pixel(self, x, y):
+        o, d = np.zeros(4, dtype=f32), np.zeros(4, dtype=f32)
+        L.lib().rtc_ray_for_pixel(C.byref(self._cam), int(x), int(y), _p(o), _p(d))
+        return o, d
+
+    def render(self, world, reflection_recursion_depth, device=0):
+        """Camera::render (camera.rs:76-91) on the MI355X -> Canvas."""
+        img = np.zeros((self.height, self.width, 3), dtype=f32)
+        stats = L.rtc_stats()
+        cs = world._c()
+        L.check(L.lib().rtc_render(C.byref(cs.scene), C.byref(self._cam), int(reflection_recursion_depth), device,
+                                   _p(img), C.byref(stats)))
+        self.last_stats = {"rays": int(stats.rays), "shaded_hits": int(stats.shaded_hits),
+                           "pixels": int(stats.pixels), "kernel_ms": float(stats.kernel_ms)}
+        return Canvas(self.width, self.height, img)
+
+
+def powf(x, y, device=0):
+    """f32::powf on the device (phong_lighting.rs:56)."""
+    a, b = _a(x), _a(y)
+    out = np.zeros(a.size, dtype=f32)
+    L.check(L.lib().rtc_powf(_p(a), _p(b), a.size, device, _p(out)))
+    return out
+
+
+def powf_host(x, y):
+    """Host compile of the device powf restatement (diagnostic only)."""
+    a, b = _a(x), _a(y)
+    out = np.zeros(a.size, dtype=f32)
+    L.lib().rtc_powf_host(_p(a), _p(b), a.size, _p(out))
+    return out
+
+
+def device_count():
+    return int(L.lib().rtc_device_count())

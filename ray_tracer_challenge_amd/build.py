@@ -1,0 +1,46 @@
+"""Builds librtc_amd.so (HIP kernels + C ABI) in-tree for gfx950.
+
+    python -m ray_tracer_challenge_amd.build
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the
+arithmetic contract (the Rust reference never fuses a*b+c), not a tuning flag.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librtc_amd.so")
+SOURCES = [os.path.join(CSRC, "rtc_device.hip"), os.path.join(CSRC, "rtc_host.cpp")]
+HEADERS = [os.path.join(CSRC, "rtc_internal.h"), os.path.join(ROOT, "include", "rtc.h")]
+
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off",  # arithmetic contract, host and device
+    "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+]
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    if not force and not stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    cmd = [hipcc] + FLAGS + list(extra_flags) + ["-o", LIB] + SOURCES
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB)

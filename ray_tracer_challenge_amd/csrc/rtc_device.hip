@@ -1,0 +1,1238 @@
+// rtc_device.hip -- the MI355X (gfx950 / CDNA4) render path of librtc_amd.so.
+//
+// One wavefront lane per pixel, 8x8 pixel tiles per 64-lane wave.  The
+// flattened scene (structure-of-arrays float4 records, 64 B geometry + 48 B
+// material per object) lives in HBM; because every lane of a wave walks the
+// same object list, the records are fetched with wave-uniform addresses
+// (scalar loads -> SGPRs) and cost no vector registers or LDS bandwidth.
+// Recursion (reflected_color / refracted_color -> color_at) is an explicit
+// per-lane post-order stack, so that sums are formed in exactly the
+// reference's order.  No MFMA: the path is branchy scalar f32 arithmetic.
+//
+// Bit-exactness rules (see DESIGN.md "Arithmetic contract"):
+//   * whole file is compiled with -ffp-contract=off and the pragma below: the
+//     Rust reference never fuses a*b+c;
+//   * every sum keeps the reference's association order;
+//   * '/' and sqrtf are the correctly rounded IEEE forms (hipcc default);
+//   * powf is a restatement of glibc 2.35's FMA powf (the routine a Linux
+//     build of the reference calls), in f64, not ocml's powf.
+//
+// Citations: file:line under /root/reference/lib/src.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+#include "rtc_internal.h"
+
+#pragma clang fp contract(off)
+
+#define DI __device__ __forceinline__
+#define HDI __host__ __device__ __forceinline__
+
+namespace rtc {
+
+// ============================================================================
+//  powf: glibc 2.35 sysdeps/ieee754/flt-32/e_powf.c (Szabolcs Nagy's
+//  algorithm from ARM optimized-routines), FMA variant (__powf_fma), which is
+//  what f32::powf (phong_lighting.rs:56) resolves to on an x86-64 Linux host
+//  with FMA.  log2(x) by a 16-entry table + degree-5 polynomial, exp2 by a
+//  32-entry table + degree-3 polynomial, all in double precision.
+// ============================================================================
+struct PowLog2Entry {
+    double invc, logc;
+};
+__device__ __constant__ PowLog2Entry d_pow_log2_tab[16] = {
+    {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+    {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+    {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+    {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+    {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+    {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2},
+};
+__device__ __constant__ uint64_t d_exp2f_tab[32] = {
+    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b,
+    0x3fef54873168b9aa, 0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb,
+    0x3feedea64c123422, 0x3feece086061892d, 0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429,
+    0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74, 0x3feea11473eb0187, 0x3feea589994cce13,
+    0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d, 0x3feee89f995ad3ad,
+    0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
+    0x3fefa4afa2a490da, 0x3fefd0765b6e4540,
+};
+// Host copies of the same tables (rtc_powf_host, used by CPU tests to pin the
+// restatement against the C library without a GPU).
+static const PowLog2Entry h_pow_log2_tab[16] = {
+    {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+    {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+    {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+    {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+    {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+    {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2},
+};
+static const uint64_t h_exp2f_tab[32] = {
+    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b,
+    0x3fef54873168b9aa, 0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb,
+    0x3feedea64c123422, 0x3feece086061892d, 0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429,
+    0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74, 0x3feea11473eb0187, 0x3feea589994cce13,
+    0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d, 0x3feee89f995ad3ad,
+    0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
+    0x3fefa4afa2a490da, 0x3fefd0765b6e4540,
+};
+
+HDI uint32_t f2u(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+HDI float u2f(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+HDI uint64_t d2u(double d) {
+    uint64_t u;
+    memcpy(&u, &d, 8);
+    return u;
+}
+HDI double u2d(uint64_t u) {
+    double d;
+    memcpy(&d, &u, 8);
+    return d;
+}
+
+HDI int pow_checkint(uint32_t iy) {  // 0: not an integer, 1: odd, 2: even
+    int e = (iy >> 23) & 0xff;
+    if (e < 0x7f) return 0;
+    if (e > 0x7f + 23) return 2;
+    if (iy & ((1u << (0x7f + 23 - e)) - 1)) return 0;
+    if (iy & (1u << (0x7f + 23 - e))) return 1;
+    return 2;
+}
+HDI bool pow_zeroinfnan(uint32_t ix) { return 2 * ix - 1 >= 2u * 0x7f800000 - 1; }
+
+HDI float powf_glibc(float x, float y, const PowLog2Entry* __restrict__ T, const uint64_t* __restrict__ E) {
+    uint32_t sign_bias = 0;
+    uint32_t ix = f2u(x), iy = f2u(y);
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || pow_zeroinfnan(iy)) {
+        if (pow_zeroinfnan(iy)) {
+            if (2 * iy == 0) return 1.0f;
+            if (ix == 0x3f800000u) return 1.0f;
+            if (2 * ix > 2u * 0x7f800000u || 2 * iy > 2u * 0x7f800000u) return x + y;
+            if (2 * ix == 2 * 0x3f800000u) return 1.0f;
+            if ((2 * ix < 2 * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;
+            return y * y;
+        }
+        if (pow_zeroinfnan(ix)) {
+            float x2 = x * x;
+            if ((ix & 0x80000000u) && pow_checkint(iy) == 1) {
+                x2 = -x2;
+                sign_bias = 1;
+            }
+            if (2 * ix == 0 && (iy & 0x80000000u)) return sign_bias ? -INFINITY : INFINITY;
+            return (iy & 0x80000000u) ? 1 / x2 : x2;
+        }
+        if (ix & 0x80000000u) {
+            int yint = pow_checkint(iy);
+            if (yint == 0) return NAN;
+            if (yint == 1) sign_bias = 1u << (5 + 11);  // SIGN_BIAS = 1 << (EXP2F_TABLE_BITS + 11)
+            ix &= 0x7fffffffu;
+        }
+        if (ix < 0x00800000u) {  // normalise a subnormal x
+            ix = f2u(x * 0x1p23f);
+            ix &= 0x7fffffffu;
+            ix -= 23u << 23;
+        }
+    }
+    // log2_inline: x = 2^k z, z in [OFF, 2*OFF); log2(x) = k + log2(c) + log2(z/c)
+    uint32_t tmp = ix - 0x3f330000u;
+    int i = (tmp >> (23 - 4)) % 16;
+    uint32_t top = tmp & 0xff800000u;
+    uint32_t iz = ix - top;
+    int k = (int32_t)top >> 23;
+    double invc = T[i].invc, logc = T[i].logc;
+    double z = (double)u2f(iz);
+    double r = fma(z, invc, -1.0);
+    double y0 = logc + (double)k;
+    const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
+                 A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp0;
+    double r2 = r * r;
+    double yy = fma(A0, r, A1);
+    double p = fma(A2, r, A3);
+    double r4 = r2 * r2;
+    double q = fma(A4, r, y0);
+    q = fma(p, r2, q);
+    double logx = fma(yy, r4, q);
+    double ylogx = (double)y * logx;
+    if (((d2u(ylogx) >> 47) & 0xffff) >= (d2u(126.0) >> 47)) {  // |y*log2(x)| >= 126
+        if (ylogx > 0x1.fffffffd1d571p+6) return sign_bias ? -INFINITY : INFINITY;  // __math_oflowf
+        if (ylogx <= -150.0) return sign_bias ? -0.0f : 0.0f;                       // __math_uflowf
+        if (ylogx < -149.0) {                                                       // __math_may_uflowf
+            float tiny = 0x1.4p-75f * 0x1.4p-75f;
+            return sign_bias ? -tiny : tiny;
+        }
+    }
+    // exp2_inline: x = k/N + r, 2^x = 2^(k/N) * 2^r
+    const double SHIFT = 0x1.8p+52 / 32.0;
+    const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
+    double kd = ylogx + SHIFT;
+    uint64_t ki = d2u(kd);
+    kd -= SHIFT;
+    double rr = ylogx - kd;
+    uint64_t t = E[ki % 32];
+    uint64_t ski = ki + sign_bias;
+    t += ski << (52 - 5);
+    double s = u2d(t);
+    double zz = fma(C0, rr, C1);
+    double rr2 = rr * rr;
+    double res = fma(C2, rr, 1.0);
+    res = fma(zz, rr2, res);
+    res = res * s;
+    return (float)res;
+}
+
+DI float rtc_powf_dev(float x, float y) { return powf_glibc(x, y, d_pow_log2_tab, d_exp2f_tab); }
+
+// ============================================================================
+//  Scene as the kernel sees it
+// ============================================================================
+struct V3 {
+    float x, y, z;
+};
+DI V3 v3(float x, float y, float z) { return {x, y, z}; }
+DI V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+DI V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+DI V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+DI V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+DI V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+// tuple.rs:44-46 for vectors (the w*w term is +0 and is dropped)
+DI float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// tuple.rs:29-43 for vectors: sqrt(x^2 + y^2 + z^2 [+ 0]); norm divides
+DI float mag3(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+DI V3 norm3(V3 a) {
+    float m = mag3(a);
+    return {a.x / m, a.y / m, a.z / m};
+}
+// ray.rs:43  -(n*2*dot(in,n) - in)
+DI V3 reflect3(V3 in, V3 n) {
+    float d = dot3(in, n);
+    return -(n * 2.0f * d - in);
+}
+
+struct SceneHdr {
+    uint32_t n_objects;
+    int32_t light_kind;
+    float li[3];      // light.intensity()
+    float lpos[3];    // light.position(): point position or rectangle centre
+    float corner[3];
+    float uvec[3];    // per-cell
+    float vvec[3];
+    int32_t u_steps, v_steps;
+    float cells_f;    // (u_steps*v_steps) as f32, rectangle_light.rs:87
+    int32_t jitter_mode;
+    float jitter_const;
+    uint32_t jitter_seed;
+    // camera
+    uint32_t width, height;
+    float half_w, half_h, pixel_size;
+    float cam[12];        // rows 0..2 of transform_inverse
+    float cam_origin[3];  // transform_inverse * point(0,0,0), camera.rs:70
+};
+
+// Structure-of-arrays scene records in HBM: 4 float4 of geometry (64 B) and
+// 3 float4 of material (48 B) per object.
+struct SceneSoA {
+    const float4* __restrict__ inv0;   // row 0 of t_inverse
+    const float4* __restrict__ inv1;
+    const float4* __restrict__ inv2;
+    const float4* __restrict__ shape;  // {min_y, max_y, bits(kind | casts<<8 | closed<<9), 0}
+    const float4* __restrict__ mat_a;  // {r, g, b, ambient}
+    const float4* __restrict__ mat_b;  // {diffuse, specular, shininess, reflective}
+    const float4* __restrict__ mat_c;  // {transparency, refractive_index, 0, 0}
+};
+
+constexpr float PLANE_EPS = 1.1920929e-7f * 10000.0f;  // plane.rs:49  f32::EPSILON * 10000.0
+constexpr float SELF_EPS = 1.1920929e-7f * 10000.0f;   // world.rs:210
+constexpr float CLOSE_TO_ZERO = 0.000001f;             // cylinder.rs:82
+
+// shape.rs:57-70 + ray.rs:26-31 for an affine inverse: o' = M*o (w = 1), d' = M*d (w = 0)
+DI V3 xform_point(float4 r0, float4 r1, float4 r2, V3 p) {
+    return {r0.x * p.x + r0.y * p.y + r0.z * p.z + r0.w, r1.x * p.x + r1.y * p.y + r1.z * p.z + r1.w,
+            r2.x * p.x + r2.y * p.y + r2.z * p.z + r2.w};
+}
+DI V3 xform_vector(float4 r0, float4 r1, float4 r2, V3 v) {
+    return {r0.x * v.x + r0.y * v.y + r0.z * v.z, r1.x * v.x + r1.y * v.y + r1.z * v.z,
+            r2.x * v.x + r2.y * v.y + r2.z * v.z};
+}
+// normal_to_world (shape.rs:72-146): transpose(t_inverse) * n, w := 0, normalise
+DI V3 xform_normal(float4 r0, float4 r1, float4 r2, V3 n) {
+    V3 w = {r0.x * n.x + r1.x * n.y + r2.x * n.z, r0.y * n.x + r1.y * n.y + r2.y * n.z,
+            r0.z * n.x + r1.z * n.y + r2.z * n.z};
+    return norm3(w);
+}
+
+// Calls f(t) for every intersection the reference's local_intersect would
+// push, in push order.  o, d: object-space ray.
+template <class F>
+DI void local_intersect(uint32_t kind, float min_y, float max_y, bool closed, V3 o, V3 d, F&& f) {
+    if (kind == RTC_SPHERE) {  // sphere.rs:47-70
+        float a = d.x * d.x + d.y * d.y + d.z * d.z;
+        float b = 2.0f * (d.x * o.x + d.y * o.y + d.z * o.z);
+        float c = (o.x * o.x + o.y * o.y + o.z * o.z) - 1.0f;
+        float disc = b * b - 4.0f * a * c;
+        if (!(disc < 0.0f)) {
+            float two_a = 2.0f * a;
+            float sq = sqrtf(disc);
+            f((-b - sq) / two_a);
+            f((-b + sq) / two_a);
+        }
+    } else if (kind == RTC_PLANE) {  // plane.rs:45-56
+        if (!(fabsf(d.y) < PLANE_EPS)) f(-o.y / d.y);
+    } else if (kind == RTC_CUBE) {  // cube.rs:55-63, 90-129; reciprocals from Ray::new (ray.rs:16)
+        float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+        float x0 = (-1.0f - o.x) * ix, x1 = (1.0f - o.x) * ix;
+        float tmin = fminf(x0, x1), tmax = fmaxf(x0, x1);
+        float y0 = (-1.0f - o.y) * iy, y1 = (1.0f - o.y) * iy;
+        tmin = fmaxf(tmin, fminf(y0, y1));
+        tmax = fminf(tmax, fmaxf(y0, y1));
+        float z0 = (-1.0f - o.z) * iz, z1 = (1.0f - o.z) * iz;
+        tmin = fmaxf(tmin, fminf(z0, z1));
+        tmax = fminf(tmax, fmaxf(z0, z1));
+        if (tmax >= fmaxf(0.0f, tmin)) {
+            f(tmin);
+            f(tmax);
+        }
+    } else {  // RTC_CYLINDER, cylinder.rs:52-59, 84-151
+        int pushed = 0;
+        float two_a = 2.0f * (d.x * d.x + d.z * d.z);
+        if (!(fabsf(two_a) < CLOSE_TO_ZERO)) {
+            float b = 2.0f * (o.x * d.x + o.z * d.z);
+            float c = o.x * o.x + o.z * o.z - 1.0f;
+            float disc = b * b - 2.0f * two_a * c;
+            if (!(disc < 0.0f)) {
+                float sq = sqrtf(disc);
+                float d1 = (-b - sq) / two_a;
+                float d2 = (-b + sq) / two_a;
+                if (d1 > d2) {
+                    float t = d1;
+                    d1 = d2;
+                    d2 = t;
+                }
+                float y1 = o.y + d1 * d.y;
+                if (min_y < y1 && y1 < max_y) {
+                    f(d1);
+                    pushed++;
+                }
+                float y2 = o.y + d2 * d.y;
+                if (min_y < y2 && y2 < max_y) {
+                    f(d2);
+                    pushed++;
+                }
+            }
+        }
+        if (pushed < 2 && closed) {  // intersect_caps, cylinder.rs:132-151
+            float t = (min_y - o.y) / d.y;
+            float cx = o.x + t * d.x, cz = o.z + t * d.z;
+            if ((cx * cx + cz * cz) <= 1.0f + CLOSE_TO_ZERO) f(t);
+            t = (max_y - o.y) / d.y;
+            cx = o.x + t * d.x;
+            cz = o.z + t * d.z;
+            if ((cx * cx + cz * cz) <= 1.0f + CLOSE_TO_ZERO) f(t);
+        }
+    }
+}
+
+// local_norm_at for the four shapes (sphere.rs:71-73, plane.rs:57-59, cube.rs:66-80, cylinder.rs:62-72)
+DI V3 local_normal(uint32_t kind, float min_y, float max_y, V3 p) {
+    if (kind == RTC_SPHERE) return p;
+    if (kind == RTC_PLANE) return v3(0.0f, 1.0f, 0.0f);
+    if (kind == RTC_CUBE) {
+        float xa = fabsf(p.x), ya = fabsf(p.y), za = fabsf(p.z);
+        float max_c = fmaxf(xa, fmaxf(ya, za));
+        if (xa == max_c) return v3(p.x, 0.0f, 0.0f);
+        if (ya == max_c) return v3(0.0f, p.y, 0.0f);
+        return v3(0.0f, 0.0f, p.z);
+    }
+    float dist_square = p.x * p.x + p.z * p.z;
+    if (dist_square < 1.0f) {
+        if (p.y >= max_y - CLOSE_TO_ZERO) return v3(0.0f, 1.0f, 0.0f);
+        if (p.y <= min_y + CLOSE_TO_ZERO) return v3(0.0f, -1.0f, 0.0f);
+    }
+    return v3(p.x, 0.0f, p.z);
+}
+
+struct Hit {
+    float t;
+    int obj;  // -1: none
+};
+
+// per-lane work counters (reduced per workgroup at kernel end)
+struct Counters {
+    uint32_t rays;    // World::intersect evaluations
+    uint32_t shaded;  // shade_hit evaluations
+};
+
+// World::intersect + Intersection::hit (world.rs:52-60, intersection.rs:30-35)
+// without materialising or sorting the list: the hit is the first entry, in
+// (object order, push order), of the minimum among distances >= 0 -- which is
+// what a stable sort followed by a first-minimum scan selects.
+DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d) {
+    Hit best = {0.0f, -1};
+    for (uint32_t i = 0; i < H.n_objects; i++) {
+        float4 r0 = S.inv0[i], r1 = S.inv1[i], r2 = S.inv2[i], sh = S.shape[i];
+        uint32_t bits = __float_as_uint(sh.z);
+        V3 oo = xform_point(r0, r1, r2, o);
+        V3 od = xform_vector(r0, r1, r2, d);
+        local_intersect(bits & 0xff, sh.x, sh.y, (bits >> 9) & 1, oo, od, [&](float t) {
+            if (t >= 0.0f && (best.obj < 0 || t < best.t)) {
+                best.t = t;
+                best.obj = (int)i;
+            }
+        });
+    }
+    return best;
+}
+
+// world.rs:104-119
+DI bool is_shadowed(const SceneHdr& H, const SceneSoA& S, V3 light_position, V3 p, Counters& cnt) {
+    V3 v = light_position - p;
+    float distance = mag3(v);
+    V3 direction = norm3(v);
+    cnt.rays++;
+    Hit h = nearest_hit(H, S, p, direction);
+    if (h.obj < 0) return false;
+    bool casts = (__float_as_uint(S.shape[h.obj].z) >> 8) & 1;
+    return casts && h.t < distance;
+}
+
+// Pinned jitter (DESIGN.md "Jitter"): counter-based hash keyed by
+// (pixel, path code, cell, draw) -> f32 in (0, 1] with 2^-23 resolution.
+DI uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+DI uint32_t jitter_base(uint32_t seed, uint32_t pixel, uint32_t path) {
+    uint32_t a = mix32(pixel ^ seed);
+    return mix32(a + path * 0x9E3779B9u);
+}
+DI float jitter_value(uint32_t h) { return (float)((h >> 9) + 1u) * 1.1920929e-7f; }
+
+// Light::intensity_at: point_light.rs:28-34, rectangle_light.rs:60-66, 76-88
+DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel, uint32_t path, Counters& cnt) {
+    if (H.light_kind == RTC_LIGHT_POINT) {
+        return is_shadowed(H, S, v3(H.lpos[0], H.lpos[1], H.lpos[2]), p, cnt) ? 0.0f : 1.0f;
+    }
+    const V3 corner = v3(H.corner[0], H.corner[1], H.corner[2]);
+    const V3 uvec = v3(H.uvec[0], H.uvec[1], H.uvec[2]);
+    const V3 vvec = v3(H.vvec[0], H.vvec[1], H.vvec[2]);
+    const bool hashed = H.jitter_mode == RTC_JITTER_HASHED;
+    const uint32_t base = hashed ? jitter_base(H.jitter_seed, pixel, path) : 0u;
+    float total = 0.0f;
+    uint32_t cell = 0;
+    for (int v = 0; v < H.v_steps; v++) {
+        for (int u = 0; u < H.u_steps; u++, cell++) {
+            float j1 = H.jitter_const, j2 = H.jitter_const;
+            if (hashed) {
+                uint32_t k = base + cell * 0x85EBCA6Bu;
+                j1 = jitter_value(mix32(k));
+                j2 = jitter_value(mix32(k ^ 0x68E31DA4u));
+            }
+            // corner + u_vec * (u + jitter1) + v_vec * (v + jitter2)
+            V3 lp = corner + uvec * ((float)u + j1) + vvec * ((float)v + j2);
+            if (!is_shadowed(H, S, lp, p, cnt)) total += 1.0f;
+        }
+    }
+    return total / H.cells_f;
+}
+
+// light/phong_lighting.rs:12-63 (pattern branch out of scope)
+DI V3 phong(const SceneHdr& H, float4 ma, float4 mb, V3 p, V3 eye, V3 n, float light_intensity) {
+    const V3 li = v3(H.li[0], H.li[1], H.li[2]);
+    V3 effective = v3(ma.x, ma.y, ma.z) * li;
+    V3 ambient = effective * ma.w;
+    if (light_intensity == 0.0f) return ambient;
+    V3 to_light = norm3(v3(H.lpos[0], H.lpos[1], H.lpos[2]) - p);
+    float light_normal_cosine = dot3(to_light, n);
+    V3 diffuse = v3(0.0f, 0.0f, 0.0f), specular = v3(0.0f, 0.0f, 0.0f);
+    if (!(light_normal_cosine < 0.0f)) {
+        diffuse = effective * mb.x * light_normal_cosine;
+        V3 surface_reflection = reflect3(-to_light, n);
+        float reflection_eye_cosine = dot3(surface_reflection, eye);
+        if (!(reflection_eye_cosine <= 0.0f)) {
+            float factor = rtc_powf_dev(reflection_eye_cosine, mb.z);
+            specular = li * mb.y * factor;
+        }
+    }
+    return ambient + (diffuse + specular) * light_intensity;
+}
+
+// n1/n2 of precompute_values (world.rs:235-263) without the sorted list.
+// Every intersection listed before the hit has t < 0 (the hit is the first
+// non-negative minimum of a stably sorted list).  Walking those toggles each
+// object in/out of an insertion-ordered set; an object ends up inside iff it
+// has an odd number of negative intersections, and its insertion slot is that
+// of its largest negative t (ties between objects: object order).  So the
+// "innermost container" is the odd-parity object with the largest
+// (t_max_negative, index); toggling the hit object then gives n2.
+DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int hit_obj, float& n1, float& n2) {
+    float t1 = 0.0f, t2 = 0.0f;  // best and runner-up container keys
+    int c1 = -1, c2 = -1;
+    bool hit_inside = false;
+    for (uint32_t i = 0; i < H.n_objects; i++) {
+        float4 r0 = S.inv0[i], r1 = S.inv1[i], r2 = S.inv2[i], sh = S.shape[i];
+        uint32_t bits = __float_as_uint(sh.z);
+        V3 oo = xform_point(r0, r1, r2, o);
+        V3 od = xform_vector(r0, r1, r2, d);
+        int negatives = 0;
+        float tmax = 0.0f;
+        local_intersect(bits & 0xff, sh.x, sh.y, (bits >> 9) & 1, oo, od, [&](float t) {
+            if (t < 0.0f) {
+                if (negatives == 0 || t > tmax) tmax = t;
+                negatives++;
+            }
+        });
+        if (negatives & 1) {
+            if ((int)i == hit_obj) hit_inside = true;
+            if (c1 < 0 || tmax >= t1) {  // later object wins ties: it sorts after
+                t2 = t1;
+                c2 = c1;
+                t1 = tmax;
+                c1 = (int)i;
+            } else if (c2 < 0 || tmax >= t2) {
+                t2 = tmax;
+                c2 = (int)i;
+            }
+        }
+    }
+    const float vacuum = 1.0f;  // REFRACTION_VACCUM, constants.rs:6
+    n1 = c1 >= 0 ? S.mat_c[c1].y : vacuum;
+    if (!hit_inside) {
+        n2 = S.mat_c[hit_obj].y;  // entering: the hit object becomes the innermost container
+    } else if (c1 == hit_obj) {
+        n2 = c2 >= 0 ? S.mat_c[c2].y : vacuum;
+    } else {
+        n2 = n1;
+    }
+}
+
+// world.rs:285-303
+DI float schlick(V3 eye, V3 n, float n1, float n2) {
+    float cosine = dot3(eye, n);
+    if (n1 > n2) {
+        float r = n1 / n2;
+        float sin2 = r * r * (1.0f - cosine * cosine);
+        if (sin2 > 1.0f) return 1.0f;
+        cosine = sqrtf(1.0f - sin2);
+    }
+    float q = (n1 - n2) / (n1 + n2);
+    float r0 = q * q;
+    float x = 1.0f - cosine;
+    float x2 = x * x;
+    float x4 = x2 * x2;
+    float x5 = x * x4;  // powi(5)
+    return r0 + (1.0f - r0) * x5;
+}
+
+// One suspended shade_hit (world.rs:62-86) waiting for a child colour.
+struct Frame {
+    V3 acc;       // surface colour, later surface + reflected[*R]
+    V3 ro, rd;    // pending refraction ray (under_point, direction)
+    float reflective, transparency, R;
+    uint32_t flags;  // bit0: waiting for the refraction child; bit1: has refraction child; bit2: Schlick
+};
+enum { F_WAIT_REFR = 1, F_HAS_REFR = 2, F_SCHLICK = 4 };
+
+// World::color_at (world.rs:88-101) with reflected_color / refracted_color
+// recursion (world.rs:121-162) unrolled into an explicit post-order stack.
+// `path` is the jitter path code: 1 at the root, 2p for the reflection child
+// of p, 2p+1 for its refraction child.
+DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint32_t pixel, Counters& cnt) {
+    Frame stack[RTC_MAX_DEPTH];
+    int sp = 0;
+    int rem = depth;
+    uint32_t path = 1;
+    V3 ret = v3(0.0f, 0.0f, 0.0f);
+    for (;;) {
+        // ---------------- color_at(ray(o, d), rem)
+        cnt.rays++;
+        Hit h = nearest_hit(H, S, o, d);
+        bool descend = false;
+        ret = v3(0.0f, 0.0f, 0.0f);
+        if (h.obj >= 0) {
+            // precompute_values, world.rs:212-233
+            const int ob = h.obj;
+            float4 r0 = S.inv0[ob], r1 = S.inv1[ob], r2 = S.inv2[ob], sh = S.shape[ob];
+            uint32_t bits = __float_as_uint(sh.z);
+            V3 point = o + d * h.t;
+            V3 op = xform_point(r0, r1, r2, point);
+            V3 n = xform_normal(r0, r1, r2, local_normal(bits & 0xff, sh.x, sh.y, op));
+            V3 eye = -d;
+            V3 reflectv = reflect3(d, n);
+            if (dot3(n, eye) < 0.0f) n = -n;
+            V3 over_point = point + n * SELF_EPS;
+            V3 under_point = point - n * SELF_EPS;
+            float4 ma = S.mat_a[ob], mb = S.mat_b[ob], mc = S.mat_c[ob];
+            const float reflective = mb.w, transparency = mc.x;
+
+            // shade_hit, world.rs:62-86
+            cnt.shaded++;
+            float li = intensity_at(H, S, over_point, pixel, path, cnt);
+            V3 surface = phong(H, ma, mb, over_point, eye, n, li);
+
+            bool has_refl = !(reflective == 0.0f || rem < 1);  // world.rs:126
+            bool has_refr = false;
+            bool use_schlick = reflective > 0.0f && transparency > 0.0f;  // world.rs:80
+            float R = 0.0f;
+            V3 rdir = v3(0.0f, 0.0f, 0.0f);
+            if (transparency != 0.0f) {
+                float n1, n2;
+                refraction_indices(H, S, o, d, ob, n1, n2);
+                if (use_schlick) R = schlick(eye, n, n1, n2);
+                if (rem != 0) {  // refracted_color, world.rs:140-161
+                    float n_ratio = n1 / n2;
+                    float cos_i = dot3(eye, n);
+                    float sin2 = n_ratio * n_ratio * (1.0f - cos_i * cos_i);
+                    if (!(sin2 > 1.0f)) {
+                        float cos_t = sqrtf(1.0f - sin2);
+                        rdir = n * (n_ratio * cos_i - cos_t) - (eye * n_ratio);
+                        has_refr = true;
+                    }
+                }
+            }
+            if (!has_refl && !has_refr) {
+                const V3 black = v3(0.0f, 0.0f, 0.0f);
+                ret = use_schlick ? surface + black * R + black * (1.0f - R) : surface + black + black;
+            } else {
+                Frame f;
+                f.reflective = reflective;
+                f.transparency = transparency;
+                f.R = R;
+                f.flags = (has_refr ? F_HAS_REFR : 0) | (use_schlick ? F_SCHLICK : 0);
+                f.ro = under_point;
+                f.rd = rdir;
+                if (has_refl) {
+                    f.acc = surface;
+                    o = over_point;
+                    d = reflectv;
+                    path = path * 2u;
+                } else {
+                    const V3 black = v3(0.0f, 0.0f, 0.0f);
+                    f.acc = use_schlick ? surface + black * R : surface + black;
+                    f.flags |= F_WAIT_REFR;
+                    o = under_point;
+                    d = rdir;
+                    path = path * 2u + 1u;
+                }
+                stack[sp++] = f;
+                rem--;
+                descend = true;
+            }
+        }
+        if (descend) continue;
+        // ---------------- return `ret` to the suspended callers
+        for (;;) {
+            if (sp == 0) return ret;
+            Frame& f = stack[sp - 1];
+            rem++;
+            path >>= 1;
+            if (!(f.flags & F_WAIT_REFR)) {
+                V3 reflected = ret * f.reflective;  // world.rs:131
+                V3 partial = (f.flags & F_SCHLICK) ? f.acc + reflected * f.R : f.acc + reflected;
+                if (f.flags & F_HAS_REFR) {
+                    f.acc = partial;
+                    f.flags |= F_WAIT_REFR;
+                    o = f.ro;
+                    d = f.rd;
+                    rem--;
+                    path = path * 2u + 1u;
+                    break;
+                }
+                const V3 black = v3(0.0f, 0.0f, 0.0f);
+                ret = (f.flags & F_SCHLICK) ? partial + black * (1.0f - f.R) : partial + black;
+                sp--;
+            } else {
+                V3 refracted = ret * f.transparency;  // world.rs:159-160
+                ret = (f.flags & F_SCHLICK) ? f.acc + refracted * (1.0f - f.R) : f.acc + refracted;
+                sp--;
+            }
+        }
+    }
+}
+
+// ============================================================================
+//  Kernels
+// ============================================================================
+struct RenderArgs {
+    SceneHdr hdr;
+    SceneSoA soa;
+    float* out;            // compact rows of this partition: [rows][width][3]
+    uint2* block_counts;   // one partial {rays, shaded hits} per workgroup
+    uint32_t rows;         // rows in `out`
+    uint32_t band_rows, n_parts, part;
+    int32_t depth;
+};
+
+// Camera::render (camera.rs:76-91): one lane per pixel, 8x8 pixel tile per
+// wave, 2x2 waves per 256-thread workgroup.
+__global__ __launch_bounds__(256) void render_kernel(RenderArgs A) {
+    const SceneHdr& H = A.hdr;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t yl = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    Counters cnt = {0u, 0u};
+    if (x < H.width && yl < A.rows) {
+        // compact local row -> global row of the image
+        const uint32_t band = yl / A.band_rows;
+        const uint32_t y = (band * A.n_parts + A.part) * A.band_rows + (yl - band * A.band_rows);
+        V3 col = v3(0.0f, 0.0f, 0.0f);
+        // camera.rs:80-81: `0..height-1` x `0..width-1` -- the last row and column stay black
+        if (x < H.width - 1u && y < H.height - 1u) {
+            // ray_for_pixel, camera.rs:60-74
+            float x_offset = ((float)x + 0.5f) * H.pixel_size;
+            float y_offset = ((float)y + 0.5f) * H.pixel_size;
+            float world_x = H.half_w - x_offset;
+            float world_y = H.half_h - y_offset;
+            const float* c = H.cam;
+            V3 pixel = {c[0] * world_x + c[1] * world_y + c[2] * -1.0f + c[3],
+                        c[4] * world_x + c[5] * world_y + c[6] * -1.0f + c[7],
+                        c[8] * world_x + c[9] * world_y + c[10] * -1.0f + c[11]};
+            V3 origin = v3(H.cam_origin[0], H.cam_origin[1], H.cam_origin[2]);
+            V3 direction = norm3(pixel - origin);
+            col = color_at(H, A.soa, origin, direction, A.depth, y * H.width + x, cnt);
+        }
+        float* dst = A.out + ((size_t)yl * H.width + x) * 3;
+        dst[0] = col.x;
+        dst[1] = col.y;
+        dst[2] = col.z;
+    }
+    // work statistics: wave reduce, then one partial per workgroup
+    uint32_t rays = cnt.rays, shaded = cnt.shaded;
+    for (int off = 32; off > 0; off >>= 1) {
+        rays += __shfl_down(rays, off, 64);
+        shaded += __shfl_down(shaded, off, 64);
+    }
+    __shared__ uint2 wave_counts[4];
+    if (lane == 0) wave_counts[wave] = make_uint2(rays, shaded);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        A.block_counts[blockIdx.y * gridDim.x + blockIdx.x] =
+            make_uint2(wave_counts[0].x + wave_counts[1].x + wave_counts[2].x + wave_counts[3].x,
+                       wave_counts[0].y + wave_counts[1].y + wave_counts[2].y + wave_counts[3].y);
+}
+
+__global__ __launch_bounds__(256) void sum_counts_kernel(const uint2* __restrict__ block_counts, uint32_t n,
+                                                         unsigned long long* __restrict__ total) {
+    unsigned long long rays = 0, shaded = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        uint2 c = block_counts[i];
+        rays += c.x;
+        shaded += c.y;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        rays += __shfl_down(rays, off, 64);
+        shaded += __shfl_down(shaded, off, 64);
+    }
+    __shared__ unsigned long long part[4][2];
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6][0] = rays;
+        part[threadIdx.x >> 6][1] = shaded;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        total[0] = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+        total[1] = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+    }
+}
+
+// canvas.rs:39-43
+__global__ void quantize_kernel(const float* __restrict__ rgb, uint64_t n, uint8_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float v = fmaxf(fminf(rgb[i] * 255.0f, 255.0f), 0.0f);
+        out[i] = (uint8_t)v;
+    }
+}
+
+__global__ void color_at_kernel(SceneHdr H, SceneSoA S, const float4* __restrict__ origins,
+                                const float4* __restrict__ directions, uint32_t n, int depth,
+                                float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Counters cnt = {0u, 0u};
+    float4 o = origins[i], d = directions[i];
+    V3 c = color_at(H, S, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), depth, i, cnt);
+    out[i * 3 + 0] = c.x;
+    out[i * 3 + 1] = c.y;
+    out[i * 3 + 2] = c.z;
+}
+
+__global__ void intensity_at_kernel(SceneHdr H, SceneSoA S, const float4* __restrict__ points, uint32_t n,
+                                    float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Counters cnt = {0u, 0u};
+    float4 p = points[i];
+    out[i] = intensity_at(H, S, v3(p.x, p.y, p.z), i, 1u, cnt);
+}
+
+__global__ void is_shadowed_kernel(SceneHdr H, SceneSoA S, const float4* __restrict__ lights,
+                                   const float4* __restrict__ points, uint32_t n, int32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Counters cnt = {0u, 0u};
+    float4 l = lights[i], p = points[i];
+    out[i] = is_shadowed(H, S, v3(l.x, l.y, l.z), v3(p.x, p.y, p.z), cnt) ? 1 : 0;
+}
+
+__global__ void powf_kernel(const float* __restrict__ x, const float* __restrict__ y, uint32_t n,
+                            float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rtc_powf_dev(x[i], y[i]);
+}
+
+// ============================================================================
+//  Host side of the device path
+// ============================================================================
+#define HIP_TRY(expr)                                                                                \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(RTC_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static int usable_devices() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static rtc_status check_tuple(const float v[4], float w, const char* what) {
+    if (v[3] != w) return fail(RTC_ERR_INVALID_ARG, "%s: w component must be %g (got %g)", what, (double)w, (double)v[3]);
+    return RTC_OK;
+}
+
+// Validates and flattens rtc_scene + rtc_camera into the kernel's header and
+// SoA records (host staging buffer, 7 float4 arrays of n entries each).
+static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHdr* hdr, std::vector<float4>* soa) {
+    if (!scene) return fail(RTC_ERR_INVALID_ARG, "scene is NULL");
+    if (!scene->light) return fail(RTC_ERR_NO_LIGHT, "World light should be set");  // world.rs:66
+    if (scene->n_objects && !scene->objects) return fail(RTC_ERR_INVALID_ARG, "scene.objects is NULL");
+    std::memset(hdr, 0, sizeof(*hdr));
+    const uint32_t n = scene->n_objects;
+    hdr->n_objects = n;
+    soa->assign((size_t)7 * (n ? n : 1), make_float4(0, 0, 0, 0));
+    for (uint32_t i = 0; i < n; i++) {
+        const rtc_object& o = scene->objects[i];
+        if (o.kind < RTC_SPHERE || o.kind > RTC_CYLINDER)
+            return fail(RTC_ERR_UNSUPPORTED, "object %u: shape kind %d is not on the device path", i, o.kind);
+        if (!is_affine(o.inv))
+            return fail(RTC_ERR_UNSUPPORTED,
+                        "object %u: inverse transform's last row is not exactly [0,0,0,1] (projective transforms "
+                        "are not supported)", i);
+        (*soa)[0 * n + i] = make_float4(o.inv[0], o.inv[1], o.inv[2], o.inv[3]);
+        (*soa)[1 * n + i] = make_float4(o.inv[4], o.inv[5], o.inv[6], o.inv[7]);
+        (*soa)[2 * n + i] = make_float4(o.inv[8], o.inv[9], o.inv[10], o.inv[11]);
+        uint32_t bits = (uint32_t)o.kind | ((o.casts_shadow ? 1u : 0u) << 8) | ((o.closed ? 1u : 0u) << 9);
+        float bits_f;
+        std::memcpy(&bits_f, &bits, 4);
+        (*soa)[3 * n + i] = make_float4(o.min_y, o.max_y, bits_f, 0.0f);
+        const rtc_material& m = o.material;
+        (*soa)[4 * n + i] = make_float4(m.color[0], m.color[1], m.color[2], m.ambient);
+        (*soa)[5 * n + i] = make_float4(m.diffuse, m.specular, m.shininess, m.reflective);
+        (*soa)[6 * n + i] = make_float4(m.transparency, m.refractive_index, 0.0f, 0.0f);
+    }
+    const rtc_light& l = *scene->light;
+    hdr->light_kind = l.kind;
+    for (int k = 0; k < 3; k++) {
+        hdr->li[k] = l.intensity[k];
+        hdr->lpos[k] = l.position[k];
+        hdr->corner[k] = l.corner[k];
+        hdr->uvec[k] = l.u_vec[k];
+        hdr->vvec[k] = l.v_vec[k];
+    }
+    rtc_status st;
+    if ((st = check_tuple(l.position, 1.0f, "light.position")) != RTC_OK) return st;
+    hdr->u_steps = hdr->v_steps = 1;
+    hdr->cells_f = 1.0f;
+    hdr->jitter_mode = RTC_JITTER_CONSTANT;
+    if (l.kind == RTC_LIGHT_RECT) {
+        if ((st = check_tuple(l.corner, 1.0f, "light.corner")) != RTC_OK) return st;
+        if ((st = check_tuple(l.u_vec, 0.0f, "light.u_vec")) != RTC_OK) return st;
+        if ((st = check_tuple(l.v_vec, 0.0f, "light.v_vec")) != RTC_OK) return st;
+        if (l.u_steps <= 0 || l.v_steps <= 0) return fail(RTC_ERR_INVALID_ARG, "light steps must be positive");
+        if (l.jitter_mode != RTC_JITTER_CONSTANT && l.jitter_mode != RTC_JITTER_HASHED)
+            return fail(RTC_ERR_UNSUPPORTED, "jitter mode %d cannot run on the device (closures are host-only)", l.jitter_mode);
+        hdr->u_steps = l.u_steps;
+        hdr->v_steps = l.v_steps;
+        hdr->cells_f = (float)(l.u_steps * l.v_steps);
+        hdr->jitter_mode = l.jitter_mode;
+        hdr->jitter_const = l.jitter_const;
+        hdr->jitter_seed = l.jitter_seed;
+    } else if (l.kind != RTC_LIGHT_POINT) {
+        return fail(RTC_ERR_UNSUPPORTED, "light kind %d", l.kind);
+    }
+    if (cam) {
+        if (cam->width == 0 || cam->height == 0) return fail(RTC_ERR_INVALID_ARG, "empty canvas");
+        if (!is_affine(cam->inv)) return fail(RTC_ERR_UNSUPPORTED, "camera inverse transform is not affine");
+        hdr->width = cam->width;
+        hdr->height = cam->height;
+        hdr->half_w = cam->half_width;
+        hdr->half_h = cam->half_height;
+        hdr->pixel_size = cam->pixel_size;
+        std::memcpy(hdr->cam, cam->inv, sizeof(float) * 12);
+        // camera.rs:70: origin = transform_inverse * point(0,0,0) -- pixel-invariant, computed once here
+        const float zero[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+        float org[4];
+        mat_vec4(cam->inv, zero, org);
+        for (int k = 0; k < 3; k++) hdr->cam_origin[k] = org[k];
+    }
+    return RTC_OK;
+}
+
+}  // namespace rtc
+
+using namespace rtc;
+
+struct rtc_ctx {
+    int device = 0;
+    SceneHdr hdr;
+    bool has_scene = false;
+    float4* d_soa = nullptr;
+    size_t soa_cap = 0;  // float4 entries
+    uint32_t n_objects = 0;
+    uint2* d_block_counts = nullptr;
+    size_t block_cap = 0;
+    unsigned long long* d_total = nullptr;  // {rays, shaded hits} of the last launch
+    // HIP-event pairs around the render kernel, one per launch since the last rtc_ctx_stats
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    bool rendered = false;
+    uint32_t last_rows = 0;
+    uint64_t last_pixels = 0;
+};
+
+static SceneSoA soa_view(const float4* base, uint32_t n) {
+    uint32_t m = n ? n : 1;
+    SceneSoA s;
+    s.inv0 = base + 0 * (size_t)m;
+    s.inv1 = base + 1 * (size_t)m;
+    s.inv2 = base + 2 * (size_t)m;
+    s.shape = base + 3 * (size_t)m;
+    s.mat_a = base + 4 * (size_t)m;
+    s.mat_b = base + 5 * (size_t)m;
+    s.mat_c = base + 6 * (size_t)m;
+    return s;
+}
+
+extern "C" {
+
+int32_t rtc_device_count(void) { return usable_devices(); }
+
+rtc_status rtc_ctx_create(int32_t device, rtc_ctx** out) {
+    if (!out) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_create: out is NULL");
+    int n = usable_devices();
+    if (n <= 0) return fail(RTC_ERR_NO_DEVICE, "no HIP device visible; librtc_amd has no CPU fallback");
+    if (device < 0 || device >= n) return fail(RTC_ERR_INVALID_ARG, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    rtc_ctx* c = new rtc_ctx();
+    c->device = device;
+    HIP_TRY(hipMalloc(&c->d_total, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_total, 0, 2 * sizeof(unsigned long long)));
+    *out = c;
+    return RTC_OK;
+}
+
+void rtc_ctx_destroy(rtc_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_soa) (void)hipFree(c->d_soa);
+    if (c->d_block_counts) (void)hipFree(c->d_block_counts);
+    if (c->d_total) (void)hipFree(c->d_total);
+    for (auto& e : c->events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    delete c;
+}
+
+rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camera* camera) {
+    if (!c) return fail(RTC_ERR_INVALID_ARG, "ctx is NULL");
+    SceneHdr hdr;
+    std::vector<float4> soa;
+    rtc_status st = flatten(scene, camera, &hdr, &soa);
+    if (st != RTC_OK) return st;
+    HIP_TRY(hipSetDevice(c->device));
+    if (soa.size() > c->soa_cap) {
+        if (c->d_soa) HIP_TRY(hipFree(c->d_soa));
+        c->d_soa = nullptr;
+        HIP_TRY(hipMalloc(&c->d_soa, soa.size() * sizeof(float4)));
+        c->soa_cap = soa.size();
+    }
+    HIP_TRY(hipMemcpy(c->d_soa, soa.data(), soa.size() * sizeof(float4), hipMemcpyHostToDevice));
+    c->hdr = hdr;
+    c->n_objects = hdr.n_objects;
+    c->has_scene = true;
+    return RTC_OK;
+}
+
+rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, void* d_out_rgb, void* stream_) {
+    if (!c || !d_out_rgb) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_render: null argument");
+    if (!c->has_scene || c->hdr.width == 0) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_render: no scene/camera set");
+    if (depth < 0 || depth > RTC_MAX_DEPTH)
+        return fail(RTC_ERR_INVALID_ARG, "depth %d outside [0, %d]", depth, RTC_MAX_DEPTH);
+    Partition q = resolve(part);
+    if (q.part >= q.n_parts) return fail(RTC_ERR_INVALID_ARG, "partition %u of %u", q.part, q.n_parts);
+    const uint32_t rows = partition_rows(c->hdr.height, part);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(c->device));
+    dim3 grid((c->hdr.width + 15) / 16, (rows + 15) / 16), block(256);
+    const size_t n_blocks = (size_t)grid.x * grid.y;
+    if (n_blocks > c->block_cap) {  // grow-only workspace (first call / larger image only)
+        if (c->d_block_counts) HIP_TRY(hipFree(c->d_block_counts));
+        c->d_block_counts = nullptr;
+        HIP_TRY(hipMalloc(&c->d_block_counts, n_blocks * sizeof(uint2)));
+        c->block_cap = n_blocks;
+    }
+    // traced pixels among this partition's rows: x < w-1, y < h-1
+    uint64_t traced_rows = 0;
+    {
+        uint32_t n_bands = (c->hdr.height + q.band_rows - 1) / q.band_rows;
+        for (uint32_t b = q.part; b < n_bands; b += q.n_parts) {
+            uint32_t y0 = b * q.band_rows;
+            uint32_t y1 = y0 + q.band_rows < c->hdr.height ? y0 + q.band_rows : c->hdr.height;
+            uint32_t lim = c->hdr.height - 1;
+            traced_rows += (y1 < lim ? y1 : lim) - (y0 < lim ? y0 : lim);
+        }
+    }
+    c->last_rows = rows;
+    c->last_pixels = traced_rows * (uint64_t)(c->hdr.width - 1);
+    if (rows == 0) {
+        c->rendered = false;
+        return RTC_OK;
+    }
+    RenderArgs a;
+    a.hdr = c->hdr;
+    a.soa = soa_view(c->d_soa, c->n_objects);
+    a.out = (float*)d_out_rgb;
+    a.block_counts = c->d_block_counts;
+    a.rows = rows;
+    a.band_rows = q.band_rows;
+    a.n_parts = q.n_parts;
+    a.part = q.part;
+    a.depth = depth;
+    if (c->events_used == c->events.size()) {
+        if (c->events.size() >= 4096) {
+            c->events_used = 0;  // nobody is reading the timings: recycle
+        } else {
+            std::pair<hipEvent_t, hipEvent_t> e;
+            HIP_TRY(hipEventCreate(&e.first));
+            HIP_TRY(hipEventCreate(&e.second));
+            c->events.push_back(e);
+        }
+    }
+    auto& ev = c->events[c->events_used++];
+    HIP_TRY(hipEventRecord(ev.first, stream));
+    hipLaunchKernelGGL(render_kernel, grid, block, 0, stream, a);
+    HIP_TRY(hipEventRecord(ev.second, stream));
+    hipLaunchKernelGGL(sum_counts_kernel, dim3(1), dim3(256), 0, stream, c->d_block_counts, (uint32_t)n_blocks, c->d_total);
+    HIP_TRY(hipGetLastError());
+    c->rendered = true;
+    return RTC_OK;
+}
+
+rtc_status rtc_ctx_stats(rtc_ctx* c, rtc_stats* out) {
+    if (!c || !out) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_stats: null argument");
+    std::memset(out, 0, sizeof(*out));
+    out->rows = c->last_rows;
+    out->pixels = c->last_pixels;
+    if (!c->rendered) return RTC_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long total[2] = {0, 0};
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(total, c->d_total, sizeof(total), hipMemcpyDeviceToHost));
+    double sum_ms = 0.0;
+    for (size_t i = 0; i < c->events_used; i++) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->events[i].first, c->events[i].second));
+        sum_ms += ms;
+    }
+    out->rays = total[0];
+    out->shaded_hits = total[1];
+    out->launches = (uint32_t)c->events_used;
+    out->kernel_ms = c->events_used ? (float)(sum_ms / (double)c->events_used) : 0.0f;
+    c->events_used = 0;
+    return RTC_OK;
+}
+
+rtc_status rtc_ctx_quantize(rtc_ctx* c, const void* d_rgb, uint64_t n, void* d_out_u8, void* stream_) {
+    if (!c || !d_rgb || !d_out_u8) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_quantize: null argument");
+    if (n == 0) return RTC_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(quantize_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream_, (const float*)d_rgb, n,
+                       (uint8_t*)d_out_u8);
+    HIP_TRY(hipGetLastError());
+    return RTC_OK;
+}
+
+rtc_status rtc_render(const rtc_scene* scene, const rtc_camera* camera, int32_t depth, int32_t device, float* out_rgb,
+                      rtc_stats* stats) {
+    if (!out_rgb || !camera) return fail(RTC_ERR_INVALID_ARG, "rtc_render: null argument");
+    rtc_ctx* c = nullptr;
+    rtc_status st = rtc_ctx_create(device, &c);
+    if (st != RTC_OK) return st;
+    float* d_out = nullptr;
+    auto cleanup = [&]() {
+        if (d_out) (void)hipFree(d_out);
+        rtc_ctx_destroy(c);
+    };
+    st = rtc_ctx_set_scene(c, scene, camera);
+    if (st != RTC_OK) {
+        cleanup();
+        return st;
+    }
+    const size_t bytes = (size_t)camera->width * camera->height * 3 * sizeof(float);
+    hipError_t e = hipMalloc(&d_out, bytes);
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(RTC_ERR_DEVICE, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    st = rtc_ctx_render(c, depth, nullptr, d_out, nullptr);
+    rtc_stats s;
+    if (st == RTC_OK) st = rtc_ctx_stats(c, &s);
+    if (st == RTC_OK) {
+        e = hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = fail(RTC_ERR_DEVICE, "hipMemcpy D2H failed: %s", hipGetErrorString(e));
+    }
+    if (st == RTC_OK && stats) *stats = s;
+    cleanup();
+    return st;
+}
+
+// ---- batched test/utility entry points (host buffers) ---------------------------
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+rtc_status begin_batch(const rtc_scene* scene, int32_t device, SceneHdr* hdr, DevBuf* soa_buf) {
+    int n = usable_devices();
+    if (n <= 0) return fail(RTC_ERR_NO_DEVICE, "no HIP device visible; librtc_amd has no CPU fallback");
+    if (device < 0 || device >= n) return fail(RTC_ERR_INVALID_ARG, "device %d out of range (have %d)", device, n);
+    std::vector<float4> soa;
+    rtc_status st = flatten(scene, nullptr, hdr, &soa);
+    if (st != RTC_OK) return st;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(soa_buf->alloc(soa.size() * sizeof(float4)));
+    HIP_TRY(hipMemcpy(soa_buf->p, soa.data(), soa.size() * sizeof(float4), hipMemcpyHostToDevice));
+    return RTC_OK;
+}
+}  // namespace
+
+rtc_status rtc_color_at(const rtc_scene* scene, const float* origins, const float* directions, uint32_t n,
+                        int32_t depth, int32_t device, float* out_rgb) {
+    if (!origins || !directions || !out_rgb) return fail(RTC_ERR_INVALID_ARG, "rtc_color_at: null argument");
+    if (depth < 0 || depth > RTC_MAX_DEPTH) return fail(RTC_ERR_INVALID_ARG, "depth %d outside [0, %d]", depth, RTC_MAX_DEPTH);
+    if (n == 0) return RTC_OK;
+    for (uint32_t i = 0; i < n; i++) {
+        if (origins[i * 4 + 3] != 1.0f || directions[i * 4 + 3] != 0.0f)
+            return fail(RTC_ERR_INVALID_ARG, "ray %u: origin.w must be 1 and direction.w 0", i);
+    }
+    SceneHdr hdr;
+    DevBuf soa, d_o, d_d, d_out;
+    rtc_status st = begin_batch(scene, device, &hdr, &soa);
+    if (st != RTC_OK) return st;
+    HIP_TRY(d_o.alloc((size_t)n * 16));
+    HIP_TRY(d_d.alloc((size_t)n * 16));
+    HIP_TRY(d_out.alloc((size_t)n * 12));
+    HIP_TRY(hipMemcpy(d_o.p, origins, (size_t)n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d.p, directions, (size_t)n * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(color_at_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, hdr,
+                       soa_view((const float4*)soa.p, hdr.n_objects), (const float4*)d_o.p, (const float4*)d_d.p, n,
+                       depth, (float*)d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out_rgb, d_out.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
+rtc_status rtc_intensity_at(const rtc_scene* scene, const float* points, uint32_t n, int32_t device, float* out) {
+    if (!points || !out) return fail(RTC_ERR_INVALID_ARG, "rtc_intensity_at: null argument");
+    if (n == 0) return RTC_OK;
+    SceneHdr hdr;
+    DevBuf soa, d_p, d_out;
+    rtc_status st = begin_batch(scene, device, &hdr, &soa);
+    if (st != RTC_OK) return st;
+    HIP_TRY(d_p.alloc((size_t)n * 16));
+    HIP_TRY(d_out.alloc((size_t)n * 4));
+    HIP_TRY(hipMemcpy(d_p.p, points, (size_t)n * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(intensity_at_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, hdr,
+                       soa_view((const float4*)soa.p, hdr.n_objects), (const float4*)d_p.p, n, (float*)d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
+rtc_status rtc_is_shadowed(const rtc_scene* scene, const float* light_positions, const float* points, uint32_t n,
+                           int32_t device, int32_t* out) {
+    if (!light_positions || !points || !out) return fail(RTC_ERR_INVALID_ARG, "rtc_is_shadowed: null argument");
+    if (n == 0) return RTC_OK;
+    SceneHdr hdr;
+    DevBuf soa, d_l, d_p, d_out;
+    rtc_status st = begin_batch(scene, device, &hdr, &soa);
+    if (st != RTC_OK) return st;
+    HIP_TRY(d_l.alloc((size_t)n * 16));
+    HIP_TRY(d_p.alloc((size_t)n * 16));
+    HIP_TRY(d_out.alloc((size_t)n * 4));
+    HIP_TRY(hipMemcpy(d_l.p, light_positions, (size_t)n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_p.p, points, (size_t)n * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(is_shadowed_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, hdr,
+                       soa_view((const float4*)soa.p, hdr.n_objects), (const float4*)d_l.p, (const float4*)d_p.p, n,
+                       (int32_t*)d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
+rtc_status rtc_powf(const float* x, const float* y, uint32_t n, int32_t device, float* out) {
+    if (!x || !y || !out) return fail(RTC_ERR_INVALID_ARG, "rtc_powf: null argument");
+    if (n == 0) return RTC_OK;
+    int nd = usable_devices();
+    if (nd <= 0) return fail(RTC_ERR_NO_DEVICE, "no HIP device visible; librtc_amd has no CPU fallback");
+    if (device < 0 || device >= nd) return fail(RTC_ERR_INVALID_ARG, "device %d out of range (have %d)", device, nd);
+    HIP_TRY(hipSetDevice(device));
+    DevBuf d_x, d_y, d_out;
+    HIP_TRY(d_x.alloc((size_t)n * 4));
+    HIP_TRY(d_y.alloc((size_t)n * 4));
+    HIP_TRY(d_out.alloc((size_t)n * 4));
+    HIP_TRY(hipMemcpy(d_x.p, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_y.p, y, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(powf_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, (const float*)d_x.p, (const float*)d_y.p, n,
+                       (float*)d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
+// Host compile of the same powf restatement (diagnostic: lets the CPU test
+// suite pin the algorithm against the C library without a GPU).  Not used by
+// any render path.
+void rtc_powf_host(const float* x, const float* y, uint32_t n, float* out) {
+    for (uint32_t i = 0; i < n; i++) out[i] = powf_glibc(x[i], y[i], h_pow_log2_tab, h_exp2f_tab);
+}
+
+}  // extern "C"

@@ -1,0 +1,357 @@
+// rtc_host.cpp -- host-side scene math of librtc_amd.so (no GPU needed).
+//
+// The kernel consumes *inverse* transforms, the camera's pixel size and the
+// area light's per-cell vectors.  The reference computes all of those once per
+// scene on the CPU with a particular sequence of f32 operations (recursive
+// cofactor expansion, divide-by-determinant, libm tanf/sinf/cosf ...).  To be a
+// drop-in, the flattened scene must hold the same bits, so this file restates
+// that arithmetic -- with fixed-size templates instead of Vec<Vec<f32>>.
+//
+// Compiled with -ffp-contract=off: rustc does not contract a*b+c.
+// Citations: file:line under /root/reference/lib/src.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "rtc_internal.h"
+
+namespace rtc {
+
+thread_local std::string g_last_error;
+
+rtc_status fail(rtc_status code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+// ---- matrix.rs:145-196: determinant by cofactor expansion along row 0 -------
+template <int N>
+struct Det {
+    static float of(const float* a) {
+        float det = 0.0f;  // `let mut det = 0.0; det += cofactor * data[0][col]` (matrix.rs:151-158)
+        for (int col = 0; col < N; col++) {
+            float sub[(N - 1) * (N - 1)];
+            submatrix<N>(a, 0, col, sub);
+            float minor = Det<N - 1>::of(sub);
+            float cof = (col % 2 == 0) ? minor : -minor;
+            det += cof * a[col];
+        }
+        return det;
+    }
+};
+template <>
+struct Det<2> {
+    static float of(const float* a) { return a[0] * a[3] - a[1] * a[2]; }  // matrix.rs:147-148
+};
+
+template <int N>
+float minor_of(const float* a, int row, int col) {
+    float sub[(N - 1) * (N - 1)];
+    submatrix<N>(a, row, col, sub);
+    return Det<N - 1>::of(sub);
+}
+template <>
+float minor_of<2>(const float* a, int row, int col) {
+    return a[(1 - row) * 2 + (1 - col)];  // 1x1 remainder (never used by the reference; kept total)
+}
+
+template <int N>
+float cofactor_of(const float* a, int row, int col) {  // matrix.rs:184-192
+    float m = minor_of<N>(a, row, col);
+    return ((row + col) % 2 == 0) ? m : -m;
+}
+
+template <int N>
+void inverse_of(const float* a, float* out) {  // matrix.rs:201-212
+    float det = Det<N>::of(a);
+    for (int row = 0; row < N; row++)
+        for (int col = 0; col < N; col++) out[col * N + row] = cofactor_of<N>(a, row, col) / det;
+}
+
+float determinant(const float* a, int n) {
+    switch (n) {
+        case 2: return Det<2>::of(a);
+        case 3: return Det<3>::of(a);
+        default: return Det<4>::of(a);
+    }
+}
+
+void inverse4(const float a[16], float out[16]) { inverse_of<4>(a, out); }
+
+void mat_mul4(const float a[16], const float b[16], float out[16]) {  // matrix.rs:86-103
+    float r[16];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            r[i * 4 + j] = a[i * 4 + 0] * b[0 * 4 + j] + a[i * 4 + 1] * b[1 * 4 + j] + a[i * 4 + 2] * b[2 * 4 + j] +
+                           a[i * 4 + 3] * b[3 * 4 + j];
+    std::memcpy(out, r, sizeof(r));
+}
+
+void mat_vec4(const float a[16], const float v[4], float out[4]) {  // matrix.rs:73-84
+    float r[4];
+    for (int i = 0; i < 4; i++) r[i] = a[i * 4] * v[0] + a[i * 4 + 1] * v[1] + a[i * 4 + 2] * v[2] + a[i * 4 + 3] * v[3];
+    std::memcpy(out, r, sizeof(r));
+}
+
+static void set16(float out[16], float a, float b, float c, float d, float e, float f, float g, float h, float i,
+                  float j, float k, float l, float m, float n, float o, float p) {
+    const float v[16] = {a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, p};
+    std::memcpy(out, v, sizeof(v));
+}
+
+float magnitude4(const float v[4]) {  // tuple.rs:29-33
+    return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+}
+void norm4(const float v[4], float out[4]) {  // tuple.rs:34-43 (w untouched)
+    float m = magnitude4(v);
+    float r[4] = {v[0] / m, v[1] / m, v[2] / m, v[3]};
+    std::memcpy(out, r, sizeof(r));
+}
+void cross4(const float a[4], const float b[4], float out[4]) {  // tuple.rs:47-55
+    float r[4] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0], 0.0f};
+    std::memcpy(out, r, sizeof(r));
+}
+
+bool is_affine(const float m[16]) { return m[12] == 0.0f && m[13] == 0.0f && m[14] == 0.0f && m[15] == 1.0f; }
+
+}  // namespace rtc
+
+using namespace rtc;
+
+extern "C" {
+
+const char* rtc_last_error(void) { return g_last_error.c_str(); }
+int32_t rtc_abi_version(void) { return RTC_ABI_VERSION; }
+
+void rtc_translation(float x, float y, float z, float out[16]) { set16(out, 1, 0, 0, x, 0, 1, 0, y, 0, 0, 1, z, 0, 0, 0, 1); }
+void rtc_scaling(float x, float y, float z, float out[16]) { set16(out, x, 0, 0, 0, 0, y, 0, 0, 0, 0, z, 0, 0, 0, 0, 1); }
+// f32::cos / f32::sin lower to libm cosf / sinf on Linux (transformations.rs:13-14)
+void rtc_rotation_x(float r, float out[16]) {
+    float c = cosf(r), s = sinf(r);
+    set16(out, 1, 0, 0, 0, 0, c, -s, 0, 0, s, c, 0, 0, 0, 0, 1);
+}
+void rtc_rotation_y(float r, float out[16]) {
+    float c = cosf(r), s = sinf(r);
+    set16(out, c, 0, s, 0, 0, 1, 0, 0, -s, 0, c, 0, 0, 0, 0, 1);
+}
+void rtc_rotation_z(float r, float out[16]) {
+    float c = cosf(r), s = sinf(r);
+    set16(out, c, -s, 0, 0, s, c, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1);
+}
+void rtc_shearing(float xy, float xz, float yx, float yz, float zx, float zy, float out[16]) {
+    set16(out, 1, xy, xz, 0, yx, 1, yz, 0, zx, zy, 1, 0, 0, 0, 0, 1);
+}
+void rtc_view_transform(const float from[4], const float to[4], const float up[4], float out[16]) {
+    // transformations.rs:57-68
+    float diff[4] = {to[0] - from[0], to[1] - from[1], to[2] - from[2], to[3] - from[3]};
+    float forward[4], upn[4], left[4], true_up[4];
+    norm4(diff, forward);
+    norm4(up, upn);
+    cross4(forward, upn, left);
+    cross4(left, forward, true_up);
+    float orientation[16], tr[16];
+    set16(orientation, left[0], left[1], left[2], 0, true_up[0], true_up[1], true_up[2], 0, -forward[0], -forward[1],
+          -forward[2], 0, 0, 0, 0, 1);
+    rtc_translation(-from[0], -from[1], -from[2], tr);
+    mat_mul4(orientation, tr, out);
+}
+void rtc_mat_mul(const float a[16], const float b[16], float out[16]) { mat_mul4(a, b, out); }
+void rtc_mat_vec(const float a[16], const float v[4], float out[4]) { mat_vec4(a, v, out); }
+void rtc_mat_transpose(const float* a, int n, float* out) {
+    float r[16];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) r[j * n + i] = a[i * n + j];
+    std::memcpy(out, r, sizeof(float) * n * n);
+}
+float rtc_mat_determinant(const float* a, int n) { return determinant(a, n); }
+void rtc_mat_submatrix(const float* a, int n, int row, int col, float* out) {
+    if (n == 4) submatrix<4>(a, row, col, out);
+    else if (n == 3) submatrix<3>(a, row, col, out);
+    else submatrix<2>(a, row, col, out);
+}
+float rtc_mat_minor(const float* a, int n, int row, int col) {
+    return n == 4 ? minor_of<4>(a, row, col) : n == 3 ? minor_of<3>(a, row, col) : minor_of<2>(a, row, col);
+}
+float rtc_mat_cofactor(const float* a, int n, int row, int col) {
+    return n == 4 ? cofactor_of<4>(a, row, col) : n == 3 ? cofactor_of<3>(a, row, col) : cofactor_of<2>(a, row, col);
+}
+rtc_status rtc_mat_inverse(const float* a, int n, float* out) {
+    if (!a || !out || n < 2 || n > 4) return fail(RTC_ERR_INVALID_ARG, "rtc_mat_inverse: n must be 2..4");
+    float r[16];
+    if (n == 4) inverse_of<4>(a, r);
+    else if (n == 3) inverse_of<3>(a, r);
+    else inverse_of<2>(a, r);
+    std::memcpy(out, r, sizeof(float) * n * n);
+    return RTC_OK;
+}
+float rtc_magnitude(const float v[4]) { return magnitude4(v); }
+void rtc_norm(const float v[4], float out[4]) { norm4(v, out); }
+float rtc_dot(const float a[4], const float b[4]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + (a[3] * b[3]); }
+void rtc_cross(const float a[4], const float b[4], float out[4]) { cross4(a, b, out); }
+void rtc_reflect(const float in[4], const float n[4], float out[4]) {
+    // ray.rs:43: -(normal * 2.0 * in.dot(normal) - in)
+    float d = rtc_dot(in, n);
+    float r[4];
+    for (int i = 0; i < 4; i++) r[i] = -(n[i] * 2.0f * d - in[i]);
+    std::memcpy(out, r, sizeof(r));
+}
+
+void rtc_material_default(rtc_material* m) {  // material.rs:20-47
+    m->color[0] = m->color[1] = m->color[2] = 1.0f;
+    m->ambient = 0.1f;
+    m->diffuse = 0.9f;
+    m->specular = 0.9f;
+    m->shininess = 200.0f;
+    m->reflective = 0.0f;
+    m->transparency = 0.0f;
+    m->refractive_index = 1.0f;
+}
+
+rtc_status rtc_object_init(rtc_object* out, int32_t kind, const float transform[16], const rtc_material* m) {
+    if (!out || !transform) return fail(RTC_ERR_INVALID_ARG, "rtc_object_init: null argument");
+    if (kind < RTC_SPHERE || kind > RTC_CYLINDER) return fail(RTC_ERR_UNSUPPORTED, "rtc_object_init: unknown shape kind %d", kind);
+    out->kind = kind;
+    out->casts_shadow = 1;  // base_shape.rs:31
+    out->closed = 0;        // cylinder.rs:41
+    out->min_y = -INFINITY; // cylinder.rs:39
+    out->max_y = INFINITY;  // cylinder.rs:40
+    inverse4(transform, out->inv);  // base_shape.rs:58
+    if (m) out->material = *m;
+    else rtc_material_default(&out->material);
+    return RTC_OK;
+}
+
+void rtc_point_light(const float position[4], const float intensity[3], rtc_light* out) {
+    std::memset(out, 0, sizeof(*out));
+    out->kind = RTC_LIGHT_POINT;
+    std::memcpy(out->position, position, sizeof(float) * 4);
+    std::memcpy(out->intensity, intensity, sizeof(float) * 3);
+    out->u_steps = out->v_steps = 1;
+}
+
+rtc_status rtc_rectangle_light(const float intensity[3], const float corner[4], const float u_vec[4], int32_t u_steps,
+                               const float v_vec[4], int32_t v_steps, int32_t jitter_mode, float jitter_const,
+                               uint32_t jitter_seed, rtc_light* out) {
+    if (!out || !intensity || !corner || !u_vec || !v_vec) return fail(RTC_ERR_INVALID_ARG, "rtc_rectangle_light: null argument");
+    if (u_steps <= 0 || v_steps <= 0) return fail(RTC_ERR_INVALID_ARG, "rtc_rectangle_light: steps must be positive");
+    if (jitter_mode != RTC_JITTER_CONSTANT && jitter_mode != RTC_JITTER_HASHED)
+        return fail(RTC_ERR_UNSUPPORTED, "rtc_rectangle_light: jitter mode %d cannot run on the device", jitter_mode);
+    std::memset(out, 0, sizeof(*out));
+    out->kind = RTC_LIGHT_RECT;
+    std::memcpy(out->intensity, intensity, sizeof(float) * 3);
+    std::memcpy(out->corner, corner, sizeof(float) * 4);
+    for (int i = 0; i < 4; i++) {
+        out->u_vec[i] = u_vec[i] / (float)u_steps;  // rectangle_light.rs:51
+        out->v_vec[i] = v_vec[i] / (float)v_steps;  // :52
+        // :57  corner + (u_vec / 2.) + (v_vec / 2.)
+        out->position[i] = corner[i] + (u_vec[i] / 2.0f) + (v_vec[i] / 2.0f);
+    }
+    out->u_steps = u_steps;
+    out->v_steps = v_steps;
+    out->jitter_mode = jitter_mode;
+    out->jitter_const = jitter_const;
+    out->jitter_seed = jitter_seed;
+    return RTC_OK;
+}
+
+rtc_status rtc_camera_new(uint32_t width, uint32_t height, float fov, const float transform[16], rtc_camera* out) {
+    if (!out || !transform) return fail(RTC_ERR_INVALID_ARG, "rtc_camera_new: null argument");
+    if (width == 0 || height == 0) return fail(RTC_ERR_INVALID_ARG, "rtc_camera_new: empty canvas");
+    // camera.rs:35-46; f32::tan -> libm tanf
+    float half_view = tanf(fov / 2.0f);
+    float aspect = (float)width / (float)height;
+    if (aspect >= 1.0f) {
+        out->half_width = half_view;
+        out->half_height = half_view / aspect;
+    } else {
+        out->half_width = half_view * aspect;
+        out->half_height = half_view;
+    }
+    out->pixel_size = (out->half_width * 2.0f) / (float)width;
+    out->width = width;
+    out->height = height;
+    out->field_of_view = fov;
+    inverse4(transform, out->inv);
+    return RTC_OK;
+}
+
+void rtc_ray_for_pixel(const rtc_camera* c, uint32_t x, uint32_t y, float origin[4], float direction[4]) {
+    // camera.rs:60-74
+    float x_offset = ((float)x + 0.5f) * c->pixel_size;
+    float y_offset = ((float)y + 0.5f) * c->pixel_size;
+    float p[4] = {c->half_width - x_offset, c->half_height - y_offset, -1.0f, 1.0f};
+    float zero[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+    float pixel[4];
+    mat_vec4(c->inv, p, pixel);
+    mat_vec4(c->inv, zero, origin);
+    float diff[4] = {pixel[0] - origin[0], pixel[1] - origin[1], pixel[2] - origin[2], pixel[3] - origin[3]};
+    norm4(diff, direction);
+}
+
+uint32_t rtc_partition_rows(uint32_t height, const rtc_partition* part) { return partition_rows(height, part); }
+
+// ---- Canvas::to_ppm, canvas.rs:39-96 ------------------------------------------
+static inline unsigned scale_color(float c) {
+    // (c * 255).min(255).max(0) as u8: f32::min/max return the non-NaN operand; `as u8` truncates
+    float v = fmaxf(fminf(c * 255.0f, 255.0f), 0.0f);
+    return (unsigned)(uint8_t)v;
+}
+
+rtc_status rtc_to_ppm(const float* rgb, uint32_t w, uint32_t h, char** out_text, uint64_t* out_len) {
+    if (!rgb || !out_text || !out_len) return fail(RTC_ERR_INVALID_ARG, "rtc_to_ppm: null argument");
+    // Single pass into one growing buffer; a row's text is at most 12 bytes per pixel + newlines.
+    std::string ppm;
+    ppm.reserve((size_t)w * h * 12 + 64);
+    char head[64];
+    snprintf(head, sizeof(head), "P3\n%u %u\n255\n", w, h);
+    ppm += head;
+    for (uint32_t row = 0; row < h; row++) {
+        size_t line_len = 0;  // length of `current_line` (canvas.rs:69)
+        auto put_value = [&](unsigned v) {
+            char tmp[4];
+            int n = 0;
+            if (v >= 100) tmp[n++] = (char)('0' + v / 100);
+            if (v >= 10) tmp[n++] = (char)('0' + (v / 10) % 10);
+            tmp[n++] = (char)('0' + v % 10);
+            ppm.append(tmp, n);
+            line_len += n;
+        };
+        auto separator = [&]() {  // write_rgb_separator, canvas.rs:47-55 (70 - 3 = 67)
+            if (line_len < 67) {
+                ppm.push_back(' ');
+                line_len++;
+            } else {
+                ppm.push_back('\n');
+                line_len = 0;
+            }
+        };
+        for (uint32_t col = 0; col < w; col++) {
+            const float* p = rgb + ((size_t)row * w + col) * 3;
+            put_value(scale_color(p[0]));
+            separator();
+            put_value(scale_color(p[1]));
+            separator();
+            put_value(scale_color(p[2]));
+            if (col != w - 1) separator();
+        }
+        if (line_len != 0) ppm.push_back('\n');  // canvas.rs:90-93
+    }
+    char* out = (char*)std::malloc(ppm.size() + 1);
+    if (!out) return fail(RTC_ERR_INVALID_ARG, "rtc_to_ppm: out of memory");
+    std::memcpy(out, ppm.data(), ppm.size());
+    out[ppm.size()] = 0;
+    *out_text = out;
+    *out_len = ppm.size();
+    return RTC_OK;
+}
+
+void rtc_free(void* p) { std::free(p); }
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// rtc_internal.h -- declarations shared by the host and device translation
+// units of librtc_amd.so.  Not part of the public ABI (that is include/rtc.h).
+#ifndef RTC_INTERNAL_H
+#define RTC_INTERNAL_H
+
+#include <cstdarg>
+#include <cstdint>
+
+#include "rtc.h"
+
+namespace rtc {
+
+rtc_status fail(rtc_status code, const char* fmt, ...);
+
+// matrix.rs:163-182 -- drop one row and one column of a row-major NxN matrix
+template <int N>
+inline void submatrix(const float* a, int remove_row, int remove_col, float* out) {
+    int k = 0;
+    for (int r = 0; r < N; r++) {
+        if (r == remove_row) continue;
+        for (int c = 0; c < N; c++) {
+            if (c == remove_col) continue;
+            out[k++] = a[r * N + c];
+        }
+    }
+}
+
+float determinant(const float* a, int n);
+void inverse4(const float a[16], float out[16]);
+void mat_mul4(const float a[16], const float b[16], float out[16]);
+void mat_vec4(const float a[16], const float v[4], float out[4]);
+float magnitude4(const float v[4]);
+void norm4(const float v[4], float out[4]);
+void cross4(const float a[4], const float b[4], float out[4]);
+bool is_affine(const float m[16]);
+
+// Band partition of rows (rtc_partition in rtc.h): resolved form.
+struct Partition {
+    uint32_t band_rows, n_parts, part;
+};
+inline Partition resolve(const rtc_partition* p) {
+    Partition r = {64u, 1u, 0u};
+    if (p) {
+        if (p->band_rows) r.band_rows = p->band_rows;
+        if (p->n_parts) r.n_parts = p->n_parts;
+        r.part = p->part;
+    }
+    return r;
+}
+inline uint32_t partition_rows(uint32_t height, const rtc_partition* p) {
+    Partition q = resolve(p);
+    if (q.part >= q.n_parts) return 0;
+    uint32_t n_bands = (height + q.band_rows - 1) / q.band_rows;
+    uint32_t rows = 0;
+    for (uint32_t b = q.part; b < n_bands; b += q.n_parts) {
+        uint32_t y0 = b * q.band_rows;
+        uint32_t y1 = y0 + q.band_rows < height ? y0 + q.band_rows : height;
+        rows += y1 - y0;
+    }
+    return rows;
+}
+
+}  // namespace rtc
+
+#endif

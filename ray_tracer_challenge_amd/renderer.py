@@ -1,0 +1,77 @@
+"""Device-resident rendering: scene uploaded once, output left in HBM.
+
+`Renderer` wraps the persistent-context half of the C ABI (rtc_ctx_*).
+PyTorch appears here only as plumbing -- it owns the output tensor and the
+stream, and (in dist.py) carries the RCCL gather.  The kernel launch itself goes
+through librtc_amd.so with raw device pointers.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class Renderer:
+    def __init__(self, world, camera, device=None):
+        if not torch.cuda.is_available():
+            raise L.RtcError(L.RTC_ERR_NO_DEVICE, "no GPU visible to torch; the render path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.width, self.height = camera.width, camera.height
+        self._ctx = C.c_void_p()
+        L.check(L.lib().rtc_ctx_create(self.device.index, C.byref(self._ctx)))
+        self._keep = None
+        self.set_scene(world, camera)
+
+    def set_scene(self, world, camera):
+        cs = world._c()
+        self._keep = (cs, camera)
+        L.check(L.lib().rtc_ctx_set_scene(self._ctx, C.byref(cs.scene), C.byref(camera._cam)))
+        self.width, self.height = camera.width, camera.height
+
+    def close(self):
+        if self._ctx:
+            L.lib().rtc_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def partition(band_rows=64, n_parts=1, part=0):
+        return L.rtc_partition(band_rows, n_parts, part)
+
+    def rows(self, part=None):
+        return int(L.lib().rtc_partition_rows(self.height, C.byref(part) if part is not None else None))
+
+    def alloc(self, part=None):
+        return torch.empty((self.rows(part), self.width, 3), dtype=torch.float32, device=self.device)
+
+    def render(self, depth, out=None, part=None, stream=None):
+        """Launches the render kernel on `stream` (default: torch's current stream); asynchronous."""
+        if out is None:
+            out = self.alloc(part)
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+        assert out.numel() == self.rows(part) * self.width * 3
+        s = torch.cuda.current_stream(self.device) if stream is None else stream
+        L.check(L.lib().rtc_ctx_render(self._ctx, int(depth), C.byref(part) if part is not None else None,
+                                       C.c_void_p(out.data_ptr()), C.c_void_p(s.cuda_stream)))
+        return out
+
+    def stats(self):
+        """Synchronises with the last render and returns its counters."""
+        st = L.rtc_stats()
+        L.check(L.lib().rtc_ctx_stats(self._ctx, C.byref(st)))
+        return {"rays": int(st.rays), "shaded_hits": int(st.shaded_hits), "pixels": int(st.pixels),
+                "kernel_ms": float(st.kernel_ms), "launches": int(st.launches), "rows": int(st.rows)}
+
+    def quantize(self, rgb, stream=None):
+        """canvas.rs:39-43 scale_color on the device: f32 tensor -> u8 tensor of the same shape."""
+        out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
+        s = torch.cuda.current_stream(self.device) if stream is None else stream
+        L.check(L.lib().rtc_ctx_quantize(self._ctx, C.c_void_p(rgb.data_ptr()), rgb.numel(),
+                                         C.c_void_p(out.data_ptr()), C.c_void_p(s.cuda_stream)))
+        return out

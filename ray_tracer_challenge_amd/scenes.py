@@ -1,0 +1,141 @@
+"""Scene scripts for the BASELINE.json configurations and the in-scope demos.
+
+Each function returns (world, camera, depth) built with the mirror API of
+api.py -- i.e. exactly what the corresponding demos/src/bin/*.rs file does before
+it calls camera.render(world, depth).  Literals are the reference's.
+"""
+import numpy as np
+
+from .api import (Camera, Cube, Cylinder, Material, Plane, PointLight, RectangleLight, Sphere, World, chain, color,
+                  identity_4x4, point, rotation_x, rotation_y, scaling, shearing, translation, vector, view_transform)
+
+f32 = np.float32
+PI = f32(3.14159265358979323846264338327950288)  # std::f32::consts::PI
+
+DEFAULT_SEED = 0x5EED5EED
+
+
+def soft_shadows(width=1000, height=400, jitter=("hashed", DEFAULT_SEED)):
+    """demos/src/bin/soft_shadows.rs:33-169 (C1: 1000x400, C3: 4096x4096)."""
+    light = RectangleLight(color(1.5, 1.5, 1.5), point(-1, 2, 4), vector(2, 0, 0), 10, vector(0, 2, 0), 10, jitter)
+    lampshade = Cube(chain(translation(0.0, 3.0, 4.0), scaling(1.0, 1.0, 0.01)),
+                     Material(color=(1.5, 1.5, 1.5), ambient=1.0, diffuse=0.0, specular=0.0), casts_shadow=False)
+    floor = Plane(identity_4x4(), Material(color=(1, 1, 1), ambient=0.025, diffuse=0.67, specular=0.0))
+    sphere_1 = Sphere(chain(translation(0.5, 0.5, 0.0), scaling(0.5, 0.5, 0.5)),
+                      Material(color=(1, 0, 0), ambient=0.1, specular=0.0, diffuse=0.6, reflective=0.3))
+    sphere_2 = Sphere(chain(translation(-0.25, 0.33, 0.0), scaling(0.33, 0.33, 0.33)),
+                      Material(color=(0.5, 0.5, 1), ambient=0.1, specular=0.0, diffuse=0.6, reflective=0.3))
+    world = World([lampshade, floor, sphere_1, sphere_2], light)
+    camera = Camera(width, height, PI / f32(4.0),
+                    view_transform(point(-3, 1, 2.5), point(0, 0.5, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
+def single_sphere(width=1024, height=1024):
+    """C2: one default sphere + point light, primary and shadow rays only (world.rs:32-48 family)."""
+    world = World([Sphere(identity_4x4(), Material())], PointLight(point(-10, 10, -10), color(1, 1, 1)))
+    camera = Camera(width, height, PI / f32(3.0), view_transform(point(0, 0, -5), point(0, 0, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
+def glass_and_mirror(width=4096, height=4096):
+    """C4: the demo's glass ball (reflect_refract.rs:129-142, casting shadows) over a mirror plane."""
+    ball = Sphere(translation(0.0, 1.0, 0.0),
+                  Material(color=(0, 0, 0), specular=1.0, shininess=300.0, transparency=1.0, refractive_index=1.52,
+                           reflective=1.0))
+    floor = Plane(identity_4x4(), Material(color=(0.8, 0.8, 0.8), specular=0.0, reflective=0.8))
+    world = World([ball, floor], PointLight(point(-10, 10, -10), color(1, 1, 1)))
+    camera = Camera(width, height, PI / f32(3.0), view_transform(point(0, 1.5, -5), point(0, 1, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
+def _xorshift32(state):
+    state ^= (state << 13) & 0xFFFFFFFF
+    state ^= state >> 17
+    state ^= (state << 5) & 0xFFFFFFFF
+    return state & 0xFFFFFFFF
+
+
+def sphere_grid(width=8192, height=8192, n=8):
+    """C5: n*n unit spheres scaled 0.4 on a grid, colours from xorshift32."""
+    objects = []
+    s = 0x9E3779B9
+    for i in range(n):
+        for j in range(n):
+            rgb = []
+            for _ in range(3):
+                s = _xorshift32(s)
+                rgb.append(float(f32(0.2) + f32(0.8) * f32(s / 4294967296.0)))
+            m = Material(color=tuple(rgb), reflective=0.3 if (i + j) % 2 else 0.0)
+            objects.append(Sphere(chain(translation(-7.0 + 2.0 * i, 0.4, 2.0 * j), scaling(0.4, 0.4, 0.4)), m))
+    world = World(objects, PointLight(point(-10, 20, -10), color(1, 1, 1)))
+    camera = Camera(width, height, PI / f32(3.0), view_transform(point(0, 12, -14), point(0, 0, 7), vector(0, 1, 0)))
+    return world, camera, 5
+
+
+def first_scene(width=1000, height=500):
+    """demos/src/bin/first_scene.rs:26-107 (six spheres incl. sheared / rotated ones)."""
+    room = Material(color=(1, 0.9, 0.9), specular=0.0)
+    floor = Sphere(scaling(10.0, 0.01, 10.0), room)
+    left_wall = Sphere(chain(translation(0.0, 0.0, 5.0), rotation_y(-PI / f32(4.0)), rotation_x(PI / f32(2.0)),
+                             scaling(10.0, 0.01, 10.0)), room)
+    right_wall = Sphere(chain(translation(0.0, 0.0, 5.0), rotation_y(PI / f32(4.0)), rotation_x(PI / f32(2.0)),
+                              scaling(10.0, 0.01, 10.0)), room)
+    middle = Sphere(translation(-0.5, 1.0, 0.5), Material(color=(0.1, 1, 0.5), diffuse=0.7, specular=0.3))
+    right = Sphere(chain(shearing(0.0, 1.0, 0.0, 0.0, 0.0, 1.0), translation(1.5, 0.5, -0.5), scaling(0.5, 0.5, 0.5)),
+                   Material(color=(0.5, 1, 0.1), diffuse=0.7, specular=0.3))
+    left = Sphere(chain(translation(-1.5, 0.33, -0.75), scaling(0.33, 0.33, 0.33)),
+                  Material(color=(1, 0.8, 0.1), diffuse=0.7, specular=0.3))
+    world = World([floor, left_wall, right_wall, left, middle, right], PointLight(point(-10, 10, -10), color(1, 1, 1)))
+    camera = Camera(width, height, PI / f32(3.0), view_transform(point(0, 1.5, -5), point(0, 1, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
+def first_plane(width=100, height=50):
+    """demos/src/bin/first_plane.rs:23-86."""
+    floor = Plane(scaling(10.0, 0.01, 10.0), Material(color=(1, 0.9, 0.9), specular=0.0))
+    middle = Sphere(translation(-0.5, 1.0, 0.5), Material(color=(0.1, 1, 0.5), diffuse=0.7, specular=0.3))
+    right = Sphere(chain(shearing(0.0, 1.0, 0.0, 0.0, 0.0, 1.0), translation(1.5, 0.5, -0.5), scaling(0.5, 0.5, 0.5)),
+                   Material(color=(0.5, 1, 0.1), diffuse=0.7, specular=0.3))
+    left = Sphere(chain(translation(-1.5, 0.33, -0.75), scaling(0.33, 0.33, 0.33)),
+                  Material(color=(1, 0.8, 0.1), diffuse=0.7, specular=0.3))
+    world = World([floor, left, middle, right], PointLight(point(-10, 10, -10), color(1, 1, 1)))
+    camera = Camera(width, height, PI / f32(3.0), view_transform(point(0, 1.5, -5), point(0, 1, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
+def shapes_medley(width=256, height=192, jitter=("hashed", 7)):
+    """All four shape kinds, nested transparent objects, a non-casting object and an area light:
+    a parity stress scene (not a reference demo).  The cylinders are the reflect_refract.rs one
+    (get_cylinder, :144-158) plus a closed glass one."""
+    floor = Plane(identity_4x4(), Material(color=(0.9, 0.9, 1.0), specular=0.1, reflective=0.25))
+    mirror_cyl = Cylinder(chain(translation(2.2, 0.0, 2.0), scaling(0.33, 1.8, 0.33)),
+                          Material(reflective=1.0, color=(0.5, 0.5, 0.5), shininess=300.0, specular=0.8),
+                          minimum_y=0.0, maximum_y=1.5)
+    glass_cyl = Cylinder(chain(translation(-2.0, 0.0, 1.0), scaling(0.6, 1.0, 0.6)),
+                         Material(color=(0.05, 0.1, 0.05), transparency=0.9, refractive_index=1.52, reflective=0.3,
+                                  diffuse=0.3),
+                         minimum_y=0.0, maximum_y=1.2, closed=True)
+    outer = Sphere(chain(translation(0.0, 1.0, 0.5), scaling(1.0, 1.0, 1.0)),
+                   Material(color=(0, 0, 0.05), specular=1.0, shininess=300.0, transparency=1.0,
+                            refractive_index=1.52, reflective=0.9))
+    inner = Sphere(chain(translation(0.0, 1.0, 0.5), scaling(0.5, 0.5, 0.5)),
+                   Material(color=(0.1, 0, 0), transparency=1.0, refractive_index=1.00029, reflective=0.2,
+                            diffuse=0.2))
+    box = Cube(chain(translation(-0.6, 0.4, -1.2), rotation_y(f32(0.5)), scaling(0.4, 0.4, 0.4)),
+               Material(color=(1.0, 0.6, 0.1), diffuse=0.7, specular=0.3, shininess=50.0))
+    ghost = Cube(chain(translation(1.2, 0.5, -1.0), scaling(0.3, 0.5, 0.3)),
+                 Material(color=(0.2, 0.9, 0.3), ambient=0.3), casts_shadow=False)
+    light = RectangleLight(color(1.2, 1.2, 1.2), point(-3, 5, -4), vector(1.5, 0, 0), 4, vector(0, 0, 1.5), 3, jitter)
+    world = World([floor, mirror_cyl, glass_cyl, outer, inner, box, ghost], light)
+    camera = Camera(width, height, PI / f32(3.0), view_transform(point(0.5, 2.2, -6.0), point(0, 0.9, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
+CONFIGS = {
+    "C1": lambda **kw: soft_shadows(1000, 400, **kw),
+    "C2": lambda **kw: single_sphere(1024, 1024, **kw),
+    "C3": lambda **kw: soft_shadows(4096, 4096, **kw),
+    "C4": lambda **kw: glass_and_mirror(4096, 4096, **kw),
+    "C5": lambda **kw: sphere_grid(8192, 8192, **kw),
+}
