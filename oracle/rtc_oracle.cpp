@@ -411,10 +411,10 @@ inline uint32_t mix32(uint32_t x) {
 inline uint32_t jitter_hash(uint32_t seed, uint32_t pixel, uint32_t path, uint32_t cell, uint32_t draw) {
     uint32_t a = mix32(pixel ^ seed);
     uint32_t b = mix32(a + path * 0x9E3779B9u);
-    uint32_t k = b + cell * 0x85EBCA6Bu;
-    return mix32(draw ? (k ^ 0x68E31DA4u) : k);
+    uint32_t h = mix32(b + cell * 0x85EBCA6Bu);
+    return draw ? (h & 0xffffu) : (h >> 16);  // one hash per cell: draw 0 = high half, draw 1 = low half
 }
-inline float jitter_value(uint32_t h) { return (float)((h >> 9) + 1u) * 1.1920929e-7f; }  // (0,1], 2^-23 steps
+inline float jitter_value(uint32_t h16) { return (float)(h16 + 1u) * 1.52587890625e-05f; }  // (0,1], 2^-16 steps
 
 struct Light {
     int kind;

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librtc_amd.so")
+# RTC_AMD_LIB: development override used by tools/ab.py to load a kernel variant
+LIB_PATH = os.environ.get("RTC_AMD_LIB") or os.path.join(HERE, "librtc_amd.so")
 
 RTC_OK = 0
 RTC_ERR_INVALID_ARG, RTC_ERR_UNSUPPORTED, RTC_ERR_NO_LIGHT, RTC_ERR_DEVICE, RTC_ERR_NO_DEVICE = -1, -2, -3, -4, -5

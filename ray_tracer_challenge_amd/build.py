@@ -19,6 +19,9 @@ HEADERS = [os.path.join(CSRC, "rtc_internal.h"), os.path.join(ROOT, "include", "
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off",  # arithmetic contract, host and device
+    # packed-f32 VALU (v_pk_mul/add_f32) is slower than two scalar ops on gfx950 for this kernel:
+    # measured 10.25 ms -> 8.40 ms on C3 with identical output (profiles/README.md, A/B "noslp")
+    "-fno-slp-vectorize",
     "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
 ]
 

@@ -246,45 +246,87 @@ struct SceneHdr {
 };
 
 // Structure-of-arrays scene records in HBM: 4 float4 of geometry (64 B) and
-// 3 float4 of material (48 B) per object.
+// 3 float4 of material (48 B) per object.  Every lane of a wave reads the same
+// record, so these loads are wave-uniform (s_load -> SGPRs).  The geometry is
+// split so that the common case -- a shadow ray against a scale+translate-only
+// object -- touches a single 16-byte record (`geo`):
+//   geo  = { m00, m11, m22, bits }          diagonal of t_inverse + kind/flags
+//   off0 = { m01, m02, m03, min_y }         off-diagonals, translation column,
+//   off1 = { m10, m12, m13, max_y }         cylinder bounds
+//   off2 = { m20, m21, m23, 0 }
 struct SceneSoA {
-    const float4* __restrict__ inv0;   // row 0 of t_inverse
-    const float4* __restrict__ inv1;
-    const float4* __restrict__ inv2;
-    const float4* __restrict__ shape;  // {min_y, max_y, bits(kind | casts<<8 | closed<<9), 0}
+    const float4* __restrict__ geo;
+    const float4* __restrict__ off0;
+    const float4* __restrict__ off1;
+    const float4* __restrict__ off2;
     const float4* __restrict__ mat_a;  // {r, g, b, ambient}
     const float4* __restrict__ mat_b;  // {diffuse, specular, shininess, reflective}
     const float4* __restrict__ mat_c;  // {transparency, refractive_index, 0, 0}
+};
+enum : uint32_t {
+    SHAPE_KIND_MASK = 0xffu,
+    SHAPE_NONE = 0xffu,      // padding record: never intersects (arrays are padded to a multiple of 8)
+    SHAPE_CASTS = 1u << 8,   // BaseShape.casts_shadow
+    SHAPE_CLOSED = 1u << 9,  // Cylinder.closed
+    SHAPE_DIAG = 1u << 10,   // t_inverse has no off-diagonal 3x3 terms (scale + translate only)
 };
 
 constexpr float PLANE_EPS = 1.1920929e-7f * 10000.0f;  // plane.rs:49  f32::EPSILON * 10000.0
 constexpr float SELF_EPS = 1.1920929e-7f * 10000.0f;   // world.rs:210
 constexpr float CLOSE_TO_ZERO = 0.000001f;             // cylinder.rs:82
 
-// shape.rs:57-70 + ray.rs:26-31 for an affine inverse: o' = M*o (w = 1), d' = M*d (w = 0)
-DI V3 xform_point(float4 r0, float4 r1, float4 r2, V3 p) {
-    return {r0.x * p.x + r0.y * p.y + r0.z * p.z + r0.w, r1.x * p.x + r1.y * p.y + r1.z * p.z + r1.w,
-            r2.x * p.x + r2.y * p.y + r2.z * p.z + r2.w};
+struct Obj {
+    float4 geo, off0, off1, off2;
+    uint32_t bits;
+    DI float min_y() const { return off0.w; }
+    DI float max_y() const { return off1.w; }
+};
+DI Obj load_obj(const SceneSoA& S, uint32_t i) {
+    Obj o;
+    o.geo = S.geo[i];
+    o.off0 = S.off0[i];
+    o.off1 = S.off1[i];
+    o.off2 = S.off2[i];
+    o.bits = __float_as_uint(o.geo.w);
+    return o;
 }
-DI V3 xform_vector(float4 r0, float4 r1, float4 r2, V3 v) {
-    return {r0.x * v.x + r0.y * v.y + r0.z * v.z, r1.x * v.x + r1.y * v.y + r1.z * v.z,
-            r2.x * v.x + r2.y * v.y + r2.z * v.z};
+
+// shape.rs:57-70 + ray.rs:26-31 for an affine inverse: o' = M*o (w = 1), d' = M*d (w = 0).
+// When the 3x3 part is diagonal the products with the (exactly zero) off-diagonal
+// entries are +-0 and adding them changes nothing, so they are skipped.
+DI V3 obj_point(const Obj& b, V3 p) {
+    if (b.bits & SHAPE_DIAG) return {b.geo.x * p.x + b.off0.z, b.geo.y * p.y + b.off1.z, b.geo.z * p.z + b.off2.z};
+    return {b.geo.x * p.x + b.off0.x * p.y + b.off0.y * p.z + b.off0.z,
+            b.off1.x * p.x + b.geo.y * p.y + b.off1.y * p.z + b.off1.z,
+            b.off2.x * p.x + b.off2.y * p.y + b.geo.z * p.z + b.off2.z};
+}
+DI V3 obj_vector(const Obj& b, V3 v) {
+    if (b.bits & SHAPE_DIAG) return {b.geo.x * v.x, b.geo.y * v.y, b.geo.z * v.z};
+    return {b.geo.x * v.x + b.off0.x * v.y + b.off0.y * v.z, b.off1.x * v.x + b.geo.y * v.y + b.off1.y * v.z,
+            b.off2.x * v.x + b.off2.y * v.y + b.geo.z * v.z};
 }
 // normal_to_world (shape.rs:72-146): transpose(t_inverse) * n, w := 0, normalise
-DI V3 xform_normal(float4 r0, float4 r1, float4 r2, V3 n) {
-    V3 w = {r0.x * n.x + r1.x * n.y + r2.x * n.z, r0.y * n.x + r1.y * n.y + r2.y * n.z,
-            r0.z * n.x + r1.z * n.y + r2.z * n.z};
+DI V3 obj_normal_to_world(const Obj& b, V3 n) {
+    V3 w = {b.geo.x * n.x + b.off1.x * n.y + b.off2.x * n.z, b.off0.x * n.x + b.geo.y * n.y + b.off2.y * n.z,
+            b.off0.y * n.x + b.off1.y * n.y + b.geo.z * n.z};
     return norm3(w);
 }
 
 // Calls f(t) for every intersection the reference's local_intersect would
 // push, in push order.  o, d: object-space ray.
+// `c` is the origin-only term of the sphere / cylinder quadratic (quadratic_c): rays that share
+// an origin (area-light shadow samples) compute it once.
+DI float quadratic_c(uint32_t kind, V3 o) {
+    if (kind == RTC_SPHERE) return (o.x * o.x + o.y * o.y + o.z * o.z) - 1.0f;  // sphere.rs:56
+    if (kind == RTC_CYLINDER) return o.x * o.x + o.z * o.z - 1.0f;              // cylinder.rs:95
+    return 0.0f;
+}
 template <class F>
-DI void local_intersect(uint32_t kind, float min_y, float max_y, bool closed, V3 o, V3 d, F&& f) {
+DI void local_intersect_c(uint32_t bits, float min_y, float max_y, V3 o, V3 d, float c, F&& f) {
+    const uint32_t kind = bits & SHAPE_KIND_MASK;
     if (kind == RTC_SPHERE) {  // sphere.rs:47-70
         float a = d.x * d.x + d.y * d.y + d.z * d.z;
         float b = 2.0f * (d.x * o.x + d.y * o.y + d.z * o.z);
-        float c = (o.x * o.x + o.y * o.y + o.z * o.z) - 1.0f;
         float disc = b * b - 4.0f * a * c;
         if (!(disc < 0.0f)) {
             float two_a = 2.0f * a;
@@ -308,12 +350,11 @@ DI void local_intersect(uint32_t kind, float min_y, float max_y, bool closed, V3
             f(tmin);
             f(tmax);
         }
-    } else {  // RTC_CYLINDER, cylinder.rs:52-59, 84-151
+    } else if (kind == RTC_CYLINDER) {  // cylinder.rs:52-59, 84-151
         int pushed = 0;
         float two_a = 2.0f * (d.x * d.x + d.z * d.z);
         if (!(fabsf(two_a) < CLOSE_TO_ZERO)) {
             float b = 2.0f * (o.x * d.x + o.z * d.z);
-            float c = o.x * o.x + o.z * o.z - 1.0f;
             float disc = b * b - 2.0f * two_a * c;
             if (!(disc < 0.0f)) {
                 float sq = sqrtf(disc);
@@ -336,7 +377,7 @@ DI void local_intersect(uint32_t kind, float min_y, float max_y, bool closed, V3
                 }
             }
         }
-        if (pushed < 2 && closed) {  // intersect_caps, cylinder.rs:132-151
+        if (pushed < 2 && (bits & SHAPE_CLOSED)) {  // intersect_caps, cylinder.rs:132-151
             float t = (min_y - o.y) / d.y;
             float cx = o.x + t * d.x, cz = o.z + t * d.z;
             if ((cx * cx + cz * cz) <= 1.0f + CLOSE_TO_ZERO) f(t);
@@ -346,6 +387,11 @@ DI void local_intersect(uint32_t kind, float min_y, float max_y, bool closed, V3
             if ((cx * cx + cz * cz) <= 1.0f + CLOSE_TO_ZERO) f(t);
         }
     }
+}
+
+template <class F>
+DI void local_intersect(uint32_t bits, float min_y, float max_y, V3 o, V3 d, F&& f) {
+    local_intersect_c(bits, min_y, max_y, o, d, quadratic_c(bits & SHAPE_KIND_MASK, o), f);
 }
 
 // local_norm_at for the four shapes (sphere.rs:71-73, plane.rs:57-59, cube.rs:66-80, cylinder.rs:62-72)
@@ -378,41 +424,138 @@ struct Counters {
     uint32_t shaded;  // shade_hit evaluations
 };
 
+// Applies `body(i)` to every object.  NOBJ > 0: the scene has at most NOBJ
+// objects and the loop is fully unrolled (record loads become loop-invariant
+// SGPR values, per-object state can live in registers); NOBJ == 0: any count.
+template <int NOBJ, class F>
+DI void for_each_object(const SceneHdr& H, F&& body) {
+    if constexpr (NOBJ > 0) {
+        // no `i < n_objects` guard: the record arrays are padded with SHAPE_NONE entries, so every
+        // load is unconditional and can be hoisted / issued ahead of the arithmetic that needs it
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)NOBJ; i++) body(i);
+    } else {
+        for (uint32_t i = 0; i < H.n_objects; i++) body(i);
+    }
+}
+
 // World::intersect + Intersection::hit (world.rs:52-60, intersection.rs:30-35)
 // without materialising or sorting the list: the hit is the first entry, in
 // (object order, push order), of the minimum among distances >= 0 -- which is
 // what a stable sort followed by a first-minimum scan selects.
+template <int NOBJ>
 DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d) {
     Hit best = {0.0f, -1};
-    for (uint32_t i = 0; i < H.n_objects; i++) {
-        float4 r0 = S.inv0[i], r1 = S.inv1[i], r2 = S.inv2[i], sh = S.shape[i];
-        uint32_t bits = __float_as_uint(sh.z);
-        V3 oo = xform_point(r0, r1, r2, o);
-        V3 od = xform_vector(r0, r1, r2, d);
-        local_intersect(bits & 0xff, sh.x, sh.y, (bits >> 9) & 1, oo, od, [&](float t) {
+    for_each_object<NOBJ>(H, [&](uint32_t i) {
+        Obj ob = load_obj(S, i);
+        if (NOBJ > 0 && (ob.bits & SHAPE_KIND_MASK) == SHAPE_NONE) return;  // padding record (wave-uniform)
+        V3 po = obj_point(ob, o);
+        V3 pd = obj_vector(ob, d);
+        local_intersect(ob.bits, ob.min_y(), ob.max_y(), po, pd, [&](float t) {
             if (t >= 0.0f && (best.obj < 0 || t < best.t)) {
                 best.t = t;
                 best.obj = (int)i;
             }
         });
-    }
+    });
     return best;
 }
 
 // world.rs:104-119
+template <int NOBJ>
 DI bool is_shadowed(const SceneHdr& H, const SceneSoA& S, V3 light_position, V3 p, Counters& cnt) {
     V3 v = light_position - p;
     float distance = mag3(v);
     V3 direction = norm3(v);
     cnt.rays++;
-    Hit h = nearest_hit(H, S, p, direction);
+    Hit h = nearest_hit<NOBJ>(H, S, p, direction);
     if (h.obj < 0) return false;
-    bool casts = (__float_as_uint(S.shape[h.obj].z) >> 8) & 1;
+    bool casts = (__float_as_uint(S.geo[h.obj].w) & SHAPE_CASTS) != 0;
     return casts && h.t < distance;
 }
 
+// ---- area-light shadow samples: many rays from one point -------------------------------------
+// Per shade point and object, the parts of World::is_shadowed that depend on the ray ORIGIN only:
+// the object-space origin (shape.rs:57-61) and the quadratic's constant term.
+struct ShadowPre {
+    V3 o;
+    float c;
+};
+template <int NOBJ>
+DI void shadow_prepare(const SceneHdr& H, const SceneSoA& S, V3 p, ShadowPre* pre) {
+    for_each_object<NOBJ>(H, [&](uint32_t i) {
+        Obj ob = load_obj(S, i);
+        pre[i].o = obj_point(ob, p);
+        pre[i].c = quadratic_c(ob.bits & SHAPE_KIND_MASK, pre[i].o);
+    });
+}
+// World::is_shadowed (world.rs:104-119) for light sample `lp`, given shadow_prepare's output.
+// Per object only its 16-byte `geo` record is fetched unless it is rotated/sheared or a cylinder.
+//
+// The reference answers "is the NEAREST hit a shadow caster closer than the light?".  That is a
+// pure function of the hit list, so it is evaluated in two passes without changing the answer:
+//   1. nearest hit among shadow CASTERS only, (t_c, i_c) in (distance, object order) order;
+//      if there is none, or t_c >= distance, the point is lit whatever the non-casters do;
+//   2. otherwise a non-caster hides that caster iff it has a hit t_n >= 0 that sorts before
+//      (t_c, i_c).  Only then are non-casters (the soft_shadows lampshade) intersected at all.
+// SIMPLE: every object is scale+translate-only and none is a cylinder (decided on the host), so the
+// loop-invariant uniform working set is 4 SGPRs per object and stays resident across the sample loop.
+template <int NOBJ, bool SIMPLE>
+DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* pre, V3 lp, V3 p, Counters& cnt) {
+    V3 v = lp - p;
+    float distance = mag3(v);
+    V3 dir = norm3(v);
+    cnt.rays++;
+    auto object_ts = [&](uint32_t i, const float4 g, uint32_t bits, auto&& f) {
+        V3 pd;
+        if (SIMPLE || (bits & SHAPE_DIAG)) {
+            pd = v3(g.x * dir.x, g.y * dir.y, g.z * dir.z);
+        } else {
+            const float4 a = S.off0[i], b = S.off1[i], c = S.off2[i];
+            pd = v3(g.x * dir.x + a.x * dir.y + a.y * dir.z, b.x * dir.x + g.y * dir.y + b.y * dir.z,
+                    c.x * dir.x + c.y * dir.y + g.z * dir.z);
+        }
+        float mn = 0.0f, mx = 0.0f;
+        if (!SIMPLE && (bits & SHAPE_KIND_MASK) == RTC_CYLINDER) {
+            mn = S.off0[i].w;
+            mx = S.off1[i].w;
+        }
+        local_intersect_c(bits, mn, mx, pre[i].o, pd, pre[i].c, f);
+    };
+    // pass 1: shadow casters
+    bool found = false;
+    float t_c = 0.0f;
+    uint32_t i_c = 0;
+    for_each_object<NOBJ>(H, [&](uint32_t i) {
+        const float4 g = S.geo[i];
+        const uint32_t bits = __float_as_uint(g.w);
+        if ((bits & SHAPE_KIND_MASK) == SHAPE_NONE || !(bits & SHAPE_CASTS)) return;  // wave-uniform
+        object_ts(i, g, bits, [&](float t) {
+            if (t >= 0.0f && (!found || t < t_c)) {
+                t_c = t;
+                i_c = i;
+                found = true;
+            }
+        });
+    });
+    bool shadowed = found && t_c < distance;
+    // pass 2: can a non-caster hide that caster?
+    if (shadowed) {
+        for_each_object<NOBJ>(H, [&](uint32_t i) {
+            const float4 g = S.geo[i];
+            const uint32_t bits = __float_as_uint(g.w);
+            if ((bits & SHAPE_KIND_MASK) == SHAPE_NONE || (bits & SHAPE_CASTS)) return;
+            object_ts(i, g, bits, [&](float t) {
+                if (t >= 0.0f && (t < t_c || (t == t_c && i < i_c))) shadowed = false;
+            });
+        });
+    }
+    return shadowed;
+}
+
 // Pinned jitter (DESIGN.md "Jitter"): counter-based hash keyed by
-// (pixel, path code, cell, draw) -> f32 in (0, 1] with 2^-23 resolution.
+// (pixel, path code, cell); one 32-bit hash per light cell, high half -> first
+// draw, low half -> second draw, each mapped to (0, 1] in 2^-16 steps.
 DI uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7feb352du;
@@ -425,31 +568,39 @@ DI uint32_t jitter_base(uint32_t seed, uint32_t pixel, uint32_t path) {
     uint32_t a = mix32(pixel ^ seed);
     return mix32(a + path * 0x9E3779B9u);
 }
-DI float jitter_value(uint32_t h) { return (float)((h >> 9) + 1u) * 1.1920929e-7f; }
+DI float jitter_value(uint32_t h16) { return (float)(h16 + 1u) * 1.52587890625e-05f; }
 
 // Light::intensity_at: point_light.rs:28-34, rectangle_light.rs:60-66, 76-88
+template <int NOBJ, bool SIMPLE>
 DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel, uint32_t path, Counters& cnt) {
     if (H.light_kind == RTC_LIGHT_POINT) {
-        return is_shadowed(H, S, v3(H.lpos[0], H.lpos[1], H.lpos[2]), p, cnt) ? 0.0f : 1.0f;
+        return is_shadowed<NOBJ>(H, S, v3(H.lpos[0], H.lpos[1], H.lpos[2]), p, cnt) ? 0.0f : 1.0f;
     }
     const V3 corner = v3(H.corner[0], H.corner[1], H.corner[2]);
     const V3 uvec = v3(H.uvec[0], H.uvec[1], H.uvec[2]);
     const V3 vvec = v3(H.vvec[0], H.vvec[1], H.vvec[2]);
     const bool hashed = H.jitter_mode == RTC_JITTER_HASHED;
-    const uint32_t base = hashed ? jitter_base(H.jitter_seed, pixel, path) : 0u;
+    uint32_t key = hashed ? jitter_base(H.jitter_seed, pixel, path) : 0u;
+    // every shadow ray of this shade point starts at p: do the origin-only work once per object
+    constexpr bool PRE = NOBJ > 0;
+    ShadowPre pre[PRE ? NOBJ : 1];
+    if constexpr (PRE) shadow_prepare<NOBJ>(H, S, p, pre);
     float total = 0.0f;
-    uint32_t cell = 0;
     for (int v = 0; v < H.v_steps; v++) {
-        for (int u = 0; u < H.u_steps; u++, cell++) {
+        for (int u = 0; u < H.u_steps; u++) {
             float j1 = H.jitter_const, j2 = H.jitter_const;
             if (hashed) {
-                uint32_t k = base + cell * 0x85EBCA6Bu;
-                j1 = jitter_value(mix32(k));
-                j2 = jitter_value(mix32(k ^ 0x68E31DA4u));
+                uint32_t h = mix32(key);
+                key += 0x85EBCA6Bu;  // key = base + cell * 0x85EBCA6B, cell = v * u_steps + u
+                j1 = jitter_value(h >> 16);
+                j2 = jitter_value(h & 0xffffu);
             }
             // corner + u_vec * (u + jitter1) + v_vec * (v + jitter2)
             V3 lp = corner + uvec * ((float)u + j1) + vvec * ((float)v + j2);
-            if (!is_shadowed(H, S, lp, p, cnt)) total += 1.0f;
+            bool blocked;
+            if constexpr (PRE) blocked = is_shadowed_pre<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt);
+            else blocked = is_shadowed<NOBJ>(H, S, lp, p, cnt);
+            if (!blocked) total += 1.0f;
         }
     }
     return total / H.cells_f;
@@ -484,18 +635,18 @@ DI V3 phong(const SceneHdr& H, float4 ma, float4 mb, V3 p, V3 eye, V3 n, float l
 // of its largest negative t (ties between objects: object order).  So the
 // "innermost container" is the odd-parity object with the largest
 // (t_max_negative, index); toggling the hit object then gives n2.
+template <int NOBJ>
 DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int hit_obj, float& n1, float& n2) {
     float t1 = 0.0f, t2 = 0.0f;  // best and runner-up container keys
     int c1 = -1, c2 = -1;
     bool hit_inside = false;
-    for (uint32_t i = 0; i < H.n_objects; i++) {
-        float4 r0 = S.inv0[i], r1 = S.inv1[i], r2 = S.inv2[i], sh = S.shape[i];
-        uint32_t bits = __float_as_uint(sh.z);
-        V3 oo = xform_point(r0, r1, r2, o);
-        V3 od = xform_vector(r0, r1, r2, d);
+    for_each_object<NOBJ>(H, [&](uint32_t i) {
+        Obj ob = load_obj(S, i);
+        V3 po = obj_point(ob, o);
+        V3 pd = obj_vector(ob, d);
         int negatives = 0;
         float tmax = 0.0f;
-        local_intersect(bits & 0xff, sh.x, sh.y, (bits >> 9) & 1, oo, od, [&](float t) {
+        local_intersect(ob.bits, ob.min_y(), ob.max_y(), po, pd, [&](float t) {
             if (t < 0.0f) {
                 if (negatives == 0 || t > tmax) tmax = t;
                 negatives++;
@@ -513,7 +664,7 @@ DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int
                 c2 = (int)i;
             }
         }
-    }
+    });
     const float vacuum = 1.0f;  // REFRACTION_VACCUM, constants.rs:6
     n1 = c1 >= 0 ? S.mat_c[c1].y : vacuum;
     if (!hit_inside) {
@@ -556,6 +707,7 @@ enum { F_WAIT_REFR = 1, F_HAS_REFR = 2, F_SCHLICK = 4 };
 // recursion (world.rs:121-162) unrolled into an explicit post-order stack.
 // `path` is the jitter path code: 1 at the root, 2p for the reflection child
 // of p, 2p+1 for its refraction child.
+template <int NOBJ, bool SIMPLE>
 DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint32_t pixel, Counters& cnt) {
     Frame stack[RTC_MAX_DEPTH];
     int sp = 0;
@@ -565,17 +717,16 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
     for (;;) {
         // ---------------- color_at(ray(o, d), rem)
         cnt.rays++;
-        Hit h = nearest_hit(H, S, o, d);
+        Hit h = nearest_hit<NOBJ>(H, S, o, d);
         bool descend = false;
         ret = v3(0.0f, 0.0f, 0.0f);
         if (h.obj >= 0) {
             // precompute_values, world.rs:212-233
             const int ob = h.obj;
-            float4 r0 = S.inv0[ob], r1 = S.inv1[ob], r2 = S.inv2[ob], sh = S.shape[ob];
-            uint32_t bits = __float_as_uint(sh.z);
+            Obj rec = load_obj(S, ob);
             V3 point = o + d * h.t;
-            V3 op = xform_point(r0, r1, r2, point);
-            V3 n = xform_normal(r0, r1, r2, local_normal(bits & 0xff, sh.x, sh.y, op));
+            V3 op = obj_point(rec, point);
+            V3 n = obj_normal_to_world(rec, local_normal(rec.bits & SHAPE_KIND_MASK, rec.min_y(), rec.max_y(), op));
             V3 eye = -d;
             V3 reflectv = reflect3(d, n);
             if (dot3(n, eye) < 0.0f) n = -n;
@@ -586,7 +737,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
 
             // shade_hit, world.rs:62-86
             cnt.shaded++;
-            float li = intensity_at(H, S, over_point, pixel, path, cnt);
+            float li = intensity_at<NOBJ, SIMPLE>(H, S, over_point, pixel, path, cnt);
             V3 surface = phong(H, ma, mb, over_point, eye, n, li);
 
             bool has_refl = !(reflective == 0.0f || rem < 1);  // world.rs:126
@@ -596,7 +747,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
             V3 rdir = v3(0.0f, 0.0f, 0.0f);
             if (transparency != 0.0f) {
                 float n1, n2;
-                refraction_indices(H, S, o, d, ob, n1, n2);
+                refraction_indices<NOBJ>(H, S, o, d, ob, n1, n2);
                 if (use_schlick) R = schlick(eye, n, n1, n2);
                 if (rem != 0) {  // refracted_color, world.rs:140-161
                     float n_ratio = n1 / n2;
@@ -683,8 +834,12 @@ struct RenderArgs {
 };
 
 // Camera::render (camera.rs:76-91): one lane per pixel, 8x8 pixel tile per
-// wave, 2x2 waves per 256-thread workgroup.
-__global__ __launch_bounds__(256) void render_kernel(RenderArgs A) {
+// wave, 2x2 waves per 256-thread workgroup.  NOBJ: see for_each_object.
+#ifndef RTC_WAVES_PER_SIMD
+#define RTC_WAVES_PER_SIMD 6
+#endif
+template <int NOBJ, bool SIMPLE>
+__global__ __launch_bounds__(256, RTC_WAVES_PER_SIMD) void render_kernel(RenderArgs A) {
     const SceneHdr& H = A.hdr;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
@@ -708,7 +863,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs A) {
                         c[8] * world_x + c[9] * world_y + c[10] * -1.0f + c[11]};
             V3 origin = v3(H.cam_origin[0], H.cam_origin[1], H.cam_origin[2]);
             V3 direction = norm3(pixel - origin);
-            col = color_at(H, A.soa, origin, direction, A.depth, y * H.width + x, cnt);
+            col = color_at<NOBJ, SIMPLE>(H, A.soa, origin, direction, A.depth, y * H.width + x, cnt);
         }
         float* dst = A.out + ((size_t)yl * H.width + x) * 3;
         dst[0] = col.x;
@@ -729,6 +884,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs A) {
             make_uint2(wave_counts[0].x + wave_counts[1].x + wave_counts[2].x + wave_counts[3].x,
                        wave_counts[0].y + wave_counts[1].y + wave_counts[2].y + wave_counts[3].y);
 }
+
 
 __global__ __launch_bounds__(256) void sum_counts_kernel(const uint2* __restrict__ block_counts, uint32_t n,
                                                          unsigned long long* __restrict__ total) {
@@ -764,6 +920,7 @@ __global__ void quantize_kernel(const float* __restrict__ rgb, uint64_t n, uint8
     }
 }
 
+// The batched entry points are test/utility paths: they use the generic loop.
 __global__ void color_at_kernel(SceneHdr H, SceneSoA S, const float4* __restrict__ origins,
                                 const float4* __restrict__ directions, uint32_t n, int depth,
                                 float* __restrict__ out) {
@@ -771,7 +928,7 @@ __global__ void color_at_kernel(SceneHdr H, SceneSoA S, const float4* __restrict
     if (i >= n) return;
     Counters cnt = {0u, 0u};
     float4 o = origins[i], d = directions[i];
-    V3 c = color_at(H, S, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), depth, i, cnt);
+    V3 c = color_at<0, false>(H, S, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), depth, i, cnt);
     out[i * 3 + 0] = c.x;
     out[i * 3 + 1] = c.y;
     out[i * 3 + 2] = c.z;
@@ -783,7 +940,15 @@ __global__ void intensity_at_kernel(SceneHdr H, SceneSoA S, const float4* __rest
     if (i >= n) return;
     Counters cnt = {0u, 0u};
     float4 p = points[i];
-    out[i] = intensity_at(H, S, v3(p.x, p.y, p.z), i, 1u, cnt);
+    out[i] = intensity_at<4, false>(H, S, v3(p.x, p.y, p.z), i, 1u, cnt);
+}
+__global__ void intensity_at_kernel_generic(SceneHdr H, SceneSoA S, const float4* __restrict__ points, uint32_t n,
+                                            float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Counters cnt = {0u, 0u};
+    float4 p = points[i];
+    out[i] = intensity_at<0, false>(H, S, v3(p.x, p.y, p.z), i, 1u, cnt);
 }
 
 __global__ void is_shadowed_kernel(SceneHdr H, SceneSoA S, const float4* __restrict__ lights,
@@ -792,7 +957,7 @@ __global__ void is_shadowed_kernel(SceneHdr H, SceneSoA S, const float4* __restr
     if (i >= n) return;
     Counters cnt = {0u, 0u};
     float4 l = lights[i], p = points[i];
-    out[i] = is_shadowed(H, S, v3(l.x, l.y, l.z), v3(p.x, p.y, p.z), cnt) ? 1 : 0;
+    out[i] = is_shadowed<0>(H, S, v3(l.x, l.y, l.z), v3(p.x, p.y, p.z), cnt) ? 1 : 0;
 }
 
 __global__ void powf_kernel(const float* __restrict__ x, const float* __restrict__ y, uint32_t n,
@@ -817,6 +982,8 @@ static int usable_devices() {
     return n;
 }
 
+static uint32_t padded_count(uint32_t n) { return n ? (n + 7u) & ~7u : 8u; }
+
 static rtc_status check_tuple(const float v[4], float w, const char* what) {
     if (v[3] != w) return fail(RTC_ERR_INVALID_ARG, "%s: w component must be %g (got %g)", what, (double)w, (double)v[3]);
     return RTC_OK;
@@ -831,7 +998,14 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     std::memset(hdr, 0, sizeof(*hdr));
     const uint32_t n = scene->n_objects;
     hdr->n_objects = n;
-    soa->assign((size_t)7 * (n ? n : 1), make_float4(0, 0, 0, 0));
+    const uint32_t np = padded_count(n);  // stride of each SoA array
+    soa->assign((size_t)7 * np, make_float4(0, 0, 0, 0));
+    {
+        uint32_t none = SHAPE_NONE;
+        float none_f;
+        std::memcpy(&none_f, &none, 4);
+        for (uint32_t i = n; i < np; i++) (*soa)[0 * np + i] = make_float4(0.0f, 0.0f, 0.0f, none_f);
+    }
     for (uint32_t i = 0; i < n; i++) {
         const rtc_object& o = scene->objects[i];
         if (o.kind < RTC_SPHERE || o.kind > RTC_CYLINDER)
@@ -840,17 +1014,20 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
             return fail(RTC_ERR_UNSUPPORTED,
                         "object %u: inverse transform's last row is not exactly [0,0,0,1] (projective transforms "
                         "are not supported)", i);
-        (*soa)[0 * n + i] = make_float4(o.inv[0], o.inv[1], o.inv[2], o.inv[3]);
-        (*soa)[1 * n + i] = make_float4(o.inv[4], o.inv[5], o.inv[6], o.inv[7]);
-        (*soa)[2 * n + i] = make_float4(o.inv[8], o.inv[9], o.inv[10], o.inv[11]);
-        uint32_t bits = (uint32_t)o.kind | ((o.casts_shadow ? 1u : 0u) << 8) | ((o.closed ? 1u : 0u) << 9);
+        uint32_t bits = (uint32_t)o.kind | (o.casts_shadow ? SHAPE_CASTS : 0u) | (o.closed ? SHAPE_CLOSED : 0u);
+        if (o.inv[1] == 0.0f && o.inv[2] == 0.0f && o.inv[4] == 0.0f && o.inv[6] == 0.0f && o.inv[8] == 0.0f &&
+            o.inv[9] == 0.0f)
+            bits |= SHAPE_DIAG;
         float bits_f;
         std::memcpy(&bits_f, &bits, 4);
-        (*soa)[3 * n + i] = make_float4(o.min_y, o.max_y, bits_f, 0.0f);
+        (*soa)[0 * np + i] = make_float4(o.inv[0], o.inv[5], o.inv[10], bits_f);
+        (*soa)[1 * np + i] = make_float4(o.inv[1], o.inv[2], o.inv[3], o.min_y);
+        (*soa)[2 * np + i] = make_float4(o.inv[4], o.inv[6], o.inv[7], o.max_y);
+        (*soa)[3 * np + i] = make_float4(o.inv[8], o.inv[9], o.inv[11], 0.0f);
         const rtc_material& m = o.material;
-        (*soa)[4 * n + i] = make_float4(m.color[0], m.color[1], m.color[2], m.ambient);
-        (*soa)[5 * n + i] = make_float4(m.diffuse, m.specular, m.shininess, m.reflective);
-        (*soa)[6 * n + i] = make_float4(m.transparency, m.refractive_index, 0.0f, 0.0f);
+        (*soa)[4 * np + i] = make_float4(m.color[0], m.color[1], m.color[2], m.ambient);
+        (*soa)[5 * np + i] = make_float4(m.diffuse, m.specular, m.shininess, m.reflective);
+        (*soa)[6 * np + i] = make_float4(m.transparency, m.refractive_index, 0.0f, 0.0f);
     }
     const rtc_light& l = *scene->light;
     hdr->light_kind = l.kind;
@@ -911,6 +1088,7 @@ struct rtc_ctx {
     float4* d_soa = nullptr;
     size_t soa_cap = 0;  // float4 entries
     uint32_t n_objects = 0;
+    bool simple = false;  // every object scale+translate-only and no cylinder
     uint2* d_block_counts = nullptr;
     size_t block_cap = 0;
     unsigned long long* d_total = nullptr;  // {rays, shaded hits} of the last launch
@@ -923,12 +1101,12 @@ struct rtc_ctx {
 };
 
 static SceneSoA soa_view(const float4* base, uint32_t n) {
-    uint32_t m = n ? n : 1;
+    uint32_t m = rtc::padded_count(n);
     SceneSoA s;
-    s.inv0 = base + 0 * (size_t)m;
-    s.inv1 = base + 1 * (size_t)m;
-    s.inv2 = base + 2 * (size_t)m;
-    s.shape = base + 3 * (size_t)m;
+    s.geo = base + 0 * (size_t)m;
+    s.off0 = base + 1 * (size_t)m;
+    s.off1 = base + 2 * (size_t)m;
+    s.off2 = base + 3 * (size_t)m;
     s.mat_a = base + 4 * (size_t)m;
     s.mat_b = base + 5 * (size_t)m;
     s.mat_c = base + 6 * (size_t)m;
@@ -982,6 +1160,12 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     HIP_TRY(hipMemcpy(c->d_soa, soa.data(), soa.size() * sizeof(float4), hipMemcpyHostToDevice));
     c->hdr = hdr;
     c->n_objects = hdr.n_objects;
+    c->simple = true;
+    for (uint32_t i = 0; i < hdr.n_objects; i++) {
+        uint32_t bits;
+        std::memcpy(&bits, &soa[i].w, 4);  // geo[i].w
+        if (!(bits & SHAPE_DIAG) || (bits & SHAPE_KIND_MASK) == RTC_CYLINDER) c->simple = false;
+    }
     c->has_scene = true;
     return RTC_OK;
 }
@@ -1043,7 +1227,13 @@ rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, 
     }
     auto& ev = c->events[c->events_used++];
     HIP_TRY(hipEventRecord(ev.first, stream));
-    hipLaunchKernelGGL(render_kernel, grid, block, 0, stream, a);
+    // instantiation: <= 4 / <= 8 objects get fully unrolled object loops (SIMPLE: all of them
+    // scale+translate-only, no cylinder); anything larger takes the generic loop
+    if (c->n_objects <= 4 && c->simple) hipLaunchKernelGGL((render_kernel<4, true>), grid, block, 0, stream, a);
+    else if (c->n_objects <= 4) hipLaunchKernelGGL((render_kernel<4, false>), grid, block, 0, stream, a);
+    else if (c->n_objects <= 8 && c->simple) hipLaunchKernelGGL((render_kernel<8, true>), grid, block, 0, stream, a);
+    else if (c->n_objects <= 8) hipLaunchKernelGGL((render_kernel<8, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, 0, stream, a);
     HIP_TRY(hipEventRecord(ev.second, stream));
     hipLaunchKernelGGL(sum_counts_kernel, dim3(1), dim3(256), 0, stream, c->d_block_counts, (uint32_t)n_blocks, c->d_total);
     HIP_TRY(hipGetLastError());
@@ -1180,8 +1370,12 @@ rtc_status rtc_intensity_at(const rtc_scene* scene, const float* points, uint32_
     HIP_TRY(d_p.alloc((size_t)n * 16));
     HIP_TRY(d_out.alloc((size_t)n * 4));
     HIP_TRY(hipMemcpy(d_p.p, points, (size_t)n * 16, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(intensity_at_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, hdr,
-                       soa_view((const float4*)soa.p, hdr.n_objects), (const float4*)d_p.p, n, (float*)d_out.p);
+    if (hdr.n_objects <= 4)
+        hipLaunchKernelGGL(intensity_at_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, hdr,
+                           soa_view((const float4*)soa.p, hdr.n_objects), (const float4*)d_p.p, n, (float*)d_out.p);
+    else
+        hipLaunchKernelGGL(intensity_at_kernel_generic, dim3((n + 63) / 64), dim3(64), 0, nullptr, hdr,
+                           soa_view((const float4*)soa.p, hdr.n_objects), (const float4*)d_p.p, n, (float*)d_out.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RTC_OK;
