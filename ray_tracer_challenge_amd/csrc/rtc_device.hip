@@ -721,23 +721,33 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
         bool descend = false;
         ret = v3(0.0f, 0.0f, 0.0f);
         if (h.obj >= 0) {
-            // precompute_values, world.rs:212-233
+            // precompute_values, world.rs:212-233.  Only what the light sampling needs is computed before
+            // it (point, normal, over_point); everything else is (re)derived afterwards so that it is not
+            // live across the 100-sample loop -- register pressure there decides occupancy.
             const int ob = h.obj;
-            Obj rec = load_obj(S, ob);
-            V3 point = o + d * h.t;
-            V3 op = obj_point(rec, point);
-            V3 n = obj_normal_to_world(rec, local_normal(rec.bits & SHAPE_KIND_MASK, rec.min_y(), rec.max_y(), op));
-            V3 eye = -d;
-            V3 reflectv = reflect3(d, n);
-            if (dot3(n, eye) < 0.0f) n = -n;
-            V3 over_point = point + n * SELF_EPS;
-            V3 under_point = point - n * SELF_EPS;
-            float4 ma = S.mat_a[ob], mb = S.mat_b[ob], mc = S.mat_c[ob];
-            const float reflective = mb.w, transparency = mc.x;
+            V3 n;
+            bool inside;
+            V3 over_point;
+            {
+                Obj rec = load_obj(S, ob);
+                V3 point = o + d * h.t;
+                V3 op = obj_point(rec, point);
+                n = obj_normal_to_world(rec, local_normal(rec.bits & SHAPE_KIND_MASK, rec.min_y(), rec.max_y(), op));
+                inside = dot3(n, -d) < 0.0f;
+                if (inside) n = -n;
+                over_point = point + n * SELF_EPS;
+            }
 
             // shade_hit, world.rs:62-86
             cnt.shaded++;
             float li = intensity_at<NOBJ, SIMPLE>(H, S, over_point, pixel, path, cnt);
+
+            V3 eye = -d;
+            V3 reflectv = reflect3(d, inside ? -n : n);  // world.rs:221 uses the normal before the inside flip
+            V3 point = o + d * h.t;
+            V3 under_point = point - n * SELF_EPS;
+            float4 ma = S.mat_a[ob], mb = S.mat_b[ob], mc = S.mat_c[ob];
+            const float reflective = mb.w, transparency = mc.x;
             V3 surface = phong(H, ma, mb, over_point, eye, n, li);
 
             bool has_refl = !(reflective == 0.0f || rem < 1);  // world.rs:126
@@ -886,10 +896,16 @@ __global__ __launch_bounds__(256, RTC_WAVES_PER_SIMD) void render_kernel(RenderA
 }
 
 
-__global__ __launch_bounds__(256) void sum_counts_kernel(const uint2* __restrict__ block_counts, uint32_t n,
-                                                         unsigned long long* __restrict__ total) {
+__global__ __launch_bounds__(1024) void sum_counts_kernel(const uint2* __restrict__ block_counts, uint32_t n,
+                                                          unsigned long long* __restrict__ total) {
     unsigned long long rays = 0, shaded = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    uint32_t i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {  // four independent loads in flight per lane
+        uint2 a = block_counts[i], b = block_counts[i + 1024], c = block_counts[i + 2048], d = block_counts[i + 3072];
+        rays += (unsigned long long)a.x + b.x + c.x + d.x;
+        shaded += (unsigned long long)a.y + b.y + c.y + d.y;
+    }
+    for (; i < n; i += 1024) {
         uint2 c = block_counts[i];
         rays += c.x;
         shaded += c.y;
@@ -898,15 +914,20 @@ __global__ __launch_bounds__(256) void sum_counts_kernel(const uint2* __restrict
         rays += __shfl_down(rays, off, 64);
         shaded += __shfl_down(shaded, off, 64);
     }
-    __shared__ unsigned long long part[4][2];
+    __shared__ unsigned long long part[16][2];
     if ((threadIdx.x & 63) == 0) {
         part[threadIdx.x >> 6][0] = rays;
         part[threadIdx.x >> 6][1] = shaded;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        total[0] = part[0][0] + part[1][0] + part[2][0] + part[3][0];
-        total[1] = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+        unsigned long long r = 0, sh = 0;
+        for (int w = 0; w < 16; w++) {
+            r += part[w][0];
+            sh += part[w][1];
+        }
+        total[0] = r;
+        total[1] = sh;
     }
 }
 
@@ -1235,7 +1256,7 @@ rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, 
     else if (c->n_objects <= 8) hipLaunchKernelGGL((render_kernel<8, false>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, 0, stream, a);
     HIP_TRY(hipEventRecord(ev.second, stream));
-    hipLaunchKernelGGL(sum_counts_kernel, dim3(1), dim3(256), 0, stream, c->d_block_counts, (uint32_t)n_blocks, c->d_total);
+    hipLaunchKernelGGL(sum_counts_kernel, dim3(1), dim3(1024), 0, stream, c->d_block_counts, (uint32_t)n_blocks, c->d_total);
     HIP_TRY(hipGetLastError());
     c->rendered = true;
     return RTC_OK;
