@@ -110,7 +110,9 @@ SIGNATURES = {
     "rtc_device_count": (C.c_int32, []),
 }
 # diagnostic export, not in rtc.h: host compile of the device powf restatement
-EXTRA = {"rtc_powf_host": (None, [FP, FP, C.c_uint32, FP])}
+EXTRA = {"rtc_powf_host": (None, [FP, FP, C.c_uint32, FP]),
+         # device self-test of the range-checked exact sqrt/divide cores against sqrtf and '/'
+         "rtc_selftest_fastmath": (C.c_int, [FP, C.c_uint32, C.c_int32, C.POINTER(C.c_uint32)])}
 
 _lib = None
 

@@ -321,7 +321,10 @@ DI float quadratic_c(uint32_t kind, V3 o) {
     if (kind == RTC_CYLINDER) return o.x * o.x + o.z * o.z - 1.0f;              // cylinder.rs:95
     return 0.0f;
 }
-template <class F>
+// HITS_ONLY: the caller only looks at distances >= 0 (hit selection, shadow tests), so an
+// intersection that is provably negative need not be evaluated; refraction_indices() needs the
+// negative ones too and passes false.
+template <bool HITS_ONLY, class F>
 DI void local_intersect_c(uint32_t bits, float min_y, float max_y, V3 o, V3 d, float c, F&& f) {
     const uint32_t kind = bits & SHAPE_KIND_MASK;
     if (kind == RTC_SPHERE) {  // sphere.rs:47-70
@@ -335,7 +338,13 @@ DI void local_intersect_c(uint32_t bits, float min_y, float max_y, V3 o, V3 d, f
             f((-b + sq) / two_a);
         }
     } else if (kind == RTC_PLANE) {  // plane.rs:45-56
-        if (!(fabsf(d.y) < PLANE_EPS)) f(-o.y / d.y);
+        if (!(fabsf(d.y) < PLANE_EPS)) {
+            // -o.y / d.y is strictly negative when o.y and d.y have the same sign and the quotient cannot
+            // underflow to -0 (|o.y| >= 2^-100, |d.y| <= 2^20): the ray leaves the plane behind.
+            const bool behind = HITS_ONLY && fabsf(d.y) <= 0x1p20f &&
+                                ((o.y >= 0x1p-100f && d.y > 0.0f) || (o.y <= -0x1p-100f && d.y < 0.0f));
+            if (!behind) f(-o.y / d.y);
+        }
     } else if (kind == RTC_CUBE) {  // cube.rs:55-63, 90-129; reciprocals from Ray::new (ray.rs:16)
         float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
         float x0 = (-1.0f - o.x) * ix, x1 = (1.0f - o.x) * ix;
@@ -389,9 +398,9 @@ DI void local_intersect_c(uint32_t bits, float min_y, float max_y, V3 o, V3 d, f
     }
 }
 
-template <class F>
+template <bool HITS_ONLY, class F>
 DI void local_intersect(uint32_t bits, float min_y, float max_y, V3 o, V3 d, F&& f) {
-    local_intersect_c(bits, min_y, max_y, o, d, quadratic_c(bits & SHAPE_KIND_MASK, o), f);
+    local_intersect_c<HITS_ONLY>(bits, min_y, max_y, o, d, quadratic_c(bits & SHAPE_KIND_MASK, o), f);
 }
 
 // local_norm_at for the four shapes (sphere.rs:71-73, plane.rs:57-59, cube.rs:66-80, cylinder.rs:62-72)
@@ -451,7 +460,7 @@ DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d) {
         if (NOBJ > 0 && (ob.bits & SHAPE_KIND_MASK) == SHAPE_NONE) return;  // padding record (wave-uniform)
         V3 po = obj_point(ob, o);
         V3 pd = obj_vector(ob, d);
-        local_intersect(ob.bits, ob.min_y(), ob.max_y(), po, pd, [&](float t) {
+        local_intersect<true>(ob.bits, ob.min_y(), ob.max_y(), po, pd, [&](float t) {
             if (t >= 0.0f && (best.obj < 0 || t < best.t)) {
                 best.t = t;
                 best.obj = (int)i;
@@ -472,6 +481,59 @@ DI bool is_shadowed(const SceneHdr& H, const SceneSoA& S, V3 light_position, V3 
     if (h.obj < 0) return false;
     bool casts = (__float_as_uint(S.geo[h.obj].w) & SHAPE_CASTS) != 0;
     return casts && h.t < distance;
+}
+
+// ---- exact sqrt / divide without the range handling ---------------------------------------------
+// hipcc expands IEEE-correct sqrtf(x) and a/b into v_sqrt_f32 / v_rcp_f32 plus FMA correction steps
+// wrapped in range handling (v_div_scale / v_div_fmas / v_div_fixup, denormal pre-scaling, class
+// checks).  When the operands are comfortably inside the normal range that wrapping is the identity,
+// so the bare correction sequence below returns the SAME bits -- it is the compiler's own sequence
+// with the no-op steps removed (checked bit-for-bit on the device by rtc_selftest_fastmath).  Three
+// quotients by one denominator also share the reciprocal refinement.
+DI float sqrt_core(float x) {  // == sqrtf(x) for x in [2^-80, 2^40]
+    float s = __builtin_amdgcn_sqrtf(x);
+    float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    float r_dn = __builtin_fmaf(-s_dn, s, x);
+    float r_up = __builtin_fmaf(-s_up, s, x);
+    float r = (r_dn <= 0.0f) ? s_dn : s;
+    return (r_up > 0.0f) ? s_up : r;
+}
+struct RcpCore {  // refined reciprocal of b, shared by every quotient n / b
+    float b, r1;
+    DI explicit RcpCore(float b_) : b(b_) {
+        float r0 = __builtin_amdgcn_rcpf(b);
+        float e0 = __builtin_fmaf(-b, r0, 1.0f);
+        r1 = __builtin_fmaf(e0, r0, r0);
+    }
+    DI float div(float n) const {  // == n / b when b in [2^-40, 2^20] and n == 0 or |n| in [2^-100, b]
+        float q0 = n * r1;
+        float e1 = __builtin_fmaf(-b, q0, n);
+        float q1 = __builtin_fmaf(e1, r1, q0);
+        float e2 = __builtin_fmaf(-b, q1, n);
+        return __builtin_fmaf(e2, r1, q1);
+    }
+};
+// distance = |v| and dir = v / |v| exactly as mag3 / norm3 compute them.  The cheap sequence is used
+// when EVERY active lane of the wave is in its validity range (wave-uniform branch); otherwise the
+// whole wave takes the general path -- both produce identical bits, so the choice is invisible.
+DI bool normalize_in_core_range(V3 v, float sum) {
+    // v_k == 0, or |v_k| >= 2^-100: as integers, (|bits| - 1) wraps zero to 0xffffffff
+    uint32_t ax = (__float_as_uint(v.x) & 0x7fffffffu) - 1u, ay = (__float_as_uint(v.y) & 0x7fffffffu) - 1u,
+             az = (__float_as_uint(v.z) & 0x7fffffffu) - 1u;
+    uint32_t lo = min(ax, min(ay, az));
+    return sum >= 0x1p-80f && sum <= 0x1p40f && lo >= 0x0d800000u - 1u;  // 0x0d800000 = 2^-100
+}
+DI void normalize_exact(V3 v, float& distance, V3& dir) {
+    float sum = v.x * v.x + v.y * v.y + v.z * v.z;
+    if (__all(normalize_in_core_range(v, sum))) {
+        distance = sqrt_core(sum);
+        RcpCore rc(distance);
+        dir = v3(rc.div(v.x), rc.div(v.y), rc.div(v.z));
+    } else {
+        distance = sqrtf(sum);
+        dir = v3(v.x / distance, v.y / distance, v.z / distance);
+    }
 }
 
 // ---- area-light shadow samples: many rays from one point -------------------------------------
@@ -503,8 +565,9 @@ DI void shadow_prepare(const SceneHdr& H, const SceneSoA& S, V3 p, ShadowPre* pr
 template <int NOBJ, bool SIMPLE>
 DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* pre, V3 lp, V3 p, Counters& cnt) {
     V3 v = lp - p;
-    float distance = mag3(v);
-    V3 dir = norm3(v);
+    float distance;
+    V3 dir;
+    normalize_exact(v, distance, dir);  // == mag3(v), norm3(v)
     cnt.rays++;
     auto object_ts = [&](uint32_t i, const float4 g, uint32_t bits, auto&& f) {
         V3 pd;
@@ -520,7 +583,7 @@ DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* p
             mn = S.off0[i].w;
             mx = S.off1[i].w;
         }
-        local_intersect_c(bits, mn, mx, pre[i].o, pd, pre[i].c, f);
+        local_intersect_c<true>(bits, mn, mx, pre[i].o, pd, pre[i].c, f);
     };
     // pass 1: shadow casters
     bool found = false;
@@ -646,7 +709,7 @@ DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int
         V3 pd = obj_vector(ob, d);
         int negatives = 0;
         float tmax = 0.0f;
-        local_intersect(ob.bits, ob.min_y(), ob.max_y(), po, pd, [&](float t) {
+        local_intersect<false>(ob.bits, ob.min_y(), ob.max_y(), po, pd, [&](float t) {
             if (t < 0.0f) {
                 if (negatives == 0 || t > tmax) tmax = t;
                 negatives++;
@@ -985,6 +1048,25 @@ __global__ void powf_kernel(const float* __restrict__ x, const float* __restrict
                             float* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = rtc_powf_dev(x[i], y[i]);
+}
+
+// Diagnostic: sqrt_core / RcpCore against the compiler's sqrtf and '/' on caller-supplied vectors.
+// out[0] = vectors inside the core range, out[1] = of those, how many differ in any bit pattern (a
+// zero's sign excepted).
+__global__ void fastmath_selftest_kernel(const float* __restrict__ v, uint32_t n, uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 a = v3(v[i * 3], v[i * 3 + 1], v[i * 3 + 2]);
+    float sum = a.x * a.x + a.y * a.y + a.z * a.z;
+    if (!normalize_in_core_range(a, sum)) return;
+    float m_ref = sqrtf(sum);
+    V3 d_ref = v3(a.x / m_ref, a.y / m_ref, a.z / m_ref);
+    float m = sqrt_core(sum);
+    RcpCore rc(m);
+    V3 d = v3(rc.div(a.x), rc.div(a.y), rc.div(a.z));
+    auto same = [](float p, float q) { return __float_as_uint(p) == __float_as_uint(q) || (p == 0.0f && q == 0.0f); };
+    atomicAdd(&out[0], 1u);
+    if (!(same(m, m_ref) && same(d.x, d_ref.x) && same(d.y, d_ref.y) && same(d.z, d_ref.z))) atomicAdd(&out[1], 1u);
 }
 
 // ============================================================================
@@ -1448,6 +1530,27 @@ rtc_status rtc_powf(const float* x, const float* y, uint32_t n, int32_t device, 
 // any render path.
 void rtc_powf_host(const float* x, const float* y, uint32_t n, float* out) {
     for (uint32_t i = 0; i < n; i++) out[i] = powf_glibc(x[i], y[i], h_pow_log2_tab, h_exp2f_tab);
+}
+
+// Diagnostic (not in rtc.h): runs fastmath_selftest_kernel on n host vectors (n*3 f32);
+// counts[0] = vectors inside the core range, counts[1] = mismatches against sqrtf and '/'.
+rtc_status rtc_selftest_fastmath(const float* vectors, uint32_t n, int32_t device, uint32_t counts[2]) {
+    if (!vectors || !counts) return fail(RTC_ERR_INVALID_ARG, "rtc_selftest_fastmath: null argument");
+    int nd = usable_devices();
+    if (nd <= 0) return fail(RTC_ERR_NO_DEVICE, "no HIP device visible; librtc_amd has no CPU fallback");
+    if (device < 0 || device >= nd) return fail(RTC_ERR_INVALID_ARG, "device %d out of range (have %d)", device, nd);
+    HIP_TRY(hipSetDevice(device));
+    DevBuf d_v, d_out;
+    HIP_TRY(d_v.alloc((size_t)n * 12));
+    HIP_TRY(d_out.alloc(8));
+    HIP_TRY(hipMemcpy(d_v.p, vectors, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_out.p, 0, 8));
+    if (n)
+        hipLaunchKernelGGL(fastmath_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, (const float*)d_v.p, n,
+                           (uint32_t*)d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(counts, d_out.p, 8, hipMemcpyDeviceToHost));
+    return RTC_OK;
 }
 
 }  // extern "C"

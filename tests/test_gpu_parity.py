@@ -47,6 +47,36 @@ def test_device_powf_equals_libm_powf():
         assert np.array_equal(got, P.powf_host(xs, ys), equal_nan=True)
 
 
+def test_exact_sqrt_and_divide_cores_equal_ieee_forms():
+    """normalize_exact's cheap branch (sqrt_core / RcpCore) must return the same bits as sqrtf and '/'
+    everywhere inside its validity range: 12 M random vectors across the whole exponent range it admits,
+    plus vectors with zero / tiny / dominant components and exact squares."""
+    rng = np.random.default_rng(2024)
+    n = 4_000_000
+    blocks = []
+    for lo, hi in ((-38, 18), (-3, 3), (-12, -8)):
+        mant = rng.uniform(1.0, 2.0, (n, 3))
+        expo = rng.integers(lo, hi, (n, 3))
+        sign = rng.choice([-1.0, 1.0], (n, 3))
+        blocks.append((sign * mant * np.exp2(expo)).astype(f32))
+    edge = rng.uniform(-4, 4, (200_000, 3)).astype(f32)
+    edge[::4, 0] = 0.0
+    edge[1::4, 1] = 0.0
+    edge[2::4, 2] = f32(1e-25)
+    edge[3::4] = np.round(edge[3::4])  # small integers: exact squares, exact quotients
+    edge[5::8, 1:] = 0.0
+    blocks.append(edge)
+    total_in, total_bad = 0, 0
+    for v in blocks:
+        v = np.ascontiguousarray(v)
+        counts = (C.c_uint32 * 2)()
+        L.check(P.lib().rtc_selftest_fastmath(v.ctypes.data_as(L.FP), v.shape[0], 0, counts))
+        total_in += counts[0]
+        total_bad += counts[1]
+    assert total_bad == 0, (total_bad, total_in)
+    assert total_in > 11_000_000, total_in
+
+
 # ------------------------------------------- the reference's world.rs tests, on device
 def _both_color_at(pw, o, d, depth):
     o, d = np.asarray(o, dtype=f32), np.asarray(d, dtype=f32)
