@@ -1,0 +1,31 @@
+// C++ counterpart of the reference's demos/src/bin/first_plane.rs: a plane floor and three spheres.
+//   ./first_plane [WIDTHxHEIGHT]   default 100x50 (first_plane.rs:20-21)
+#include <cstdio>
+#include <iostream>
+
+#include "rtc.hpp"
+using namespace rtc;
+
+int main(int argc, char** argv) {
+    unsigned w = 100, h = 50;
+    if (argc > 1 && std::sscanf(argv[1], "%ux%u", &w, &h) != 2) return 2;
+    try {
+        Plane floor = Plane::build(scaling(10.0f, 0.01f, 10.0f), Material::builder().color(color(1, 0.9f, 0.9f)).specular(0.0f).build());
+        Sphere middle = Sphere::build(translation(-0.5f, 1.0f, 0.5f),
+                                      Material::builder().color(color(0.1f, 1, 0.5f)).diffuse(0.7f).specular(0.3f).build());
+        Sphere right = Sphere::build(shearing(0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f) * translation(1.5f, 0.5f, -0.5f) * scaling(0.5f, 0.5f, 0.5f),
+                                     Material::builder().color(color(0.5f, 1, 0.1f)).diffuse(0.7f).specular(0.3f).build());
+        Sphere left = Sphere::build(translation(-1.5f, 0.33f, -0.75f) * scaling(0.33f, 0.33f, 0.33f),
+                                    Material::builder().color(color(1, 0.8f, 0.1f)).diffuse(0.7f).specular(0.3f).build());
+        World world;
+        world.objects = {floor, left, middle, right};
+        world.light = std::make_shared<PointLight>(point(-10, 10, -10), white());
+        Camera camera(w, h, PI / 3.0f, view_transform(point(0, 1.5f, -5), point(0, 1, 0), vector(0, 1, 0)));
+        Canvas canvas = camera.render(world, 5);
+        std::cout << canvas.to_ppm() << "\n";
+    } catch (const Error& e) {
+        std::cerr << "first_plane: " << e.what() << "\n";
+        return 1;
+    }
+    return 0;
+}

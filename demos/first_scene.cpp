@@ -1,0 +1,36 @@
+// C++ counterpart of the reference's demos/src/bin/first_scene.rs: six spheres (three of them squashed
+// into floor and walls, one sheared), point light.   ./first_scene [WIDTHxHEIGHT]   default 1000x500
+#include <cstdio>
+#include <iostream>
+
+#include "rtc.hpp"
+using namespace rtc;
+
+int main(int argc, char** argv) {
+    unsigned w = 1000, h = 500;
+    if (argc > 1 && std::sscanf(argv[1], "%ux%u", &w, &h) != 2) return 2;
+    try {
+        Material room_material = Material::builder().color(color(1, 0.9f, 0.9f)).specular(0.0f).build();
+        Sphere floor = Sphere::build(scaling(10.0f, 0.01f, 10.0f), room_material);
+        Sphere left_wall = Sphere::build(
+            translation(0.0f, 0.0f, 5.0f) * rotation_y(-PI / 4.0f) * rotation_x(PI / 2.0f) * scaling(10.0f, 0.01f, 10.0f), room_material);
+        Sphere right_wall = Sphere::build(
+            translation(0.0f, 0.0f, 5.0f) * rotation_y(PI / 4.0f) * rotation_x(PI / 2.0f) * scaling(10.0f, 0.01f, 10.0f), room_material);
+        Sphere middle = Sphere::build(translation(-0.5f, 1.0f, 0.5f),
+                                      Material::builder().color(color(0.1f, 1, 0.5f)).diffuse(0.7f).specular(0.3f).build());
+        Sphere right = Sphere::build(shearing(0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f) * translation(1.5f, 0.5f, -0.5f) * scaling(0.5f, 0.5f, 0.5f),
+                                     Material::builder().color(color(0.5f, 1, 0.1f)).diffuse(0.7f).specular(0.3f).build());
+        Sphere left = Sphere::build(translation(-1.5f, 0.33f, -0.75f) * scaling(0.33f, 0.33f, 0.33f),
+                                    Material::builder().color(color(1, 0.8f, 0.1f)).diffuse(0.7f).specular(0.3f).build());
+        World world;
+        world.objects = {floor, left_wall, right_wall, left, middle, right};
+        world.light = std::make_shared<PointLight>(point(-10, 10, -10), white());
+        Camera camera(w, h, PI / 3.0f, view_transform(point(0, 1.5f, -5), point(0, 1, 0), vector(0, 1, 0)));
+        Canvas canvas = camera.render(world, 5);  // DEFAULT_RAY_RECURSION_DEPTH, constants.rs:4
+        std::cout << canvas.to_ppm() << "\n";
+    } catch (const Error& e) {
+        std::cerr << "first_scene: " << e.what() << "\n";
+        return 1;
+    }
+    return 0;
+}

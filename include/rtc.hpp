@@ -1,0 +1,222 @@
+// rtc.hpp -- header-only C++17 mirror of the reference's scene API for the render hot path, on top of
+// the C ABI in rtc.h.  The reference's host language is Rust and this image has no Rust toolchain, so
+// this is the compiled-language host side: the same names and argument meaning as the crate
+// (lib/src/{tuple,color,matrix,transformations,material,world,camera,canvas}.rs, shape/*.rs, light/*.rs),
+// so a demo translates line by line (demos/*.cpp next to the reference's demos/src/bin/*.rs).
+// Everything numeric happens inside librtc_amd.so; this header only marshals.
+#ifndef RTC_HPP
+#define RTC_HPP
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rtc.h"
+
+namespace rtc {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string& what) : std::runtime_error(what), status(s) {}
+};
+inline void check(int status) {
+    if (status != RTC_OK) throw Error(status, rtc_last_error());
+}
+
+// ---- tuple.rs / color.rs -------------------------------------------------------------------------
+struct Tuple {
+    float x, y, z, w;
+    const float* data() const { return &x; }
+};
+inline Tuple point(float x, float y, float z) { return {x, y, z, 1.0f}; }   // point!()
+inline Tuple vector(float x, float y, float z) { return {x, y, z, 0.0f}; }  // vector!()
+struct Color {
+    float r, g, b;
+    const float* data() const { return &r; }
+};
+inline Color color(float r, float g, float b) { return {r, g, b}; }  // color!()
+inline Color white() { return {1, 1, 1}; }                           // constants.rs:19-21
+inline Color red() { return {1, 0, 0}; }                             // constants.rs:25-27
+
+// ---- matrix.rs / transformations.rs ----------------------------------------------------------------
+struct Matrix {
+    float m[16];
+    Matrix operator*(const Matrix& o) const {  // matrix.rs:86-103
+        Matrix r;
+        rtc_mat_mul(m, o.m, r.m);
+        return r;
+    }
+    Tuple operator*(const Tuple& t) const {  // matrix.rs:73-84
+        Tuple r;
+        rtc_mat_vec(m, t.data(), &r.x);
+        return r;
+    }
+    Matrix inverse() const {  // matrix.rs:201-212
+        Matrix r;
+        check(rtc_mat_inverse(m, 4, r.m));
+        return r;
+    }
+};
+inline Matrix identity_4x4() {
+    Matrix r;
+    rtc_scaling(1, 1, 1, r.m);
+    return r;
+}
+#define RTC_HPP_MAT(name, decl, call) \
+    inline Matrix name decl {         \
+        Matrix r;                     \
+        call;                         \
+        return r;                     \
+    }
+RTC_HPP_MAT(translation, (float x, float y, float z), rtc_translation(x, y, z, r.m))
+RTC_HPP_MAT(scaling, (float x, float y, float z), rtc_scaling(x, y, z, r.m))
+RTC_HPP_MAT(rotation_x, (float a), rtc_rotation_x(a, r.m))
+RTC_HPP_MAT(rotation_y, (float a), rtc_rotation_y(a, r.m))
+RTC_HPP_MAT(rotation_z, (float a), rtc_rotation_z(a, r.m))
+RTC_HPP_MAT(shearing, (float xy, float xz, float yx, float yz, float zx, float zy), rtc_shearing(xy, xz, yx, yz, zx, zy, r.m))
+RTC_HPP_MAT(view_transform, (Tuple from, Tuple to, Tuple up), rtc_view_transform(from.data(), to.data(), up.data(), r.m))
+#undef RTC_HPP_MAT
+
+// ---- material.rs:18-51 (TypedBuilder defaults) -------------------------------------------------------
+struct Material {
+    Color color_{1, 1, 1};
+    float ambient_ = 0.1f, diffuse_ = 0.9f, specular_ = 0.9f, shininess_ = 200.0f;
+    float reflective_ = 0.0f, transparency_ = 0.0f, refractive_index_ = 1.0f;
+    static Material builder() { return Material(); }
+    Material& color(Color c) { color_ = c; return *this; }
+    Material& ambient(float v) { ambient_ = v; return *this; }
+    Material& diffuse(float v) { diffuse_ = v; return *this; }
+    Material& specular(float v) { specular_ = v; return *this; }
+    Material& shininess(float v) { shininess_ = v; return *this; }
+    Material& reflective(float v) { reflective_ = v; return *this; }
+    Material& transparency(float v) { transparency_ = v; return *this; }
+    Material& refractive_index(float v) { refractive_index_ = v; return *this; }
+    Material build() const { return *this; }
+    rtc_material c() const {
+        return {{color_.r, color_.g, color_.b}, ambient_, diffuse_, specular_, shininess_, reflective_, transparency_,
+                refractive_index_};
+    }
+};
+
+// ---- shape/*.rs -----------------------------------------------------------------------------------
+struct Shape {
+    int32_t kind;
+    Matrix transform = identity_4x4();
+    Material material;
+    bool casts_shadow = true;                                   // base_shape.rs:31
+    float minimum_y = -std::numeric_limits<float>::infinity();  // cylinder.rs:39-41
+    float maximum_y = std::numeric_limits<float>::infinity();
+    bool closed = false;
+    explicit Shape(int32_t k) : kind(k) {}
+    Shape(int32_t k, Matrix t, Material m) : kind(k), transform(t), material(m) {}
+    void set_transformation(Matrix t) { transform = t; }
+    void set_material(Material m) { material = m; }
+    void set_casts_shadow(bool v) { casts_shadow = v; }
+    rtc_object c() const {
+        rtc_object o;
+        rtc_material m = material.c();
+        check(rtc_object_init(&o, kind, transform.m, &m));  // stores transform.inverse(), base_shape.rs:58
+        o.casts_shadow = casts_shadow;
+        o.closed = closed;
+        o.min_y = minimum_y;
+        o.max_y = maximum_y;
+        return o;
+    }
+};
+struct Sphere : Shape {
+    Sphere() : Shape(RTC_SPHERE) {}
+    static Sphere build(Matrix t, Material m) { Sphere s; s.transform = t; s.material = m; return s; }  // sphere.rs:23-28
+};
+struct Plane : Shape {
+    Plane() : Shape(RTC_PLANE) {}
+    static Plane build(Matrix t, Material m) { Plane s; s.transform = t; s.material = m; return s; }
+};
+struct Cube : Shape {
+    Cube() : Shape(RTC_CUBE) {}
+    static Cube build(Matrix t, Material m) { Cube s; s.transform = t; s.material = m; return s; }
+};
+struct Cylinder : Shape {
+    Cylinder() : Shape(RTC_CYLINDER) {}
+    static Cylinder build(Matrix t, Material m) { Cylinder s; s.transform = t; s.material = m; return s; }
+};
+
+// ---- light/*.rs -----------------------------------------------------------------------------------
+struct Light {
+    rtc_light l;
+};
+struct PointLight : Light {
+    PointLight(Tuple position, Color intensity) { rtc_point_light(position.data(), intensity.data(), &l); }  // point_light.rs:12-19
+};
+// RectangleLight::new(..., jitter_fn_opt).  `hashed(seed)` stands in for jitter_fn_opt = None (thread_rng);
+// `constant(c)` for test/utils.rs constant_jitter().  An arbitrary closure cannot run on a device.
+struct Jitter {
+    int32_t mode;
+    float value;
+    uint32_t seed;
+    static Jitter hashed(uint32_t seed = 0x5EED5EEDu) { return {RTC_JITTER_HASHED, 0.0f, seed}; }
+    static Jitter constant(float c = 0.5f) { return {RTC_JITTER_CONSTANT, c, 0}; }
+};
+struct RectangleLight : Light {
+    RectangleLight(Color intensity, Tuple corner, Tuple u_vec, int32_t u_steps, Tuple v_vec, int32_t v_steps,
+                   Jitter jitter = Jitter::hashed()) {  // rectangle_light.rs:33-58
+        check(rtc_rectangle_light(intensity.data(), corner.data(), u_vec.data(), u_steps, v_vec.data(), v_steps,
+                                  jitter.mode, jitter.value, jitter.seed, &l));
+    }
+};
+
+// ---- world.rs:18-21 -------------------------------------------------------------------------------
+struct World {
+    std::vector<Shape> objects;
+    std::shared_ptr<Light> light;  // None -> "World light should be set" (world.rs:66)
+};
+
+// ---- canvas.rs ------------------------------------------------------------------------------------
+struct Canvas {
+    size_t width, height;
+    std::vector<float> data;  // [y][x][rgb]
+    Canvas(size_t w, size_t h) : width(w), height(h), data(w * h * 3, 0.0f) {}
+    Color pixel_at(size_t x, size_t y) const {
+        const float* p = &data[(y * width + x) * 3];
+        return {p[0], p[1], p[2]};
+    }
+    void write_pixel(size_t x, size_t y, Color c) {
+        float* p = &data[(y * width + x) * 3];
+        p[0] = c.r, p[1] = c.g, p[2] = c.b;
+    }
+    std::string to_ppm() const {  // canvas.rs:58-96
+        char* text = nullptr;
+        uint64_t len = 0;
+        check(rtc_to_ppm(data.data(), (uint32_t)width, (uint32_t)height, &text, &len));
+        std::string s(text, len);
+        rtc_free(text);
+        return s;
+    }
+};
+
+// ---- camera.rs ------------------------------------------------------------------------------------
+struct Camera {
+    rtc_camera c;
+    rtc_stats last_stats{};
+    Camera(uint32_t width_pixels, uint32_t height_pixels, float field_of_view, Matrix transform) {  // camera.rs:23-56
+        check(rtc_camera_new(width_pixels, height_pixels, field_of_view, transform.m, &c));
+    }
+    // Camera::render (camera.rs:76-91) on the MI355X
+    Canvas render(const World& world, int16_t reflection_recursion_depth, int device = 0) {
+        std::vector<rtc_object> objs;
+        objs.reserve(world.objects.size());
+        for (const Shape& s : world.objects) objs.push_back(s.c());
+        rtc_scene scene{(uint32_t)objs.size(), objs.data(), world.light ? &world.light->l : nullptr};
+        Canvas canvas(c.width, c.height);
+        check(rtc_render(&scene, &c, reflection_recursion_depth, device, canvas.data.data(), &last_stats));
+        return canvas;
+    }
+};
+
+constexpr float PI = 3.14159265358979323846264338327950288f;  // std::f32::consts::PI
+
+}  // namespace rtc
+#endif

@@ -1,0 +1,40 @@
+"""The C++ host API (include/rtc.hpp) and the C++ counterparts of the reference's in-scope demo
+binaries (demos/*.cpp).  CPU: they compile, link against librtc_amd.so and fail loudly without a GPU.
+GPU: their stdout equals Canvas::to_ppm of the oracle's render plus println!'s extra newline."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ray_tracer_challenge_amd as P
+from oracle import oracle as O
+from ray_tracer_challenge_amd import scenes
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMOS = os.path.join(ROOT, "demos")
+
+
+@pytest.fixture(scope="module")
+def built():
+    subprocess.check_call(["make", "-C", DEMOS, "-s"])
+    return DEMOS
+
+
+def test_demos_build_and_refuse_to_run_without_gpu(built):
+    for name in ("soft_shadows", "first_scene", "first_plane"):
+        assert os.access(os.path.join(built, name), os.X_OK)
+    if P.device_count() == 0:
+        p = subprocess.run([os.path.join(built, "first_plane"), "8x8"], capture_output=True, text=True)
+        assert p.returncode == 1 and "no CPU fallback" in p.stderr and p.stdout == ""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,size", [("soft_shadows", (100, 40)), ("first_scene", (100, 50)), ("first_plane", (100, 50))])
+def test_demo_stdout_is_the_oracles_ppm(built, name, size):
+    p = subprocess.run([os.path.join(built, name), "%dx%d" % size], capture_output=True)
+    assert p.returncode == 0, p.stderr
+    world, camera, depth = getattr(scenes, name)(*size)
+    img, _ = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=8)
+    assert p.stdout == O.to_ppm(img) + b"\n"

@@ -41,18 +41,35 @@ def _worker(rank, world_size, port, height, width, ok):
         g = BandGather(height, width, 3, torch.float32, torch.device("cpu"), rank, world_size)
         rows = _global_rows(height, world_size, rank)
         assert g.local_rows == len(rows)
-        # stand-in for the kernel: pixel value encodes (global row, column, channel)
-        local = g.local_view()
-        for i, y in enumerate(rows):
-            local[i] = (y * 1000.0 + torch.arange(width, dtype=torch.float32)[:, None] + torch.tensor([0.0, 0.25, 0.5]))
-        image = g.gather()
-        if rank == 0:
-            exp = (torch.arange(height, dtype=torch.float32)[:, None, None] * 1000.0
-                   + torch.arange(width, dtype=torch.float32)[None, :, None] + torch.tensor([0.0, 0.25, 0.5]))
-            assert image.shape == (height, width, 3)
-            assert torch.equal(image, exp)
-        else:
-            assert image is None
+
+        def fill(slot, frame):
+            # stand-in for the kernel: pixel value encodes (frame, global row, column, channel)
+            local = g.local_view(slot)
+            for i, y in enumerate(rows):
+                local[i] = (frame * 1e6 + y * 1000.0 + torch.arange(width, dtype=torch.float32)[:, None]
+                            + torch.tensor([0.0, 0.25, 0.5]))
+
+        def expected(frame):
+            return (frame * 1e6 + torch.arange(height, dtype=torch.float32)[:, None, None] * 1000.0
+                    + torch.arange(width, dtype=torch.float32)[None, :, None] + torch.tensor([0.0, 0.25, 0.5]))
+
+        def check(image, frame):
+            if rank == 0:
+                assert image.shape == (height, width, 3) and torch.equal(image, expected(frame)), frame
+            else:
+                assert image is None
+
+        # unpipelined
+        fill(0, 0)
+        check(g.gather(0), 0)
+        # bench.py's software pipeline: start(i), then finish(i-1), over 5 frames and 2 slots
+        n_frames = 5
+        for i in range(n_frames):
+            fill(i % 2, i + 1)
+            g.start(i % 2)
+            if i > 0:
+                check(g.finish((i - 1) % 2), i)
+        check(g.finish((n_frames - 1) % 2), n_frames)
         dist.barrier()
         ok[rank] = 1
     finally:
@@ -83,5 +100,8 @@ def test_band_layout_matches_c_abi_partition():
 
 def test_single_rank_gather_is_identity():
     g = BandGather(100, 8, 3, torch.float32, torch.device("cpu"), 0, 1)
-    g.local_view().copy_(torch.arange(100 * 8 * 3, dtype=torch.float32).view(100, 8, 3))
-    assert torch.equal(g.gather(), torch.arange(100 * 8 * 3, dtype=torch.float32).view(100, 8, 3))
+    for slot in (0, 1):
+        g.local_view(slot).copy_(torch.arange(100 * 8 * 3, dtype=torch.float32).view(100, 8, 3) + slot)
+        g.start(slot)
+    for slot in (0, 1):
+        assert torch.equal(g.finish(slot), torch.arange(100 * 8 * 3, dtype=torch.float32).view(100, 8, 3) + slot)
