@@ -201,6 +201,10 @@ rtc_status rtc_ctx_render(rtc_ctx* ctx, int32_t depth, const rtc_partition* part
 /* Waits for every rtc_ctx_render issued on this context so far and reports the
  * last launch's counters plus the mean kernel time since the previous call. */
 rtc_status rtc_ctx_stats(rtc_ctx* ctx, rtc_stats* out);
+/* Name of the kernel rtc_ctx_render launches for the current scene: an ahead-of-time instantiation
+ * ("render_kernel<4,simple>") or a scene-specialised one compiled at rtc_ctx_set_scene
+ * ("render_kernel_spec[...]"; env RTC_AMD_SPECIALIZE=0|1 overrides the size-based default). */
+const char* rtc_ctx_kernel_name(rtc_ctx* ctx);
 /* canvas.rs:39-43 scale_color on the device: n f32 channel values -> n bytes
  * ((c*255).min(255).max(0) as u8).  Both pointers are device pointers. */
 rtc_status rtc_ctx_quantize(rtc_ctx* ctx, const void* d_rgb, uint64_t n, void* d_out_u8, void* stream);

@@ -98,6 +98,7 @@ SIGNATURES = {
     "rtc_partition_rows": (C.c_uint32, [C.c_uint32, C.POINTER(rtc_partition)]),
     "rtc_ctx_render": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(rtc_partition), C.c_void_p, C.c_void_p]),
     "rtc_ctx_stats": (C.c_int, [C.c_void_p, C.POINTER(rtc_stats)]),
+    "rtc_ctx_kernel_name": (C.c_char_p, [C.c_void_p]),
     "rtc_ctx_quantize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rtc_color_at": (C.c_int, [C.POINTER(rtc_scene), FP, FP, C.c_uint32, C.c_int32, C.c_int32, FP]),
     "rtc_intensity_at": (C.c_int, [C.POINTER(rtc_scene), FP, C.c_uint32, C.c_int32, FP]),
@@ -123,6 +124,30 @@ class RtcError(RuntimeError):
         self.status = status
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (same SONAME as
+    /opt/rocm's).  If librtc_amd.so pulls in the system copy first and torch is imported afterwards,
+    torch finds a runtime it was not built against and reports no GPU.  So, when torch is installed but
+    not imported yet, load ITS runtime first (without importing torch): both then share it, whatever
+    the import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -130,6 +155,7 @@ def lib():
             raise ImportError(
                 "%s is missing: build it with `python -m ray_tracer_challenge_amd.build` "
                 "(there is no CPU/Python fallback for the render path)" % LIB_PATH)
+        _preload_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in list(SIGNATURES.items()) + list(EXTRA.items()):
             fn = getattr(L, name)

@@ -14,7 +14,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librtc_amd.so")
 SOURCES = [os.path.join(CSRC, "rtc_device.hip"), os.path.join(CSRC, "rtc_host.cpp")]
-HEADERS = [os.path.join(CSRC, "rtc_internal.h"), os.path.join(ROOT, "include", "rtc.h")]
+HEADERS = [os.path.join(CSRC, "rtc_internal.h"), os.path.join(CSRC, "rtc_kernel_core.h"),
+           os.path.join(ROOT, "include", "rtc.h")]
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -37,7 +38,7 @@ def build(force=False, verbose=False, extra_flags=()):
     if not force and not stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc] + FLAGS + list(extra_flags) + ["-o", LIB] + SOURCES
+    cmd = [hipcc] + FLAGS + list(extra_flags) + ["-o", LIB] + SOURCES + ["-lhiprtc", "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

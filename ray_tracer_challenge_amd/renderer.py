@@ -61,6 +61,10 @@ class Renderer:
                                        C.c_void_p(out.data_ptr()), C.c_void_p(s.cuda_stream)))
         return out
 
+    @property
+    def kernel_name(self):
+        return L.lib().rtc_ctx_kernel_name(self._ctx).decode()
+
     def stats(self):
         """Synchronises with the last render and returns its counters."""
         st = L.rtc_stats()

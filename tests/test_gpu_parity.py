@@ -257,3 +257,44 @@ def test_boundary_errors_on_device():
     with pytest.raises(P.RtcError) as e:
         cam.render(w, 5)
     assert e.value.status == L.RTC_ERR_UNSUPPORTED
+
+
+# ------------------------------------------------- scene-specialised (hiprtc) kernels
+@pytest.mark.parametrize("name,size,kw", [
+    ("soft_shadows", (100, 40), {"jitter": ("hashed", scenes.DEFAULT_SEED)}),
+    ("soft_shadows", (64, 64), {"jitter": ("constant", 0.5)}),
+    ("single_sphere", (64, 64), {}),
+    ("first_scene", (100, 50), {}),
+    ("first_plane", (100, 50), {}),
+    ("glass_and_mirror", (96, 96), {}),
+    ("shapes_medley", (128, 96), {}),
+])
+def test_specialised_kernel_matches_generic_and_oracle(name, size, kw, monkeypatch):
+    """RTC_AMD_SPECIALIZE=1 compiles the kernel for this scene's shape with hiprtc; the image, the ray
+    count and the shaded-hit count must equal the ahead-of-time kernel's and the oracle's."""
+    from ray_tracer_challenge_amd.renderer import Renderer
+    world, camera, depth = getattr(scenes, name)(*size, **kw)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RTC_AMD_SPECIALIZE", mode)
+        r = Renderer(world, camera, device=0)
+        assert r.kernel_name.startswith("render_kernel_spec[" if mode == "1" else "render_kernel<"), r.kernel_name
+        img = r.render(depth).cpu().numpy()
+        out[mode] = (img, r.stats())
+        r.close()
+    exp, rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=8)
+    for mode in ("0", "1"):
+        H.assert_images_equal(out[mode][0], exp, "%s specialise=%s" % (name, mode))
+        assert out[mode][1]["rays"] == rays
+    assert out["0"][1]["shaded_hits"] == out["1"][1]["shaded_hits"]
+
+
+def test_specialisation_policy_defaults(monkeypatch):
+    from ray_tracer_challenge_amd.renderer import Renderer
+    monkeypatch.delenv("RTC_AMD_SPECIALIZE", raising=False)
+    world, camera, _ = scenes.soft_shadows(64, 64)
+    assert Renderer(world, camera, device=0).kernel_name == "render_kernel<4,simple>"      # thumbnail: AOT
+    world, camera, _ = scenes.soft_shadows(1024, 512)
+    assert Renderer(world, camera, device=0).kernel_name.startswith("render_kernel_spec[")  # >= 2^18 pixels
+    world, camera, _ = scenes.sphere_grid(1024, 512)
+    assert Renderer(world, camera, device=0).kernel_name == "render_kernel<0,general>"     # 64 objects: generic

@@ -25,7 +25,7 @@ def build(specs):
     for spec in specs:
         tag, _, flags = spec.partition("=")
         out = os.path.join(VDIR, "librtc_amd_%s.so" % tag)
-        cmd = ["hipcc"] + B.FLAGS + flags.split() + ["-o", out] + B.SOURCES
+        cmd = ["hipcc"] + B.FLAGS + flags.split() + ["-o", out] + B.SOURCES + ["-lhiprtc", "-ldl"]
         procs.append((tag, subprocess.Popen(cmd)))
     for tag, p in procs:
         if p.wait() != 0:
