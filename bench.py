@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=4096, help="image edge in pixels (metric config: 4096)")
     ap.add_argument("--scene", default="soft_shadows", help="scene function in ray_tracer_challenge_amd.scenes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU oracle sample (0 = skip)")
@@ -160,13 +160,14 @@ def main():
         # roofline of the dominant kernel (render_kernel) on THIS rank: per-launch algorithmic bytes / mean duration
         algo_bytes = st["rays"] * n_obj * 64 + st["shaded_hits"] * 48 + st["pixels"] * 12
         achieved = algo_bytes / (st["kernel_ms"] * 1e-3) / 1e9 if st["kernel_ms"] > 0 else 0.0
-        traffic = None
+        traffic, tmeta = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and world_size == 1 and args.size == 4096 and args.scene == "soft_shadows":
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tmeta = json.load(open(tpath))
+                traffic = tmeta.get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic, tmeta = None, None
         verify = None
         if not args.no_verify:
             verify = verify_rows(image, world, camera, depth)
@@ -183,18 +184,15 @@ def main():
                            world_size, ", RCCL gather of f32 rows to rank 0" if world_size > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "render_kernel", "kernel_ms": round(st["kernel_ms"], 4),
+                         "kernel": renderer.kernel_name, "kernel_ms": round(st["kernel_ms"], 4),
                          "algorithmic_bytes": algo_bytes,
                          "note": "contractual figure (SURVEY.md 8d): rays x n_objects x 64 B + 48 B/shaded hit + "
                                  "12 B/pixel; the scene is SGPR/cache resident so physical HBM traffic is ~ the "
                                  "canvas store and frac may exceed 1; the physical limiter is FP32 VALU issue"},
-            # the physical limiter: FP32 VALU issue.  lane-ops/s from the PMC-measured VALU instruction count
-            # per ray (profiles/*_pmc.json) is not available live, so report the issue-slot view instead:
-            # one non-FMA f32 op per lane per cycle = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 Tops/s.
-            "valu": {"peak_tops": 78.6, "note": "see profiles/README.md: 190 VALU lane-ops per ray measured -> "
-                     "%.1f Tops/s = %.0f%% of the non-FMA FP32 issue peak" % (
-                         rays / (elapsed / args.steps) * 190 / 1e12, rays / (elapsed / args.steps) * 190 / 78.6e12 * 100)}
-            if args.scene == "soft_shadows" and args.size == 4096 else None,
+            # the physical limiter is FP32 VALU issue: VALU lane-ops/s from the PMC-measured instruction count of
+            # this kernel (profiles/hbm_traffic.json, written by profiles/summarize.py) against one non-FMA f32 op
+            # per lane per cycle = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 Tops/s
+            "valu": valu_view(tmeta, st["kernel_ms"]),
             "parity_check": verify,
         }
         if args.cpu_seconds > 0 and world_size == 1:
@@ -205,6 +203,15 @@ def main():
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def valu_view(tmeta, kernel_ms):
+    if not tmeta or "valu_wave_insts_per_launch" not in tmeta or kernel_ms <= 0:
+        return None
+    lane_ops = tmeta["valu_wave_insts_per_launch"] * 64.0
+    tops = lane_ops / (kernel_ms * 1e-3) / 1e12
+    return {"lane_ops_per_launch": lane_ops, "achieved_tops": round(tops, 2), "peak_tops": 78.6,
+            "frac": round(tops / 78.6, 3), "source": tmeta.get("source")}
 
 
 def verify_rows(image, world, camera, depth):

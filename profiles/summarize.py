@@ -44,8 +44,9 @@ if "GRBM_GUI_ACTIVE" in m and "SQ_INSTS_VALU" in m:
 if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
     hbm = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
     out["hbm_bytes_per_launch"] = hbm
-    json.dump({"kernel": "render_kernel", "workload": "C3 soft_shadows 4096x4096", "hbm_bytes_per_launch": hbm,
+    json.dump({"workload": "C3 soft_shadows 4096x4096", "hbm_bytes_per_launch": hbm,
                "fetch_size_kb": m["FETCH_SIZE"], "write_size_kb": m["WRITE_SIZE"], "source": "profiles/%s_pmc.json" % tag,
+               "valu_wave_insts_per_launch": m.get("SQ_INSTS_VALU"), "kernel": meta.get("kernel"),
                "method": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes"},
               open(os.path.join(here, "hbm_traffic.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(here, "%s_pmc.json" % tag), "w"), indent=1)

@@ -788,6 +788,20 @@ DI float schlick(V3 eye, V3 n, float n1, float n2) {
     return r0 + (1.0f - r0) * x5;
 }
 
+// Per-lane parking space in LDS for the state that must survive the light-sampling loop but is not
+// used inside it (ray, hit, normal, recursion bookkeeping).  Parked there it costs no VGPRs during
+// the 100-sample loop and no scratch (HBM-side) traffic; slot k of lane t lives at lds[k*stride + t],
+// so a wave's accesses are consecutive dwords (conflict-free).
+constexpr int STASH_SLOTS = 13;
+struct LaneStash {
+    float* base;
+    uint32_t stride;
+    DI void put(int k, float v) const { base[k * stride] = v; }
+    DI void putu(int k, uint32_t v) const { base[k * stride] = __uint_as_float(v); }
+    DI float get(int k) const { return base[k * stride]; }
+    DI uint32_t getu(int k) const { return __float_as_uint(base[k * stride]); }
+};
+
 // One suspended shade_hit (world.rs:62-86) waiting for a child colour.
 struct Frame {
     V3 acc;       // surface colour, later surface + reflected[*R]
@@ -802,7 +816,8 @@ enum { F_WAIT_REFR = 1, F_HAS_REFR = 2, F_SCHLICK = 4 };
 // `path` is the jitter path code: 1 at the root, 2p for the reflection child
 // of p, 2p+1 for its refraction child.
 template <int NOBJ, bool SIMPLE>
-DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint32_t pixel, Counters& cnt) {
+DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint32_t pixel, Counters& cnt,
+               const LaneStash stash) {
     Frame stack[RTC_MAX_DEPTH];
     int sp = 0;
     int rem = depth;
@@ -818,7 +833,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
             // precompute_values, world.rs:212-233.  Only what the light sampling needs is computed before
             // it (point, normal, over_point); everything else is (re)derived afterwards so that it is not
             // live across the 100-sample loop -- register pressure there decides occupancy.
-            const int ob = h.obj;
+            int ob = h.obj;
             V3 n;
             bool inside;
             V3 over_point;
@@ -834,7 +849,31 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
 
             // shade_hit, world.rs:62-86
             cnt.shaded++;
+            // park everything the sampling loop does not touch
+            stash.put(0, o.x), stash.put(1, o.y), stash.put(2, o.z);
+            stash.put(3, d.x), stash.put(4, d.y), stash.put(5, d.z);
+            stash.put(6, n.x), stash.put(7, n.y), stash.put(8, n.z);
+            stash.put(9, h.t);
+            stash.putu(10, (uint32_t)ob | (inside ? 0x80000000u : 0u));
+            stash.putu(11, pixel);
+            stash.putu(12, path | ((uint32_t)rem << 16) | ((uint32_t)sp << 20) | ((uint32_t)depth << 24));
+            asm volatile("" ::: "memory");
             float li = intensity_at<NOBJ, SIMPLE>(H, S, over_point, pixel, path, cnt);
+            asm volatile("" ::: "memory");
+            o = v3(stash.get(0), stash.get(1), stash.get(2));
+            d = v3(stash.get(3), stash.get(4), stash.get(5));
+            n = v3(stash.get(6), stash.get(7), stash.get(8));
+            h.t = stash.get(9);
+            {
+                const uint32_t w10 = stash.getu(10), w12 = stash.getu(12);
+                ob = (int)(w10 & 0x7fffffffu);
+                inside = (w10 >> 31) != 0;
+                pixel = stash.getu(11);
+                path = w12 & 0xffffu;
+                rem = (int)((w12 >> 16) & 0xfu);
+                sp = (int)((w12 >> 20) & 0xfu);
+                depth = (int)(w12 >> 24);
+            }
 
             V3 eye = -d;
             V3 reflectv = reflect3(d, inside ? -n : n);  // world.rs:221 uses the normal before the inside flip
@@ -949,6 +988,8 @@ DI void render_body(const RenderArgs& A) {
     const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t yl = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
     Counters cnt = {0u, 0u};
+    __shared__ float stash_lds[STASH_SLOTS * 256];
+    const LaneStash stash = {stash_lds + threadIdx.x, 256u};
     if (x < H.width && yl < A.rows) {
         // compact local row -> global row of the image
         const uint32_t band = yl / A.band_rows;
@@ -967,7 +1008,7 @@ DI void render_body(const RenderArgs& A) {
                         c[8] * world_x + c[9] * world_y + c[10] * -1.0f + c[11]};
             V3 origin = v3(H.cam_origin[0], H.cam_origin[1], H.cam_origin[2]);
             V3 direction = norm3(pixel - origin);
-            col = color_at<NOBJ, SIMPLE>(H, A.soa, origin, direction, A.depth, y * H.width + x, cnt);
+            col = color_at<NOBJ, SIMPLE>(H, A.soa, origin, direction, A.depth, y * H.width + x, cnt, stash);
         }
         float* dst = A.out + ((size_t)yl * H.width + x) * 3;
         dst[0] = col.x;
@@ -1055,8 +1096,10 @@ __global__ void color_at_kernel(SceneHdr H, SceneSoA S, const float4* __restrict
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Counters cnt = {0u, 0u};
+    __shared__ float stash_lds[STASH_SLOTS * 64];
+    const LaneStash stash = {stash_lds + threadIdx.x, 64u};
     float4 o = origins[i], d = directions[i];
-    V3 c = color_at<0, false>(H, S, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), depth, i, cnt);
+    V3 c = color_at<0, false>(H, S, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), depth, i, cnt, stash);
     out[i * 3 + 0] = c.x;
     out[i * 3 + 1] = c.y;
     out[i * 3 + 2] = c.z;
