@@ -314,10 +314,34 @@ DI Obj load_obj(const SceneSoA& S, uint32_t i) {
     o.bits = __float_as_uint(o.geo.w);
     return o;
 }
-// object i of an unrolled loop: its bits may be compile-time constants (spec_bits)
+// Record i of an object LOOP (i is the same in every lane).  Two things keep the compiler from fetching it
+// with scalar loads by itself: inside divergent control flow it carries a run-time loop counter in a VGPR,
+// and it cannot prove that the read-only scene is not clobbered by the kernel's own stores.  On C5 (64
+// spheres, generic loop) that meant per-lane vector loads and 64 % of wave-cycles waiting on memory.
+// readfirstlane states the uniformity, the constant address space states the immutability: the record
+// then comes through the scalar cache into SGPRs.  In the unrolled kernels i is a compile-time constant
+// and the bits may be too (spec_bits).
+typedef float RawF4 __attribute__((ext_vector_type(4)));
+typedef const RawF4 __attribute__((address_space(4))) * ConstF4Ptr;
+DI float4 load_uniform(const float4* base, uint32_t i) {
+    const uint32_t iu = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+    const RawF4 r = ((ConstF4Ptr)(unsigned long)base)[iu];
+    return make_float4(r.x, r.y, r.z, r.w);
+}
+// RUNTIME_INDEX: the generic any-count loop.  (The unrolled kernels index with constants; forcing the
+// constant address space there makes the loads freely hoistable and costs SGPR spills: C3 4.06 -> 4.37 ms.)
+template <bool RUNTIME_INDEX>
 DI Obj load_obj_static(const SceneSoA& S, uint32_t i) {
-    Obj o = load_obj(S, i);
-    o.bits = spec_bits(i, o.bits);
+    Obj o;
+    if constexpr (RUNTIME_INDEX) {
+        o.geo = load_uniform(S.geo, i);
+        o.off0 = load_uniform(S.off0, i);
+        o.off1 = load_uniform(S.off1, i);
+        o.off2 = load_uniform(S.off2, i);
+    } else {
+        o = load_obj(S, i);
+    }
+    o.bits = spec_bits(i, __float_as_uint(o.geo.w));
     return o;
 }
 
@@ -474,7 +498,15 @@ DI void for_each_object(const SceneHdr& H, F&& body) {
 #pragma unroll
         for (uint32_t i = 0; i < (uint32_t)NOBJ; i++) body(i);
     } else {
-        for (uint32_t i = 0; i < H.n_objects; i++) body(i);
+        // any object count: the record arrays are padded to a multiple of 8 with SHAPE_NONE entries (skipped by
+        // the bodies), so the loop advances four records at a time and their loads are issued together
+        const uint32_t padded = (H.n_objects + 7u) & ~7u;
+        for (uint32_t i = 0; i < padded; i += 4) {
+            body(i);
+            body(i + 1);
+            body(i + 2);
+            body(i + 3);
+        }
     }
 }
 
@@ -486,8 +518,8 @@ template <int NOBJ>
 DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d) {
     Hit best = {0.0f, -1};
     for_each_object<NOBJ>(H, [&](uint32_t i) {
-        Obj ob = load_obj_static(S, i);
-        if (NOBJ > 0 && (ob.bits & SHAPE_KIND_MASK) == SHAPE_NONE) return;  // padding record (wave-uniform)
+        Obj ob = load_obj_static<NOBJ == 0>(S, i);
+        if ((ob.bits & SHAPE_KIND_MASK) == SHAPE_NONE) return;  // padding record (wave-uniform)
         V3 po = obj_point(ob, o);
         V3 pd = obj_vector(ob, d);
         local_intersect<true>(ob.bits, ob.min_y(), ob.max_y(), po, pd, [&](float t) {
@@ -577,7 +609,7 @@ struct ShadowPre {
 template <int NOBJ>
 DI void shadow_prepare(const SceneHdr& H, const SceneSoA& S, V3 p, ShadowPre* pre) {
     for_each_object<NOBJ>(H, [&](uint32_t i) {
-        Obj ob = load_obj_static(S, i);
+        Obj ob = load_obj_static<NOBJ == 0>(S, i);
         pre[i].o = obj_point(ob, p);
         pre[i].c = quadratic_c(ob.bits & SHAPE_KIND_MASK, pre[i].o);
     });
@@ -735,7 +767,7 @@ DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int
     int c1 = -1, c2 = -1;
     bool hit_inside = false;
     for_each_object<NOBJ>(H, [&](uint32_t i) {
-        Obj ob = load_obj_static(S, i);
+        Obj ob = load_obj_static<NOBJ == 0>(S, i);
         V3 po = obj_point(ob, o);
         V3 pd = obj_vector(ob, d);
         int negatives = 0;
