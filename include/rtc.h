@@ -209,6 +209,14 @@ const char* rtc_ctx_kernel_name(rtc_ctx* ctx);
  * ((c*255).min(255).max(0) as u8).  Both pointers are device pointers. */
 rtc_status rtc_ctx_quantize(rtc_ctx* ctx, const void* d_rgb, uint64_t n, void* d_out_u8, void* stream);
 
+/* Canvas::to_ppm (canvas.rs:58-96) on the device: formats an f32 image that is already in HBM
+ * (d_rgb: height*width*3 f32) as P3 text into d_text (DEVICE buffer of at least
+ * rtc_ppm_max_bytes(width, height) bytes), byte-for-byte what the reference builds, including the
+ * 70-column wrapping.  Synchronises `stream`; *out_len = bytes written. */
+uint64_t rtc_ppm_max_bytes(uint32_t width, uint32_t height);
+rtc_status rtc_ctx_to_ppm(rtc_ctx* ctx, const void* d_rgb, uint32_t width, uint32_t height, void* d_text,
+                          uint64_t capacity, uint64_t* out_len, void* stream);
+
 /* Batched World::color_at (world.rs:88-101) for caller-supplied rays; ray i
  * uses pixel index i as its jitter key.  Host buffers: origins/directions
  * n*4 f32, out n*3 f32. */

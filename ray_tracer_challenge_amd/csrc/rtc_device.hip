@@ -171,6 +171,10 @@ struct rtc_ctx {
     size_t soa_cap = 0;  // float4 entries
     uint32_t n_objects = 0;
     bool simple = false;  // every object scale+translate-only and no cylinder
+    // workspace of rtc_ctx_to_ppm (grow-only)
+    unsigned long long* d_ppm_rows = nullptr;  // per-row length, then offset; [h] is the total
+    uint32_t* d_ppm_bits = nullptr;
+    size_t ppm_rows_cap = 0, ppm_bits_cap = 0;
     hipFunction_t spec_fn = nullptr;  // scene-specialised kernel (hiprtc), or null: ahead-of-time kernels
     std::string kernel_name;          // what rtc_ctx_render launches, for rtc_ctx_kernel_name()
     uint2* d_block_counts = nullptr;
@@ -349,6 +353,8 @@ void rtc_ctx_destroy(rtc_ctx* c) {
     if (c->d_soa) (void)hipFree(c->d_soa);
     if (c->d_block_counts) (void)hipFree(c->d_block_counts);
     if (c->d_total) (void)hipFree(c->d_total);
+    if (c->d_ppm_rows) (void)hipFree(c->d_ppm_rows);
+    if (c->d_ppm_bits) (void)hipFree(c->d_ppm_bits);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -522,6 +528,50 @@ rtc_status rtc_ctx_quantize(rtc_ctx* c, const void* d_rgb, uint64_t n, void* d_o
     hipLaunchKernelGGL(quantize_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream_, (const float*)d_rgb, n,
                        (uint8_t*)d_out_u8);
     HIP_TRY(hipGetLastError());
+    return RTC_OK;
+}
+
+uint64_t rtc_ppm_max_bytes(uint32_t width, uint32_t height) {
+    // header "P3\n<w> <h>\n255\n" (<= 32 bytes) + at most 4 bytes per colour channel
+    return 32ull + (uint64_t)width * height * 12ull;
+}
+
+rtc_status rtc_ctx_to_ppm(rtc_ctx* c, const void* d_rgb, uint32_t width, uint32_t height, void* d_text, uint64_t cap,
+                          uint64_t* out_len, void* stream_) {
+    if (!c || !d_rgb || !d_text || !out_len) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_to_ppm: null argument");
+    if (width == 0 || height == 0) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_to_ppm: empty canvas");
+    if (cap < rtc_ppm_max_bytes(width, height))
+        return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_to_ppm: text buffer must hold rtc_ppm_max_bytes() = %llu bytes",
+                    (unsigned long long)rtc_ppm_max_bytes(width, height));
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t words = (3u * width + 31u) / 32u;
+    if ((size_t)height + 1 > c->ppm_rows_cap) {
+        if (c->d_ppm_rows) HIP_TRY(hipFree(c->d_ppm_rows));
+        c->d_ppm_rows = nullptr;
+        HIP_TRY(hipMalloc(&c->d_ppm_rows, ((size_t)height + 1) * sizeof(unsigned long long)));
+        c->ppm_rows_cap = (size_t)height + 1;
+    }
+    if ((size_t)height * words > c->ppm_bits_cap) {
+        if (c->d_ppm_bits) HIP_TRY(hipFree(c->d_ppm_bits));
+        c->d_ppm_bits = nullptr;
+        HIP_TRY(hipMalloc(&c->d_ppm_bits, (size_t)height * words * sizeof(uint32_t)));
+        c->ppm_bits_cap = (size_t)height * words;
+    }
+    char head[40];
+    const int head_len = snprintf(head, sizeof(head), "P3\n%u %u\n255\n", width, height);  // canvas.rs:60-63
+    HIP_TRY(hipMemcpyAsync(d_text, head, (size_t)head_len, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(ppm_row_scan_kernel, dim3((height + 63) / 64), dim3(64), 0, stream, (const float*)d_rgb, width, height,
+                       c->d_ppm_rows, c->d_ppm_bits, words);
+    hipLaunchKernelGGL(ppm_row_offsets_kernel, dim3(1), dim3(1024), 0, stream, c->d_ppm_rows, height,
+                       (unsigned long long)head_len, c->d_ppm_rows + height);
+    hipLaunchKernelGGL(ppm_emit_kernel, dim3((height + 3) / 4), dim3(256), 0, stream, (const float*)d_rgb, width, height,
+                       c->d_ppm_rows, c->d_ppm_bits, words, (char*)d_text);
+    HIP_TRY(hipGetLastError());
+    unsigned long long total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, c->d_ppm_rows + height, sizeof(total), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));  // `head` and `total` are host stack memory
+    *out_len = total;
     return RTC_OK;
 }
 

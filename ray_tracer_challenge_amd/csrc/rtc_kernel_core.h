@@ -1121,6 +1121,122 @@ __global__ void quantize_kernel(const float* __restrict__ rgb, uint64_t n, uint8
     }
 }
 
+// ---- Canvas::to_ppm (canvas.rs:47-96) on the device -----------------------------------------------
+// The P3 body is a stream of tokens (one per colour channel, 3*w per image row); every token emits its
+// 1-3 digits followed by exactly ONE separator byte: ' ' while the current text line is shorter than 67
+// characters, '\n' otherwise (write_rgb_separator, canvas.rs:47-55), and '\n' after a row's last token
+// (canvas.rs:90-93).  So byte offsets are a plain prefix sum of (digits + 1); only the KIND of each
+// separator depends on the running line length, a tiny sequential automaton per image row.
+DI uint32_t ppm_channel(float c) {  // scale_color, canvas.rs:39-43
+    float v = fmaxf(fminf(c * 255.0f, 255.0f), 0.0f);
+    return (uint32_t)(uint8_t)v;
+}
+DI uint32_t ppm_digits(uint32_t v) { return 1u + (v >= 10u) + (v >= 100u); }
+
+// Pass 1, one thread per image row: row text length, and one bit per token: 1 = its separator is '\n'.
+__global__ void ppm_row_scan_kernel(const float* __restrict__ rgb, uint32_t w, uint32_t h,
+                                    unsigned long long* __restrict__ row_len, uint32_t* __restrict__ sep_bits,
+                                    uint32_t words_per_row) {
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= h) return;
+    const uint32_t n_tok = 3u * w;
+    const float* src = rgb + (size_t)row * n_tok;
+    uint32_t* bits = sep_bits + (size_t)row * words_per_row;
+    uint32_t line = 0, word = 0;
+    unsigned long long len = 0;
+    for (uint32_t k = 0; k < n_tok; k++) {
+        const uint32_t d = ppm_digits(ppm_channel(src[k]));
+        len += d + 1u;
+        line += d;
+        bool newline;
+        if (k + 1u == n_tok) {
+            newline = true;  // end of the image row
+        } else if (line < 67u) {
+            newline = false;
+            line += 1u;
+        } else {
+            newline = true;
+            line = 0u;
+        }
+        if (newline) word |= 1u << (k & 31u);
+        if ((k & 31u) == 31u || k + 1u == n_tok) {
+            bits[k >> 5] = word;
+            word = 0u;
+        }
+    }
+    row_len[row] = len;
+}
+
+// Pass 2: exclusive prefix sum of the row lengths (h entries, one workgroup), plus the total.
+__global__ __launch_bounds__(1024) void ppm_row_offsets_kernel(unsigned long long* __restrict__ row_len, uint32_t h,
+                                                               unsigned long long base,
+                                                               unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long part[1024];
+    const uint32_t per = (h + 1023u) / 1024u;
+    const uint32_t b = threadIdx.x * per, e = b + per < h ? b + per : h;
+    unsigned long long s = 0;
+    for (uint32_t i = b; i < e; i++) s += row_len[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = base;
+        for (int t = 0; t < 1024; t++) {
+            unsigned long long v = part[t];
+            part[t] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (uint32_t i = b; i < e; i++) {
+        unsigned long long v = row_len[i];
+        row_len[i] = run;
+        run += v;
+    }
+}
+
+// Pass 3, one wave per image row, 64 tokens per step: a wave-level prefix sum places each token's bytes.
+__global__ __launch_bounds__(256) void ppm_emit_kernel(const float* __restrict__ rgb, uint32_t w, uint32_t h,
+                                                       const unsigned long long* __restrict__ row_off,
+                                                       const uint32_t* __restrict__ sep_bits, uint32_t words_per_row,
+                                                       char* __restrict__ text) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (row >= h) return;
+    const uint32_t n_tok = 3u * w;
+    const float* src = rgb + (size_t)row * n_tok;
+    const uint32_t* bits = sep_bits + (size_t)row * words_per_row;
+    unsigned long long base = row_off[row];
+    for (uint32_t k0 = 0; k0 < n_tok; k0 += 64u) {
+        const uint32_t k = k0 + lane;
+        const bool active = k < n_tok;
+        uint32_t v = 0, d = 0, nbytes = 0;
+        bool newline = false;
+        if (active) {
+            v = ppm_channel(src[k]);
+            d = ppm_digits(v);
+            nbytes = d + 1u;
+            newline = (bits[k >> 5] >> (k & 31u)) & 1u;
+        }
+        // inclusive wave scan of nbytes
+        uint32_t incl = nbytes;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t up = __shfl_up(incl, off, 64);
+            if ((int)lane >= off) incl += up;
+        }
+        if (active) {
+            char* dst = text + base + (incl - nbytes);
+            uint32_t p = 0;
+            if (v >= 100u) dst[p++] = (char)('0' + v / 100u);
+            if (v >= 10u) dst[p++] = (char)('0' + (v / 10u) % 10u);
+            dst[p++] = (char)('0' + v % 10u);
+            dst[p] = newline ? '\n' : ' ';
+        }
+        base += __shfl(incl, 63, 64);
+    }
+}
+
 // The batched entry points are test/utility paths: they use the generic loop.
 __global__ void color_at_kernel(SceneHdr H, SceneSoA S, const float4* __restrict__ origins,
                                 const float4* __restrict__ directions, uint32_t n, int depth,

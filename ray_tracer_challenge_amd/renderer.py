@@ -72,6 +72,18 @@ class Renderer:
         return {"rays": int(st.rays), "shaded_hits": int(st.shaded_hits), "pixels": int(st.pixels),
                 "kernel_ms": float(st.kernel_ms), "launches": int(st.launches), "rows": int(st.rows)}
 
+    def to_ppm(self, rgb, stream=None):
+        """Canvas::to_ppm (canvas.rs:58-96) formatted on the device from an (h, w, 3) f32 tensor -> bytes."""
+        assert rgb.is_cuda and rgb.dtype == torch.float32 and rgb.is_contiguous() and rgb.dim() == 3
+        h, w = int(rgb.shape[0]), int(rgb.shape[1])
+        cap = int(L.lib().rtc_ppm_max_bytes(w, h))
+        text = torch.empty(cap, dtype=torch.uint8, device=rgb.device)
+        n = C.c_uint64()
+        s = torch.cuda.current_stream(self.device) if stream is None else stream
+        L.check(L.lib().rtc_ctx_to_ppm(self._ctx, C.c_void_p(rgb.data_ptr()), w, h, C.c_void_p(text.data_ptr()), cap,
+                                       C.byref(n), C.c_void_p(s.cuda_stream)))
+        return text[: n.value].cpu().numpy().tobytes()
+
     def quantize(self, rgb, stream=None):
         """canvas.rs:39-43 scale_color on the device: f32 tensor -> u8 tensor of the same shape."""
         out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)

@@ -142,3 +142,33 @@ def test_c1_soft_shadows_demo_default_resolution(torch):
     ppm = canvas.to_ppm()
     assert ppm.startswith(b"P3\n1000 400\n255\n") and ppm.endswith(b"\n")
     assert max(len(line) for line in ppm.split(b"\n")) <= 70
+
+
+def test_device_ppm_formatter(torch):
+    """Canvas::to_ppm formatted on the device (next-1 of SURVEY.md 8(f)): byte-identical to the oracle's
+    canvas.rs restatement for ragged sizes and edge values, and to the host writer on a full 4096^2 frame."""
+    import time
+    rng = np.random.default_rng(17)
+    world, camera, depth = scenes.soft_shadows(64, 64)
+    r = _renderer(world, camera)
+    for (w, h) in [(1, 1), (5, 3), (10, 2), (23, 7), (70, 3), (101, 4), (64, 64), (333, 17)]:
+        img = rng.uniform(-0.2, 1.3, (h, w, 3)).astype(f32)
+        img[0, 0] = [np.nan, np.inf, -np.inf]
+        if w > 4:
+            img[-1, -4:] = 1.0   # rows ending in three-digit values exercise the wrap at the row end
+        got = r.to_ppm(torch.from_numpy(img).cuda())
+        assert got == O.to_ppm(img), (w, h)
+    world, camera, depth = scenes.CONFIGS["C3"]()
+    r = _renderer(world, camera)
+    frame = r.render(depth)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    text = r.to_ppm(frame)
+    t_dev = time.perf_counter() - t0
+    host = P.Canvas(4096, 4096, frame.cpu().numpy())
+    t0 = time.perf_counter()
+    ref = host.to_ppm()
+    t_host = time.perf_counter() - t0
+    assert text == ref
+    assert text.startswith(b"P3\n4096 4096\n255\n") and len(text) > 100_000_000
+    print("\nto_ppm 4096^2: device formatter + D2H %.3f s, host writer %.3f s, %d bytes" % (t_dev, t_host, len(text)))
