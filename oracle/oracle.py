@@ -17,8 +17,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "librtc_oracle.so")
 
-SPHERE, PLANE, CUBE, CYLINDER = 0, 1, 2, 3
+SPHERE, PLANE, CUBE, CYLINDER, CONE = 0, 1, 2, 3, 4
 TEST_SHAPE = 100
+PATTERN_NONE, PATTERN_STRIPES, PATTERN_GRADIENT, PATTERN_RINGS, PATTERN_CHECKERS, PATTERN_SINE2D = 0, 1, 2, 3, 4, 5
+PATTERN_TEST = 100
 LIGHT_POINT, LIGHT_RECT = 0, 1
 JITTER_CONSTANT, JITTER_CYCLE, JITTER_HASHED = 0, 1, 2
 
@@ -37,10 +39,14 @@ def build(force=False):
     return _LIB_PATH
 
 
+class _Pattern(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("a", C.c_float * 3), ("b", C.c_float * 3), ("transform", C.c_float * 16)]
+
+
 class _Material(C.Structure):
     _fields_ = [("color", C.c_float * 3), ("ambient", C.c_float), ("diffuse", C.c_float),
                 ("specular", C.c_float), ("shininess", C.c_float), ("reflective", C.c_float),
-                ("transparency", C.c_float), ("refractive_index", C.c_float)]
+                ("transparency", C.c_float), ("refractive_index", C.c_float), ("pattern", _Pattern)]
 
 
 class _Shape(C.Structure):
@@ -101,6 +107,7 @@ def lib():
         L.rtco_camera_new.argtypes = [C.c_uint32, C.c_uint32, C.c_float, _FP, C.POINTER(_Camera)]
         L.rtco_position.argtypes = [_FP, _FP, C.c_float, _FP]
         L.rtco_phong.argtypes = [C.c_void_p, C.POINTER(_Material), _FP, _FP, _FP, C.c_float, _FP]
+        L.rtco_phong_on.argtypes = [C.c_void_p, C.POINTER(_Shape), _FP, _FP, _FP, C.c_float, _FP]
         L.rtco_scale_color.argtypes = [C.c_float]
         L.rtco_jitter_value.argtypes = [C.c_uint32]
         _lib = L
@@ -324,19 +331,80 @@ def jitter_value(h):
 
 
 # ------------------------------------------------------------ scene classes
+class Pattern:
+    """pattern/*.rs: two colours and a pattern->object transform (set_transformation inverts it)."""
+
+    def __init__(self, kind, a=(1, 1, 1), b=(0, 0, 0), transform=None):
+        self.kind = kind
+        self.a, self.b = tuple(float(c) for c in a), tuple(float(c) for c in b)
+        self.transform = identity_4x4() if transform is None else np.asarray(transform, dtype=f32)
+
+    def set_transformation(self, t):
+        self.transform = np.asarray(t, dtype=f32)
+
+    def _c(self):
+        p = _Pattern()
+        p.kind = self.kind
+        p.a[:] = [f32(c) for c in self.a]
+        p.b[:] = [f32(c) for c in self.b]
+        p.transform[:] = [f32(v) for v in self.transform.reshape(-1)]
+        return p
+
+    def color_at_world(self, point):
+        c, a = self._c(), _a(point, 4)
+        out = np.zeros(3, dtype=f32)
+        lib().rtco_pattern_color_at_world(C.byref(c), _p(a), _p(out))
+        return out
+
+    def color_at_object(self, world_point, shape):
+        c, s, a = self._c(), shape._c(), _a(world_point, 4)
+        out = np.zeros(3, dtype=f32)
+        lib().rtco_pattern_color_at_object(C.byref(c), C.byref(s), _p(a), _p(out))
+        return out
+
+
+def Stripes(a=(1, 1, 1), b=(0, 0, 0), transform=None):
+    return Pattern(PATTERN_STRIPES, a, b, transform)
+
+
+def Gradient(a=(1, 1, 1), b=(0, 0, 0), transform=None):
+    return Pattern(PATTERN_GRADIENT, a, b, transform)
+
+
+def Rings(a=(1, 1, 1), b=(0, 0, 0), transform=None):
+    return Pattern(PATTERN_RINGS, a, b, transform)
+
+
+def Checkers(a=(1, 1, 1), b=(0, 0, 0), transform=None):
+    return Pattern(PATTERN_CHECKERS, a, b, transform)
+
+
+def Sine2D(a=(1, 1, 1), b=(0, 0, 0), transform=None):
+    return Pattern(PATTERN_SINE2D, a, b, transform)
+
+
+def TestPattern(transform=None):
+    """pattern.rs:66-89: returns the pattern-space point as the colour."""
+    return Pattern(PATTERN_TEST, transform=transform)
+
+
+TestPattern.__test__ = False
+
+
 class Material:
     """material.rs:18-51 defaults."""
 
     def __init__(self, color=(1, 1, 1), ambient=0.1, diffuse=0.9, specular=0.9, shininess=200.0,
-                 reflective=0.0, transparency=0.0, refractive_index=1.0):
+                 reflective=0.0, transparency=0.0, refractive_index=1.0, pattern=None):
         self.color = tuple(float(c) for c in color)
         self.ambient, self.diffuse, self.specular = ambient, diffuse, specular
         self.shininess, self.reflective = shininess, reflective
         self.transparency, self.refractive_index = transparency, refractive_index
+        self.pattern = pattern
 
     def copy(self, **kw):
         m = Material(self.color, self.ambient, self.diffuse, self.specular, self.shininess,
-                     self.reflective, self.transparency, self.refractive_index)
+                     self.reflective, self.transparency, self.refractive_index, self.pattern)
         for k, v in kw.items():
             setattr(m, k, v)
         return m
@@ -347,6 +415,8 @@ class Material:
         for k in ("ambient", "diffuse", "specular", "shininess", "reflective", "transparency",
                   "refractive_index"):
             setattr(m, k, f32(getattr(self, k)))
+        if self.pattern is not None:
+            m.pattern = self.pattern._c()
         return m
 
 
@@ -410,6 +480,10 @@ def Cube(transform=None, material=None, **kw):
 
 def Cylinder(transform=None, material=None, **kw):
     return Shape(CYLINDER, transform, material, **kw)
+
+
+def Cone(transform=None, material=None, **kw):
+    return Shape(CONE, transform, material, **kw)
 
 
 def TestShape(transform=None, material=None, **kw):
@@ -555,11 +629,16 @@ class World:
         lib().rtco_refracted_color(self._handle(), C.byref(comps), int(depth), _p(out))
         return out
 
-    def phong_lighting(self, material, p, eye, n, light_intensity):
-        m = material._c()
+    def phong_lighting(self, material, p, eye, n, light_intensity, shape=None):
+        """phong_lighting.rs:12-63; `shape` is the lit object (default: the tests' any_shape(), a unit sphere)."""
         a, b, c = _a(p, 4), _a(eye, 4), _a(n, 4)
         out = np.zeros(3, dtype=f32)
-        lib().rtco_phong(self._handle(), C.byref(m), _p(a), _p(b), _p(c), f32(light_intensity), _p(out))
+        if shape is None:
+            m = material._c()
+            lib().rtco_phong(self._handle(), C.byref(m), _p(a), _p(b), _p(c), f32(light_intensity), _p(out))
+        else:
+            s = Shape(shape.kind, shape.transform, material)._c()
+            lib().rtco_phong_on(self._handle(), C.byref(s), _p(a), _p(b), _p(c), f32(light_intensity), _p(out))
         return out
 
 

@@ -54,6 +54,7 @@ struct Color {
     float r, g, b;
 };
 inline Color operator+(Color a, Color b) { return {a.r + b.r, a.g + b.g, a.b + b.b}; }  // color.rs:33-39
+inline Color operator-(Color a, Color b) { return {a.r - b.r, a.g - b.g, a.b - b.b}; }  // color.rs:41-47
 inline Color operator*(Color a, float s) { return {a.r * s, a.g * s, a.b * s}; }        // color.rs:50-56
 inline Color operator*(Color a, Color b) { return {a.r * b.r, a.g * b.g, a.b * b.b}; }  // color.rs:70-76
 const Color BLACK = {0.0f, 0.0f, 0.0f};
@@ -224,10 +225,71 @@ int hit_index(const std::vector<Intersection>& xs) {
 }
 
 // --------------------------------------------------------------- material.rs
+// ------------------------------------------------------------- pattern/*.rs
+struct Pattern {
+    int kind = RTCO_PATTERN_NONE;
+    Color a{0, 0, 0}, b{0, 0, 0};
+    Color distance{0, 0, 0};  // gradient.rs:17, sine_2d.rs:17: b - a, computed once in new()
+    Matrix t_inverse;         // pattern.rs:52-54
+};
+// Rust `f as i32` saturates (and maps NaN to 0); a bare C cast is undefined outside the i32 range.
+inline int32_t rust_f32_as_i32(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return INT32_MAX;
+    if (f <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)f;
+}
+Color pattern_color_at_world(const Pattern& p, Tuple pt) {
+    switch (p.kind) {
+        case RTCO_PATTERN_STRIPES:  // stripes.rs:39-45; Rust % keeps the dividend's sign, as C's does
+            return rust_f32_as_i32(std::floor(pt.x)) % 2 == 0 ? p.a : p.b;
+        case RTCO_PATTERN_GRADIENT: {  // gradient.rs:33-36
+            float fraction = pt.x - std::floor(pt.x);
+            return p.a + (p.distance * fraction);
+        }
+        case RTCO_PATTERN_RINGS:  // rings.rs:38-50
+            return rust_f32_as_i32(std::floor(std::sqrt(pt.x * pt.x + pt.z * pt.z))) % 2 == 0 ? p.a : p.b;
+        case RTCO_PATTERN_CHECKERS:  // checkers.rs:38-46
+            return rust_f32_as_i32(std::floor(std::fabs(pt.x) + std::fabs(pt.y) + std::fabs(pt.z))) % 2 == 0 ? p.a : p.b;
+        case RTCO_PATTERN_SINE2D: {  // sine_2d.rs:39-44; f32::cos is the platform cosf (glibc here)
+            float cosine = cosf(pt.x + pt.z);
+            float fraction = (-cosine + 1.0f) / 2.0f;
+            return p.a + (p.distance * fraction);
+        }
+        case RTCO_PATTERN_TEST:  // pattern.rs:85-87
+            return {pt.x, pt.y, pt.z};
+    }
+    return {0, 0, 0};
+}
+Pattern pattern_from(const rtco_pattern& c) {
+    Pattern p;
+    p.kind = c.kind;
+    if (c.kind == RTCO_PATTERN_NONE) return p;
+    p.a = {c.a[0], c.a[1], c.a[2]};
+    p.b = {c.b[0], c.b[1], c.b[2]};
+    p.distance = p.b - p.a;
+    p.t_inverse = inverse(mat_from(c.transform, 4));
+    return p;
+}
+
 struct Material {
     Color color;
     float ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
+    Pattern pattern;  // material.rs:50 Option<BoxedPattern>; kind NONE == None
 };
+Material material_from(const rtco_material& m) {
+    Material mm;
+    mm.color = {m.color[0], m.color[1], m.color[2]};
+    mm.ambient = m.ambient;
+    mm.diffuse = m.diffuse;
+    mm.specular = m.specular;
+    mm.shininess = m.shininess;
+    mm.reflective = m.reflective;
+    mm.transparency = m.transparency;
+    mm.refractive_index = m.refractive_index;
+    mm.pattern = pattern_from(m.pattern);
+    return mm;
+}
 
 // ------------------------------------------------- shape/{shape,base_shape}.rs
 const float CLOSE_TO_ZERO = 0.000001f;  // cylinder.rs:82
@@ -250,14 +312,7 @@ Shape shape_from(const rtco_shape& s, int id) {
     sh.t = mat_from(s.transform, 4);
     sh.t_inverse = inverse(sh.t);                        // base_shape.rs:58
     sh.t_inverse_transpose = transpose(inverse(sh.t));   // base_shape.rs:59
-    sh.m.color = {s.material.color[0], s.material.color[1], s.material.color[2]};
-    sh.m.ambient = s.material.ambient;
-    sh.m.diffuse = s.material.diffuse;
-    sh.m.specular = s.material.specular;
-    sh.m.shininess = s.material.shininess;
-    sh.m.reflective = s.material.reflective;
-    sh.m.transparency = s.material.transparency;
-    sh.m.refractive_index = s.material.refractive_index;
+    sh.m = material_from(s.material);
     sh.id = id;
     return sh;
 }
@@ -289,6 +344,13 @@ bool check_cap(const Ray& r, float t) {
     float x = r.origin.x + t * r.direction.x;
     float z = r.origin.z + t * r.direction.z;
     return (x * x + z * z) <= 1.0f + CLOSE_TO_ZERO;
+}
+
+// cone.rs:148-154
+bool cone_check_cap(float radius, const Ray& r, float t) {
+    float x = r.origin.x + t * r.direction.x;
+    float z = r.origin.z + t * r.direction.z;
+    return (x * x + z * z) <= radius + CLOSE_TO_ZERO;
 }
 
 void local_intersect(const Shape& s, const Ray& r, std::vector<Intersection>& out) {
@@ -347,6 +409,37 @@ void local_intersect(const Shape& s, const Ray& r, std::vector<Intersection>& ou
             }
             return;
         }
+        case RTCO_CONE: {  // cone.rs:52-57 (sides, then caps -- always, unlike the cylinder), :89-175
+            do {  // intersect_sides :89-141
+                float two_a = 2.0f * (r.direction.x * r.direction.x - r.direction.y * r.direction.y +
+                                      r.direction.z * r.direction.z);
+                float b = 2.0f * (r.origin.x * r.direction.x - r.origin.y * r.direction.y + r.origin.z * r.direction.z);
+                // calc_c :143-146
+                float c = r.origin.x * r.origin.x - r.origin.y * r.origin.y + r.origin.z * r.origin.z;
+                if (std::fabs(two_a) < CLOSE_TO_ZERO) {
+                    if (std::fabs(b) < CLOSE_TO_ZERO) break;
+                    out.push_back({-c / (2.0f * b), s.id, 0.f, 0.f});  // no y-range check on this branch (:99-107)
+                    break;
+                }
+                float disc = b * b - 2.0f * two_a * c;
+                if (disc < 0.0f) break;
+                float sq = std::sqrt(disc);
+                float d1 = (-b - sq) / two_a;
+                float d2 = (-b + sq) / two_a;
+                if (d1 > d2) std::swap(d1, d2);
+                float y1 = r.origin.y + d1 * r.direction.y;
+                if (s.min_y < y1 && y1 < s.max_y) out.push_back({d1, s.id, 0.f, 0.f});
+                float y2 = r.origin.y + d2 * r.direction.y;
+                if (s.min_y < y2 && y2 < s.max_y) out.push_back({d2, s.id, 0.f, 0.f});
+            } while (false);
+            if (s.closed) {  // intersect_caps :156-175; check_cap :148-154 compares x^2+z^2 with |y| (not y^2)
+                float t = (s.min_y - r.origin.y) / r.direction.y;
+                if (cone_check_cap(std::fabs(s.min_y), r, t)) out.push_back({t, s.id, 0.f, 0.f});
+                t = (s.max_y - r.origin.y) / r.direction.y;
+                if (cone_check_cap(std::fabs(s.max_y), r, t)) out.push_back({t, s.id, 0.f, 0.f});
+            }
+            return;
+        }
     }
 }
 
@@ -372,6 +465,16 @@ Tuple local_norm_at(const Shape& s, Tuple p) {
                 if (p.y <= s.min_y + CLOSE_TO_ZERO) return vector(0, -1, 0);
             }
             return vector(p.x, 0, p.z);
+        }
+        case RTCO_CONE: {  // cone.rs:60-73 (the cap test uses radius 1, as written there)
+            float dist_square = p.x * p.x + p.z * p.z;
+            if (dist_square < 1.0f) {
+                if (p.y >= s.max_y - CLOSE_TO_ZERO) return vector(0, 1, 0);
+                if (p.y <= s.min_y + CLOSE_TO_ZERO) return vector(0, -1, 0);
+            }
+            float y = std::sqrt(p.x * p.x + p.z * p.z);
+            if (p.y > 0.0f) y = -y;
+            return vector(p.x, y, p.z);
         }
     }
     return vector(0, 0, 0);
@@ -504,8 +607,18 @@ float intensity_at(World& w, Tuple p, uint32_t path) {
 }
 
 // light/phong_lighting.rs:12-63 (pattern branch :24-27 out of scope)
-Color phong_lighting(const Material& m, const Light& light, Tuple p, Tuple eye, Tuple n, float light_intensity) {
-    Color effective = m.color * light.intensity;
+// pattern.rs:15-19
+Color pattern_color_at_object(const Pattern& pat, const Shape& object, Tuple world_point) {
+    Tuple object_point = object.t_inverse * world_point;
+    Tuple pattern_point = pat.t_inverse * object_point;
+    return pattern_color_at_world(pat, pattern_point);
+}
+
+Color phong_lighting(const Shape& object, const Material& m, const Light& light, Tuple p, Tuple eye, Tuple n,
+                     float light_intensity) {
+    // phong_lighting.rs:24-28
+    Color material_color = m.pattern.kind != RTCO_PATTERN_NONE ? pattern_color_at_object(m.pattern, object, p) : m.color;
+    Color effective = material_color * light.intensity;
     Color ambient = effective * m.ambient;
     if (light_intensity == 0.0f) return ambient;
     Tuple to_light = norm(light.position - p);
@@ -627,7 +740,7 @@ Color refracted_color(World& w, const Comps& c, int remaining, uint32_t path) {
 // world.rs:62-86
 Color shade_hit(World& w, const Comps& c, int remaining, uint32_t path) {
     const Material& m = w.objects[c.object].m;
-    Color surface = phong_lighting(m, w.light, c.over_point, c.eye, c.normal, intensity_at(w, c.over_point, path));
+    Color surface = phong_lighting(w.objects[c.object], m, w.light, c.over_point, c.eye, c.normal, intensity_at(w, c.over_point, path));
     Color reflected = reflected_color(w, c, remaining, path);
     Color refracted = refracted_color(w, c, remaining, path);
     if (m.reflective > 0.0f && m.transparency > 0.0f) {
@@ -917,16 +1030,25 @@ void rtco_refracted_color(rtco_world* w, const rtco_comps* c, int depth, float o
 float rtco_schlick(const rtco_comps* c) { return schlick_reflectance(comps_from(c)); }
 void rtco_phong(rtco_world* w, const rtco_material* m, const float p[4], const float eye[4], const float n[4],
                 float light_intensity, float out[3]) {
-    Material mm;
-    mm.color = {m->color[0], m->color[1], m->color[2]};
-    mm.ambient = m->ambient;
-    mm.diffuse = m->diffuse;
-    mm.specular = m->specular;
-    mm.shininess = m->shininess;
-    mm.reflective = m->reflective;
-    mm.transparency = m->transparency;
-    mm.refractive_index = m->refractive_index;
-    putc(phong_lighting(mm, w->light, T(p), T(eye), T(n), light_intensity), out);
+    // the reference's tests pass any_shape(): an untransformed sphere (test/utils.rs)
+    rtco_shape any{};
+    any.kind = RTCO_SPHERE;
+    for (int i = 0; i < 4; i++) any.transform[i * 5] = 1.0f;
+    any.material = *m;
+    Shape sh = shape_from(any, 0);
+    putc(phong_lighting(sh, sh.m, w->light, T(p), T(eye), T(n), light_intensity), out);
+}
+void rtco_phong_on(rtco_world* w, const rtco_shape* object, const float p[4], const float eye[4], const float n[4],
+                   float light_intensity, float out[3]) {
+    Shape sh = shape_from(*object, 0);
+    putc(phong_lighting(sh, sh.m, w->light, T(p), T(eye), T(n), light_intensity), out);
+}
+void rtco_pattern_color_at_world(const rtco_pattern* pat, const float p[4], float out[3]) {
+    putc(pattern_color_at_world(pattern_from(*pat), T(p)), out);
+}
+void rtco_pattern_color_at_object(const rtco_pattern* pat, const rtco_shape* object, const float world_point[4],
+                                  float out[3]) {
+    putc(pattern_color_at_object(pattern_from(*pat), shape_from(*object, 0), T(world_point)), out);
 }
 
 uint64_t rtco_render_rows(rtco_world* w, const rtco_camera* cam, int depth, int threads, uint32_t y0, uint32_t y1,

@@ -23,17 +23,30 @@
 extern "C" {
 #endif
 
-enum { RTCO_SPHERE = 0, RTCO_PLANE = 1, RTCO_CUBE = 2, RTCO_CYLINDER = 3,
+enum { RTCO_SPHERE = 0, RTCO_PLANE = 1, RTCO_CUBE = 2, RTCO_CYLINDER = 3, RTCO_CONE = 4,
        RTCO_TEST_SHAPE = 100 /* shape/test_shape.rs: no hits, local normal (2x,3y,4z) */ };
 enum { RTCO_LIGHT_POINT = 0, RTCO_LIGHT_RECT = 1 };
 /* jitter sources for RectangleLight (light/rectangle_light.rs:44-47, test/utils.rs:15-24) */
 enum { RTCO_JITTER_CONSTANT = 0, RTCO_JITTER_CYCLE = 1, RTCO_JITTER_HASHED = 2 };
 
-/* material.rs:18-51 (pattern is out of scope) */
+/* pattern/{stripes,gradient,rings,checkers,sine_2d}.rs; RTCO_PATTERN_TEST is pattern/pattern.rs:66-89
+ * (test double: the pattern-space point as the colour) */
+enum { RTCO_PATTERN_NONE = 0, RTCO_PATTERN_STRIPES = 1, RTCO_PATTERN_GRADIENT = 2, RTCO_PATTERN_RINGS = 3,
+       RTCO_PATTERN_CHECKERS = 4, RTCO_PATTERN_SINE2D = 5, RTCO_PATTERN_TEST = 100 };
+
+/* `transform` is the FORWARD pattern->object matrix; the oracle inverts it (pattern.rs:52-54). */
+typedef struct rtco_pattern {
+    int32_t kind;
+    float a[3], b[3];
+    float transform[16];
+} rtco_pattern;
+
+/* material.rs:18-51 */
 typedef struct rtco_material {
     float color[3];
     float ambient, diffuse, specular, shininess;
     float reflective, transparency, refractive_index;
+    rtco_pattern pattern;
 } rtco_material;
 
 /* shape/base_shape.rs:13-20 + cylinder.rs:14-19.  `transform` is the FORWARD
@@ -147,6 +160,13 @@ float rtco_schlick(const rtco_comps* c);
 /* light/phong_lighting.rs:12-63; light taken from the world */
 void rtco_phong(rtco_world* w, const rtco_material* m, const float p[4], const float eye[4],
                 const float n[4], float light_intensity, float out[3]);
+/* same with the lit object given (phong_lighting.rs:13), for patterned materials */
+void rtco_phong_on(rtco_world* w, const rtco_shape* object, const float p[4], const float eye[4],
+                   const float n[4], float light_intensity, float out[3]);
+/* pattern.rs:12 color_at_world / :15-19 color_at_object */
+void rtco_pattern_color_at_world(const rtco_pattern* pat, const float p[4], float out[3]);
+void rtco_pattern_color_at_object(const rtco_pattern* pat, const rtco_shape* object, const float world_point[4],
+                                  float out[3]);
 
 /* ---- camera.rs:76-91 render + canvas.rs ---- */
 /* out_rgb: w*h*3 f32 row-major, fully written (last row/column black).

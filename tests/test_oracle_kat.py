@@ -376,3 +376,69 @@ def test_scale_color_and_ppm(kat):  # canvas.rs:218-278
     c = C["header"]
     w, h = c["size"]
     assert O.to_ppm(np.zeros((h, w, 3), dtype=f32)).decode().split("\n")[:3] == c["lines"]
+
+
+def test_cone(kat):  # shape/cone.rs:190-278
+    co = kat["cone"]
+    c = O.Cone()
+    for o, d, t0, t1 in co["sides"]["cases"]:
+        ts = c.local_intersect(K.point(o), O.norm(K.vector(d)))
+        assert len(ts) == 2, (o, d, ts)
+        K.assert_eps(ts, [t0, t1])
+    blk = co["parallel_to_one_half"]
+    ts = c.local_intersect(K.point(blk["ray"][0]), O.norm(K.vector(blk["ray"][1])))
+    assert len(ts) == 1
+    K.assert_eps(ts, blk["expect_eps"])
+    blk = co["caps"]
+    cc = O.Cone(minimum_y=blk["min"], maximum_y=blk["max"], closed=blk["closed"])
+    for o, d, count in blk["cases"]:
+        assert len(cc.local_intersect(K.point(o), O.norm(K.vector(d)))) == count, (o, d)
+    for p, n in co["normals"]["cases"]:
+        K.assert_exact(c.local_norm_at(K.point(p)), K.vector(n))
+
+
+PATTERN_CTORS = {"stripes": O.Stripes, "gradient": O.Gradient, "rings": O.Rings, "checkers": O.Checkers,
+                 "sine_2d": O.Sine2D}
+
+
+def test_patterns_color_at_world(kat):  # pattern/{stripes,gradient,rings,checkers,sine_2d}.rs tests
+    for name, ctor in PATTERN_CTORS.items():
+        blk = kat["pattern"][name]
+        pat = ctor(blk["a"], blk["b"])
+        for p, expect in blk["cases_exact"]:
+            K.assert_exact(pat.color_at_world(K.point(p)), K.vec(expect))
+        for p, expect in blk.get("cases_eps", []):
+            K.assert_eps(pat.color_at_world(K.point(p)), K.vec(expect))
+
+
+def test_pattern_transformations(kat):  # pattern/pattern.rs:99-122
+    P = kat["pattern"]
+    c = P["with_object_transformation"]
+    got = O.TestPattern().color_at_object(K.point(c["point"]), O.Sphere(O.scaling(*c["object_scaling"])))
+    K.assert_exact(got, c["expect_exact"])
+    c = P["with_pattern_transformation"]
+    got = O.TestPattern(O.scaling(*c["pattern_scaling"])).color_at_object(K.point(c["point"]), O.Sphere())
+    K.assert_exact(got, c["expect_exact"])
+    c = P["with_both_transformations"]
+    got = O.TestPattern(O.translation(*c["pattern_translation"])).color_at_object(
+        K.point(c["point"]), O.Sphere(O.scaling(*c["object_scaling"])))
+    K.assert_exact(got, c["expect_exact"])
+
+
+def test_phong_lighting_with_pattern(kat):  # light/phong_lighting.rs:197-235
+    c = kat["pattern"]["phong_with_pattern"]
+    m = O.Material(color=c["color"], ambient=c["ambient"], diffuse=c["diffuse"], specular=c["specular"],
+                   pattern=O.Stripes((1, 1, 1), (0, 0, 0)))
+    w = O.World([], O.PointLight(K.point(c["light"]), O.color(1, 1, 1)))
+    for p, expect in c["cases_exact"]:
+        got = w.phong_lighting(m, K.point(p), K.vector(c["eye"]), K.vector(c["normal"]), 1.0)
+        K.assert_exact(got, expect)
+
+
+def test_refracted_color_with_refracted_ray(kat):  # world.rs:716-744
+    c = kat["pattern"]["refracted_color_with_refracted_ray"]
+    w = O.default_world()
+    w.objects[0].material = w.objects[0].material.copy(ambient=1.0, pattern=O.TestPattern())
+    w.objects[1].material = w.objects[1].material.copy(transparency=1.0, refractive_index=1.5)
+    comps = w.precompute_values(K.point(c["ray"][0]), K.vector(c["ray"][1]), c["hit_index"], [tuple(x) for x in c["xs"]])
+    K.assert_eps(w.refracted_color(comps, c["depth"]), c["expect_eps"])
