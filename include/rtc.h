@@ -9,7 +9,8 @@
  *
  * and everything it calls per pixel (ray_for_pixel, World::color_at / intersect /
  * shade_hit / is_shadowed / reflected_color / refracted_color, the Sphere /
- * Plane / Cube / Cylinder intersectors, phong_lighting).  The reference has no
+ * Plane / Cube / Cylinder / Cone intersectors, phong_lighting with the
+ * procedural patterns of pattern/*.rs).  The reference has no
  * FFI of its own; INTEGRATION.md shows the `extern "C"` block a maintainer
  * would add to camera.rs to bind these entry points.
  *
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTC_ABI_VERSION 1
+#define RTC_ABI_VERSION 2
 /* maximum reflection_recursion_depth accepted (reference default: 5, constants.rs:4) */
 #define RTC_MAX_DEPTH 8
 
@@ -42,8 +43,11 @@ typedef enum rtc_status {
     RTC_ERR_NO_DEVICE = -5    /* no gfx950 device visible: there is NO CPU fallback      */
 } rtc_status;
 
-/* shape/{sphere,plane,cube,cylinder}.rs */
-enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3 };
+/* shape/{sphere,plane,cube,cylinder,cone}.rs */
+enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3, RTC_CONE = 4 };
+/* pattern/{stripes,gradient,rings,checkers,sine_2d}.rs; NONE = Material.pattern is None (material.rs:50) */
+enum { RTC_PATTERN_NONE = 0, RTC_PATTERN_STRIPES = 1, RTC_PATTERN_GRADIENT = 2, RTC_PATTERN_RINGS = 3,
+       RTC_PATTERN_CHECKERS = 4, RTC_PATTERN_SINE2D = 5 };
 /* light/{point_light,rectangle_light}.rs */
 enum { RTC_LIGHT_POINT = 0, RTC_LIGHT_RECT = 1 };
 /* RectangleLight jitter source.  The reference takes an arbitrary closure
@@ -52,7 +56,18 @@ enum { RTC_LIGHT_POINT = 0, RTC_LIGHT_RECT = 1 };
  * hash (DESIGN.md "Jitter") standing in for thread_rng(). */
 enum { RTC_JITTER_CONSTANT = 0, RTC_JITTER_HASHED = 2 };
 
-/* material.rs:18-51 (pattern: out of scope) */
+/* A boxed Pattern (pattern/pattern.rs:8-26) flattened: the two colours every pattern is built from and
+ * BasePattern.t_inverse (pattern.rs:33,52-54).  Gradient and Sine2D keep `distance = b - a`
+ * (gradient.rs:17, sine_2d.rs:17); the library forms it from a and b with the same single subtraction.
+ * Build with rtc_pattern_init().  (uv.rs texture maps are not on this path.) */
+typedef struct rtc_pattern {
+    int32_t kind; /* RTC_PATTERN_* */
+    float a[3];
+    float b[3];
+    float inv[16];
+} rtc_pattern;
+
+/* material.rs:18-51 */
 typedef struct rtc_material {
     float color[3];
     float ambient;
@@ -62,6 +77,7 @@ typedef struct rtc_material {
     float reflective;
     float transparency;
     float refractive_index;
+    rtc_pattern pattern; /* kind RTC_PATTERN_NONE: use `color` (phong_lighting.rs:24-27) */
 } rtc_material;
 
 /* One entry of World.objects (world.rs:19), flattened.  `inv` is exactly
@@ -71,9 +87,9 @@ typedef struct rtc_material {
 typedef struct rtc_object {
     int32_t kind;         /* RTC_SPHERE ... */
     int32_t casts_shadow; /* BaseShape.casts_shadow, base_shape.rs:14 */
-    int32_t closed;       /* Cylinder.closed,  cylinder.rs:18 */
-    float min_y;          /* Cylinder.minimum_y (ignored for other kinds) */
-    float max_y;          /* Cylinder.maximum_y */
+    int32_t closed;       /* Cylinder.closed / Cone.closed, cylinder.rs:18, cone.rs:16 */
+    float min_y;          /* Cylinder/Cone.minimum_y (ignored for other kinds) */
+    float max_y;          /* Cylinder/Cone.maximum_y */
     float inv[16];
     rtc_material material;
 } rtc_object;
@@ -161,10 +177,14 @@ float rtc_dot(const float a[4], const float b[4]);                              
 void rtc_cross(const float a[4], const float b[4], float out[4]);               /* tuple.rs:47-55 */
 void rtc_reflect(const float in[4], const float normal[4], float out[4]);       /* ray.rs:42-44   */
 
-/* Material::default(), material.rs:53-57 */
+/* Material::default(), material.rs:53-57 (no pattern) */
 void rtc_material_default(rtc_material* out);
+/* Stripes/Gradient/Rings/Checkers/Sine2D::new(a, b) followed by set_transformation(transform):
+ * stores transform.inverse() (pattern.rs:52-54).  transform NULL = identity. */
+rtc_status rtc_pattern_init(rtc_pattern* out, int32_t kind, const float a[3], const float b[3],
+                            const float transform[16]);
 /* Shape::build(transform, material): stores transform.inverse() (base_shape.rs:56-60).
- * Cylinder bounds default to -inf/+inf, open (cylinder.rs:34-43). */
+ * Cylinder / Cone bounds default to -inf/+inf, open (cylinder.rs:34-43, cone.rs:33-42). */
 rtc_status rtc_object_init(rtc_object* out, int32_t kind, const float transform[16], const rtc_material* m);
 void rtc_point_light(const float position[4], const float intensity[3], rtc_light* out);   /* point_light.rs:12-19 */
 rtc_status rtc_rectangle_light(const float intensity[3], const float corner[4], const float u_vec[4],
@@ -228,9 +248,23 @@ rtc_status rtc_intensity_at(const rtc_scene* scene, const float* points, uint32_
 /* Batched World::is_shadowed (world.rs:104-119): light_positions, points n*4 f32; out n int32 (0/1). */
 rtc_status rtc_is_shadowed(const rtc_scene* scene, const float* light_positions, const float* points, uint32_t n,
                            int32_t device, int32_t* out);
-/* f32::powf as the reference's Linux build computes it (phong_lighting.rs:56),
- * evaluated on the device; host buffers of n f32. */
+/* Batched Shape::local_intersect (shape.rs:50, e.g. cone.rs:52-57) on the device: n object-space rays
+ * (n*4 f32 each) against `object`'s kind/bounds; out_t receives up to 4 distances per ray in push
+ * order (n*4 f32), out_count the number pushed (n int32). */
+rtc_status rtc_local_intersect(const rtc_object* object, const float* origins, const float* directions, uint32_t n,
+                               int32_t device, float* out_t, int32_t* out_count);
+/* Batched Shape::normal_at (shape.rs:72-154: object space, local_norm_at, back to world, normalise)
+ * for n world points (n*4 f32); out n*4 f32 vectors. */
+rtc_status rtc_normal_at(const rtc_object* object, const float* world_points, uint32_t n, int32_t device,
+                         float* out);
+/* Batched Pattern::color_at_object (pattern.rs:15-19) for n world points (n*4 f32) on `object`
+ * (NULL: an untransformed shape); out n*3 f32. */
+rtc_status rtc_pattern_color_at(const rtc_pattern* pattern, const rtc_object* object, const float* world_points,
+                                uint32_t n, int32_t device, float* out_rgb);
+/* f32::powf / f32::cos as the reference's Linux build computes them (phong_lighting.rs:56,
+ * pattern/sine_2d.rs:40), evaluated on the device; host buffers of n f32. */
 rtc_status rtc_powf(const float* x, const float* y, uint32_t n, int32_t device, float* out);
+rtc_status rtc_cosf(const float* x, uint32_t n, int32_t device, float* out);
 
 /* Canvas::to_ppm (canvas.rs:58-96) on an f32 image already on the host:
  * returns a malloc'd buffer (free with rtc_free) holding the P3 text. */

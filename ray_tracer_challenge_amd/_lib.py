@@ -14,7 +14,9 @@ LIB_PATH = os.environ.get("RTC_AMD_LIB") or os.path.join(HERE, "librtc_amd.so")
 
 RTC_OK = 0
 RTC_ERR_INVALID_ARG, RTC_ERR_UNSUPPORTED, RTC_ERR_NO_LIGHT, RTC_ERR_DEVICE, RTC_ERR_NO_DEVICE = -1, -2, -3, -4, -5
-RTC_SPHERE, RTC_PLANE, RTC_CUBE, RTC_CYLINDER = 0, 1, 2, 3
+RTC_SPHERE, RTC_PLANE, RTC_CUBE, RTC_CYLINDER, RTC_CONE = 0, 1, 2, 3, 4
+(RTC_PATTERN_NONE, RTC_PATTERN_STRIPES, RTC_PATTERN_GRADIENT, RTC_PATTERN_RINGS, RTC_PATTERN_CHECKERS,
+ RTC_PATTERN_SINE2D) = 0, 1, 2, 3, 4, 5
 RTC_LIGHT_POINT, RTC_LIGHT_RECT = 0, 1
 RTC_JITTER_CONSTANT, RTC_JITTER_HASHED = 0, 2
 RTC_MAX_DEPTH = 8
@@ -22,10 +24,14 @@ RTC_MAX_DEPTH = 8
 FP = C.POINTER(C.c_float)
 
 
+class rtc_pattern(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("a", C.c_float * 3), ("b", C.c_float * 3), ("inv", C.c_float * 16)]
+
+
 class rtc_material(C.Structure):
     _fields_ = [("color", C.c_float * 3), ("ambient", C.c_float), ("diffuse", C.c_float),
                 ("specular", C.c_float), ("shininess", C.c_float), ("reflective", C.c_float),
-                ("transparency", C.c_float), ("refractive_index", C.c_float)]
+                ("transparency", C.c_float), ("refractive_index", C.c_float), ("pattern", rtc_pattern)]
 
 
 class rtc_object(C.Structure):
@@ -84,6 +90,7 @@ SIGNATURES = {
     "rtc_cross": (None, [FP, FP, FP]),
     "rtc_reflect": (None, [FP, FP, FP]),
     "rtc_material_default": (None, [C.POINTER(rtc_material)]),
+    "rtc_pattern_init": (C.c_int, [C.POINTER(rtc_pattern), C.c_int32, FP, FP, FP]),
     "rtc_object_init": (C.c_int, [C.POINTER(rtc_object), C.c_int32, FP, C.POINTER(rtc_material)]),
     "rtc_point_light": (None, [FP, FP, C.POINTER(rtc_light)]),
     "rtc_rectangle_light": (C.c_int, [FP, FP, FP, C.c_int32, FP, C.c_int32, C.c_int32, C.c_float, C.c_uint32,
@@ -106,7 +113,11 @@ SIGNATURES = {
     "rtc_color_at": (C.c_int, [C.POINTER(rtc_scene), FP, FP, C.c_uint32, C.c_int32, C.c_int32, FP]),
     "rtc_intensity_at": (C.c_int, [C.POINTER(rtc_scene), FP, C.c_uint32, C.c_int32, FP]),
     "rtc_is_shadowed": (C.c_int, [C.POINTER(rtc_scene), FP, FP, C.c_uint32, C.c_int32, C.POINTER(C.c_int32)]),
+    "rtc_local_intersect": (C.c_int, [C.POINTER(rtc_object), FP, FP, C.c_uint32, C.c_int32, FP, C.POINTER(C.c_int32)]),
+    "rtc_normal_at": (C.c_int, [C.POINTER(rtc_object), FP, C.c_uint32, C.c_int32, FP]),
+    "rtc_pattern_color_at": (C.c_int, [C.POINTER(rtc_pattern), C.POINTER(rtc_object), FP, C.c_uint32, C.c_int32, FP]),
     "rtc_powf": (C.c_int, [FP, FP, C.c_uint32, C.c_int32, FP]),
+    "rtc_cosf": (C.c_int, [FP, C.c_uint32, C.c_int32, FP]),
     "rtc_to_ppm": (C.c_int, [FP, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "rtc_free": (None, [C.c_void_p]),
     "rtc_last_error": (C.c_char_p, []),
@@ -115,6 +126,7 @@ SIGNATURES = {
 }
 # diagnostic export, not in rtc.h: host compile of the device powf restatement
 EXTRA = {"rtc_powf_host": (None, [FP, FP, C.c_uint32, FP]),
+         "rtc_cosf_host": (None, [FP, C.c_uint32, FP]),
          # device self-test of the range-checked exact sqrt/divide cores against sqrtf and '/'
          "rtc_selftest_fastmath": (C.c_int, [FP, C.c_uint32, C.c_int32, C.POINTER(C.c_uint32)])}
 

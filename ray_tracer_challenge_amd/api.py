@@ -175,6 +175,69 @@ def inverse(a):
     return out.reshape(n, n)
 
 
+# ------------------------------------------------------------------- pattern/*.rs
+class Pattern:
+    """A procedural pattern: two colours and a pattern->object transform (pattern/pattern.rs:8-26).
+    color_at_world / color_at_object evaluate on the device."""
+
+    def __init__(self, kind, a=(1.0, 1.0, 1.0), b=(0.0, 0.0, 0.0), transform=None):
+        self.kind = kind
+        self.a, self.b = tuple(float(c) for c in a), tuple(float(c) for c in b)
+        self.transform = identity_4x4() if transform is None else np.asarray(transform, dtype=f32).reshape(4, 4)
+
+    def set_transformation(self, t):
+        """pattern.rs:20-22; the inverse is taken when the pattern is flattened."""
+        self.transform = np.asarray(t, dtype=f32).reshape(4, 4)
+
+    def transformation_inverse(self):
+        return np.array(list(self._c().inv), dtype=f32).reshape(4, 4)
+
+    def _c(self):
+        p = L.rtc_pattern()
+        a, b, t = _a(self.a, 3), _a(self.b, 3), _a(self.transform, 16)
+        L.check(L.lib().rtc_pattern_init(C.byref(p), self.kind, _p(a), _p(b), _p(t)))
+        return p
+
+    def color_at_object(self, world_points, shape=None, device=0):
+        """Pattern::color_at_object (pattern.rs:15-19), batched: (n, 4) world points -> (n, 3)."""
+        pts = np.ascontiguousarray(np.asarray(world_points, dtype=f32).reshape(-1, 4))
+        out = np.zeros((pts.shape[0], 3), dtype=f32)
+        p = self._c()
+        o = shape._c() if shape is not None else None
+        L.check(L.lib().rtc_pattern_color_at(C.byref(p), C.byref(o) if o is not None else None, _p(pts), pts.shape[0],
+                                             device, _p(out)))
+        return out
+
+    def color_at_world(self, points, device=0):
+        """Pattern::color_at_world: the pattern-space lookup itself (identity object and pattern transforms)."""
+        return Pattern(self.kind, self.a, self.b).color_at_object(points, None, device)
+
+
+def Stripes(a=(1.0, 1.0, 1.0), b=(0.0, 0.0, 0.0), transform=None):
+    """Stripes::new(a, b) -- pattern/stripes.rs:17-24 (default: white, black)"""
+    return Pattern(L.RTC_PATTERN_STRIPES, a, b, transform)
+
+
+def Gradient(a=(1.0, 1.0, 1.0), b=(0.0, 0.0, 0.0), transform=None):
+    """Gradient::new -- pattern/gradient.rs:16-23"""
+    return Pattern(L.RTC_PATTERN_GRADIENT, a, b, transform)
+
+
+def Rings(a=(1.0, 1.0, 1.0), b=(0.0, 0.0, 0.0), transform=None):
+    """Rings::new -- pattern/rings.rs:16-22"""
+    return Pattern(L.RTC_PATTERN_RINGS, a, b, transform)
+
+
+def Checkers(a=(1.0, 1.0, 1.0), b=(0.0, 0.0, 0.0), transform=None):
+    """Checkers::new -- pattern/checkers.rs:16-22"""
+    return Pattern(L.RTC_PATTERN_CHECKERS, a, b, transform)
+
+
+def Sine2D(a=(1.0, 1.0, 1.0), b=(0.0, 0.0, 0.0), transform=None):
+    """Sine2D::new -- pattern/sine_2d.rs:16-23"""
+    return Pattern(L.RTC_PATTERN_SINE2D, a, b, transform)
+
+
 # ------------------------------------------------------------------ material.rs
 class Material:
     """Material::builder() with the reference's defaults (material.rs:18-51)."""
@@ -182,22 +245,26 @@ class Material:
     FIELDS = ("ambient", "diffuse", "specular", "shininess", "reflective", "transparency", "refractive_index")
 
     def __init__(self, color=(1.0, 1.0, 1.0), ambient=0.1, diffuse=0.9, specular=0.9, shininess=200.0,
-                 reflective=0.0, transparency=0.0, refractive_index=1.0):
+                 reflective=0.0, transparency=0.0, refractive_index=1.0, pattern=None):
         self.color = tuple(float(c) for c in color)
         self.ambient, self.diffuse, self.specular, self.shininess = ambient, diffuse, specular, shininess
         self.reflective, self.transparency, self.refractive_index = reflective, transparency, refractive_index
+        self.pattern = pattern
 
     def copy(self, **changes):
-        m = Material(self.color, *[getattr(self, k) for k in self.FIELDS])
+        m = Material(self.color, *[getattr(self, k) for k in self.FIELDS], pattern=self.pattern)
         for k, v in changes.items():
             setattr(m, k, v)
         return m
 
     def _c(self):
         m = L.rtc_material()
+        L.lib().rtc_material_default(C.byref(m))
         m.color[:] = [float(f32(c)) for c in self.color]
         for k in self.FIELDS:
             setattr(m, k, float(f32(getattr(self, k))))
+        if self.pattern is not None:
+            m.pattern = self.pattern._c()
         return m
 
 
@@ -247,6 +314,27 @@ class Shape:
         o.max_y = float(f32(self.maximum_y))
         return o
 
+    def local_intersect(self, origins, directions, device=0):
+        """Shape::local_intersect, batched on the device: (n, 4) object-space rays -> list of per-ray distance
+        lists in the reference's push order."""
+        o = np.ascontiguousarray(np.asarray(origins, dtype=f32).reshape(-1, 4))
+        d = np.ascontiguousarray(np.asarray(directions, dtype=f32).reshape(-1, 4))
+        assert o.shape == d.shape
+        ts = np.zeros((o.shape[0], 4), dtype=f32)
+        counts = np.zeros(o.shape[0], dtype=np.int32)
+        c = self._c()
+        L.check(L.lib().rtc_local_intersect(C.byref(c), _p(o), _p(d), o.shape[0], device, _p(ts),
+                                            counts.ctypes.data_as(C.POINTER(C.c_int32))))
+        return [list(ts[i, :counts[i]]) for i in range(o.shape[0])]
+
+    def normal_at(self, world_points, device=0):
+        """Shape::normal_at (shape.rs:72-154), batched on the device: (n, 4) points -> (n, 4) vectors."""
+        p = np.ascontiguousarray(np.asarray(world_points, dtype=f32).reshape(-1, 4))
+        out = np.zeros_like(p)
+        c = self._c()
+        L.check(L.lib().rtc_normal_at(C.byref(c), _p(p), p.shape[0], device, _p(out)))
+        return out
+
 
 def Sphere(transform=None, material=None, **kw):
     """Sphere::build(transform, material) -- shape/sphere.rs:23-28"""
@@ -266,6 +354,11 @@ def Cube(transform=None, material=None, **kw):
 def Cylinder(transform=None, material=None, **kw):
     """Cylinder::build; minimum_y / maximum_y / closed are its pub fields (shape/cylinder.rs:14-19)"""
     return Shape(L.RTC_CYLINDER, transform, material, **kw)
+
+
+def Cone(transform=None, material=None, **kw):
+    """Cone::build; minimum_y / maximum_y / closed are its pub fields (shape/cone.rs:12-17)"""
+    return Shape(L.RTC_CONE, transform, material, **kw)
 
 
 # ------------------------------------------------------------------- light/*.rs
@@ -468,6 +561,22 @@ def powf(x, y, device=0):
     a, b = _a(x), _a(y)
     out = np.zeros(a.size, dtype=f32)
     L.check(L.lib().rtc_powf(_p(a), _p(b), a.size, device, _p(out)))
+    return out
+
+
+def cosf(x, device=0):
+    """f32::cos on the device (pattern/sine_2d.rs:40)."""
+    a = _a(x)
+    out = np.zeros(a.size, dtype=f32)
+    L.check(L.lib().rtc_cosf(_p(a), a.size, device, _p(out)))
+    return out
+
+
+def cosf_host(x):
+    """Host compile of the device cosf restatement (diagnostic only)."""
+    a = _a(x)
+    out = np.zeros(a.size, dtype=f32)
+    L.lib().rtc_cosf_host(_p(a), a.size, _p(out))
     return out
 
 

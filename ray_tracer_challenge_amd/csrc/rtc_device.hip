@@ -47,6 +47,8 @@ static const uint64_t h_exp2f_tab[32] = {
     0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
     0x3fefa4afa2a490da, 0x3fefd0765b6e4540,
 };
+static const SinCosTab h_sincosf_tab[2] = RTC_SINCOSF_TAB_INIT;
+static const uint32_t h_inv_pio4[24] = RTC_INV_PIO4_INIT;
 
 // ============================================================================
 //  Host side of the device path
@@ -64,6 +66,14 @@ static int usable_devices() {
     return n;
 }
 
+static rtc_status select_device(int32_t device) {
+    int nd = usable_devices();
+    if (nd <= 0) return fail(RTC_ERR_NO_DEVICE, "no HIP device visible; librtc_amd has no CPU fallback");
+    if (device < 0 || device >= nd) return fail(RTC_ERR_INVALID_ARG, "device %d out of range (have %d)", device, nd);
+    HIP_TRY(hipSetDevice(device));
+    return RTC_OK;
+}
+
 static uint32_t padded_count(uint32_t n) { return n ? (n + 7u) & ~7u : 8u; }
 
 static rtc_status check_tuple(const float v[4], float w, const char* what) {
@@ -71,8 +81,35 @@ static rtc_status check_tuple(const float v[4], float w, const char* what) {
     return RTC_OK;
 }
 
+// The four geometry records of one object (see SceneSoA).
+static void pack_geometry(const rtc_object& o, float4 g[4]) {
+    uint32_t bits = (uint32_t)o.kind | (o.casts_shadow ? SHAPE_CASTS : 0u) | (o.closed ? SHAPE_CLOSED : 0u);
+    if (o.inv[1] == 0.0f && o.inv[2] == 0.0f && o.inv[4] == 0.0f && o.inv[6] == 0.0f && o.inv[8] == 0.0f &&
+        o.inv[9] == 0.0f)
+        bits |= SHAPE_DIAG;
+    float bits_f;
+    std::memcpy(&bits_f, &bits, 4);
+    g[0] = make_float4(o.inv[0], o.inv[5], o.inv[10], bits_f);
+    g[1] = make_float4(o.inv[1], o.inv[2], o.inv[3], o.min_y);
+    g[2] = make_float4(o.inv[4], o.inv[6], o.inv[7], o.max_y);
+    g[3] = make_float4(o.inv[8], o.inv[9], o.inv[11], 0.0f);
+}
+// The five pattern records of one material (see SceneSoA::pat).
+static void pack_pattern(const rtc_pattern& pt, float4 rec[5]) {
+    uint32_t kind = (uint32_t)pt.kind;
+    float kind_f;
+    std::memcpy(&kind_f, &kind, 4);
+    rec[0] = make_float4(pt.a[0], pt.a[1], pt.a[2], kind_f);
+    // Gradient::new / Sine2D::new keep distance = b - a (gradient.rs:17, sine_2d.rs:17)
+    const bool dist = pt.kind == RTC_PATTERN_GRADIENT || pt.kind == RTC_PATTERN_SINE2D;
+    rec[1] = dist ? make_float4(pt.b[0] - pt.a[0], pt.b[1] - pt.a[1], pt.b[2] - pt.a[2], 0.0f)
+                  : make_float4(pt.b[0], pt.b[1], pt.b[2], 0.0f);
+    for (int r = 0; r < 3; r++)
+        rec[2 + r] = make_float4(pt.inv[4 * r], pt.inv[4 * r + 1], pt.inv[4 * r + 2], pt.inv[4 * r + 3]);
+}
+
 // Validates and flattens rtc_scene + rtc_camera into the kernel's header and
-// SoA records (host staging buffer, 7 float4 arrays of n entries each).
+// SoA records (host staging buffer: 7 float4 arrays of np entries each, then 5 pattern records per object).
 static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHdr* hdr, std::vector<float4>* soa) {
     if (!scene) return fail(RTC_ERR_INVALID_ARG, "scene is NULL");
     if (!scene->light) return fail(RTC_ERR_NO_LIGHT, "World light should be set");  // world.rs:66
@@ -81,7 +118,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     const uint32_t n = scene->n_objects;
     hdr->n_objects = n;
     const uint32_t np = padded_count(n);  // stride of each SoA array
-    soa->assign((size_t)7 * np, make_float4(0, 0, 0, 0));
+    soa->assign((size_t)12 * np, make_float4(0, 0, 0, 0));
     {
         uint32_t none = SHAPE_NONE;
         float none_f;
@@ -90,26 +127,28 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     }
     for (uint32_t i = 0; i < n; i++) {
         const rtc_object& o = scene->objects[i];
-        if (o.kind < RTC_SPHERE || o.kind > RTC_CYLINDER)
+        if (o.kind < RTC_SPHERE || o.kind > RTC_CONE)
             return fail(RTC_ERR_UNSUPPORTED, "object %u: shape kind %d is not on the device path", i, o.kind);
         if (!is_affine(o.inv))
             return fail(RTC_ERR_UNSUPPORTED,
                         "object %u: inverse transform's last row is not exactly [0,0,0,1] (projective transforms "
                         "are not supported)", i);
-        uint32_t bits = (uint32_t)o.kind | (o.casts_shadow ? SHAPE_CASTS : 0u) | (o.closed ? SHAPE_CLOSED : 0u);
-        if (o.inv[1] == 0.0f && o.inv[2] == 0.0f && o.inv[4] == 0.0f && o.inv[6] == 0.0f && o.inv[8] == 0.0f &&
-            o.inv[9] == 0.0f)
-            bits |= SHAPE_DIAG;
-        float bits_f;
-        std::memcpy(&bits_f, &bits, 4);
-        (*soa)[0 * np + i] = make_float4(o.inv[0], o.inv[5], o.inv[10], bits_f);
-        (*soa)[1 * np + i] = make_float4(o.inv[1], o.inv[2], o.inv[3], o.min_y);
-        (*soa)[2 * np + i] = make_float4(o.inv[4], o.inv[6], o.inv[7], o.max_y);
-        (*soa)[3 * np + i] = make_float4(o.inv[8], o.inv[9], o.inv[11], 0.0f);
+        float4 g[4];
+        pack_geometry(o, g);
+        for (int k = 0; k < 4; k++) (*soa)[(size_t)k * np + i] = g[k];
         const rtc_material& m = o.material;
         (*soa)[4 * np + i] = make_float4(m.color[0], m.color[1], m.color[2], m.ambient);
         (*soa)[5 * np + i] = make_float4(m.diffuse, m.specular, m.shininess, m.reflective);
         (*soa)[6 * np + i] = make_float4(m.transparency, m.refractive_index, 0.0f, 0.0f);
+        const rtc_pattern& pt = m.pattern;
+        if (pt.kind != RTC_PATTERN_NONE) {
+            if (pt.kind < RTC_PATTERN_STRIPES || pt.kind > RTC_PATTERN_SINE2D)
+                return fail(RTC_ERR_UNSUPPORTED, "object %u: pattern kind %d is not on the device path", i, pt.kind);
+            if (!is_affine(pt.inv))
+                return fail(RTC_ERR_UNSUPPORTED, "object %u: pattern inverse transform is not affine", i);
+            hdr->has_patterns = 1;
+            pack_pattern(pt, &(*soa)[7 * (size_t)np + 5 * (size_t)i]);
+        }
     }
     const rtc_light& l = *scene->light;
     hdr->light_kind = l.kind;
@@ -170,7 +209,7 @@ struct rtc_ctx {
     float4* d_soa = nullptr;
     size_t soa_cap = 0;  // float4 entries
     uint32_t n_objects = 0;
-    bool simple = false;  // every object scale+translate-only and no cylinder
+    bool simple = false;  // every object scale+translate-only, no cylinder / cone, no patterns
     // workspace of rtc_ctx_to_ppm (grow-only)
     unsigned long long* d_ppm_rows = nullptr;  // per-row length, then offset; [h] is the total
     uint32_t* d_ppm_bits = nullptr;
@@ -326,6 +365,7 @@ static SceneSoA soa_view(const float4* base, uint32_t n) {
     s.mat_a = base + 4 * (size_t)m;
     s.mat_b = base + 5 * (size_t)m;
     s.mat_c = base + 6 * (size_t)m;
+    s.pat = base + 7 * (size_t)m;
     return s;
 }
 
@@ -378,11 +418,12 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     HIP_TRY(hipMemcpy(c->d_soa, soa.data(), soa.size() * sizeof(float4), hipMemcpyHostToDevice));
     c->hdr = hdr;
     c->n_objects = hdr.n_objects;
-    c->simple = true;
+    c->simple = !hdr.has_patterns;
     for (uint32_t i = 0; i < hdr.n_objects; i++) {
         uint32_t bits;
         std::memcpy(&bits, &soa[i].w, 4);  // geo[i].w
-        if (!(bits & SHAPE_DIAG) || (bits & SHAPE_KIND_MASK) == RTC_CYLINDER) c->simple = false;
+        const uint32_t kind = bits & SHAPE_KIND_MASK;
+        if (!(bits & SHAPE_DIAG) || kind == RTC_CYLINDER || kind == RTC_CONE) c->simple = false;
     }
     c->has_scene = true;
     // which kernel will render this scene
@@ -408,12 +449,13 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         defs.push_back(std::string("-DRTC_SPEC_SIMPLE=") + (c->simple ? "1" : "0"));
         defs.push_back("-DRTC_SPEC_LIGHT_KIND=" + std::to_string(hdr.light_kind));
         defs.push_back("-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode));
+        defs.push_back(std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0"));
         rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
         if (jst != RTC_OK) {
             if (policy == 1) return jst;  // explicitly requested: report
             c->spec_fn = nullptr;         // auto: the ahead-of-time kernel computes the same image
         } else {
-            c->kernel_name = "render_kernel_spec[" + list.substr(16) + (c->simple ? ";simple" : "") + "]";
+            c->kernel_name = "render_kernel_spec[" + list.substr(16) + (c->simple ? ";simple" : "") + (hdr.has_patterns ? ";patterns" : "") + "]";
         }
     }
     return RTC_OK;
@@ -720,11 +762,124 @@ rtc_status rtc_powf(const float* x, const float* y, uint32_t n, int32_t device, 
     return RTC_OK;
 }
 
+rtc_status rtc_cosf(const float* x, uint32_t n, int32_t device, float* out) {
+    if (!x || !out) return fail(RTC_ERR_INVALID_ARG, "rtc_cosf: null argument");
+    if (n == 0) return RTC_OK;
+    rtc_status st = select_device(device);
+    if (st != RTC_OK) return st;
+    DevBuf d_x, d_out;
+    HIP_TRY(d_x.alloc((size_t)n * 4));
+    HIP_TRY(d_out.alloc((size_t)n * 4));
+    HIP_TRY(hipMemcpy(d_x.p, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(cosf_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, (const float*)d_x.p, n, (float*)d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
+// One object's geometry as a kernel argument for the batched shape / pattern entry points.
+static rtc_status object_arg(const rtc_object* object, const char* who, Obj* ob) {
+    rtc_object unit;
+    if (!object) {  // an untransformed unit sphere
+        std::memset(&unit, 0, sizeof(unit));
+        unit.kind = RTC_SPHERE;
+        unit.casts_shadow = 1;
+        unit.min_y = -INFINITY;
+        unit.max_y = INFINITY;
+        for (int i = 0; i < 4; i++) unit.inv[i * 5] = 1.0f;
+        object = &unit;
+    }
+    if (object->kind < RTC_SPHERE || object->kind > RTC_CONE)
+        return fail(RTC_ERR_UNSUPPORTED, "%s: shape kind %d is not on the device path", who, object->kind);
+    if (!is_affine(object->inv)) return fail(RTC_ERR_UNSUPPORTED, "%s: inverse transform is not affine", who);
+    float4 g[4];
+    pack_geometry(*object, g);
+    ob->geo = g[0];
+    ob->off0 = g[1];
+    ob->off1 = g[2];
+    ob->off2 = g[3];
+    std::memcpy(&ob->bits, &g[0].w, 4);
+    return RTC_OK;
+}
+
+rtc_status rtc_local_intersect(const rtc_object* object, const float* origins, const float* directions, uint32_t n,
+                               int32_t device, float* out_t, int32_t* out_count) {
+    if (!object || !origins || !directions || !out_t || !out_count)
+        return fail(RTC_ERR_INVALID_ARG, "rtc_local_intersect: null argument");
+    Obj ob;
+    rtc_status st = object_arg(object, "rtc_local_intersect", &ob);
+    if (st != RTC_OK) return st;
+    if ((st = select_device(device)) != RTC_OK) return st;
+    if (n == 0) return RTC_OK;
+    DevBuf d_o, d_d, d_t, d_c;
+    HIP_TRY(d_o.alloc((size_t)n * 16));
+    HIP_TRY(d_d.alloc((size_t)n * 16));
+    HIP_TRY(d_t.alloc((size_t)n * 16));
+    HIP_TRY(d_c.alloc((size_t)n * 4));
+    HIP_TRY(hipMemcpy(d_o.p, origins, (size_t)n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d.p, directions, (size_t)n * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(local_intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, ob, (const float4*)d_o.p,
+                       (const float4*)d_d.p, n, (float4*)d_t.p, (int32_t*)d_c.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out_t, d_t.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_count, d_c.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
+rtc_status rtc_normal_at(const rtc_object* object, const float* world_points, uint32_t n, int32_t device, float* out) {
+    if (!object || !world_points || !out) return fail(RTC_ERR_INVALID_ARG, "rtc_normal_at: null argument");
+    Obj ob;
+    rtc_status st = object_arg(object, "rtc_normal_at", &ob);
+    if (st != RTC_OK) return st;
+    if ((st = select_device(device)) != RTC_OK) return st;
+    if (n == 0) return RTC_OK;
+    DevBuf d_p, d_out;
+    HIP_TRY(d_p.alloc((size_t)n * 16));
+    HIP_TRY(d_out.alloc((size_t)n * 16));
+    HIP_TRY(hipMemcpy(d_p.p, world_points, (size_t)n * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(normal_at_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, ob, (const float4*)d_p.p, n,
+                       (float4*)d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
+rtc_status rtc_pattern_color_at(const rtc_pattern* pattern, const rtc_object* object, const float* world_points,
+                                uint32_t n, int32_t device, float* out_rgb) {
+    if (!pattern || !world_points || !out_rgb) return fail(RTC_ERR_INVALID_ARG, "rtc_pattern_color_at: null argument");
+    if (pattern->kind < RTC_PATTERN_STRIPES || pattern->kind > RTC_PATTERN_SINE2D)
+        return fail(RTC_ERR_UNSUPPORTED, "rtc_pattern_color_at: pattern kind %d is not on the device path", pattern->kind);
+    if (!is_affine(pattern->inv)) return fail(RTC_ERR_UNSUPPORTED, "rtc_pattern_color_at: pattern inverse transform is not affine");
+    Obj ob;
+    rtc_status st = object_arg(object, "rtc_pattern_color_at", &ob);
+    if (st != RTC_OK) return st;
+    if ((st = select_device(device)) != RTC_OK) return st;
+    if (n == 0) return RTC_OK;
+    float4 rec[5];
+    pack_pattern(*pattern, rec);
+    DevBuf d_pat, d_p, d_out;
+    HIP_TRY(d_pat.alloc(sizeof(rec)));
+    HIP_TRY(d_p.alloc((size_t)n * 16));
+    HIP_TRY(d_out.alloc((size_t)n * 12));
+    HIP_TRY(hipMemcpy(d_pat.p, rec, sizeof(rec), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_p.p, world_points, (size_t)n * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pattern_color_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, ob, (const float4*)d_pat.p,
+                       (const float4*)d_p.p, n, (float*)d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out_rgb, d_out.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
 // Host compile of the same powf restatement (diagnostic: lets the CPU test
 // suite pin the algorithm against the C library without a GPU).  Not used by
 // any render path.
 void rtc_powf_host(const float* x, const float* y, uint32_t n, float* out) {
     for (uint32_t i = 0; i < n; i++) out[i] = powf_glibc(x[i], y[i], h_pow_log2_tab, h_exp2f_tab);
+}
+
+// Same for the cosf restatement (pattern/sine_2d.rs:40).
+void rtc_cosf_host(const float* x, uint32_t n, float* out) {
+    for (uint32_t i = 0; i < n; i++) out[i] = cosf_glibc(x[i], h_sincosf_tab, h_inv_pio4);
 }
 
 // Diagnostic (not in rtc.h): runs fastmath_selftest_kernel on n host vectors (n*3 f32);

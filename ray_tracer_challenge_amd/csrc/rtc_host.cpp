@@ -212,11 +212,31 @@ void rtc_material_default(rtc_material* m) {  // material.rs:20-47
     m->reflective = 0.0f;
     m->transparency = 0.0f;
     m->refractive_index = 1.0f;
+    std::memset(&m->pattern, 0, sizeof(m->pattern));  // pattern: None
+    m->pattern.kind = RTC_PATTERN_NONE;
+    for (int i = 0; i < 4; i++) m->pattern.inv[i * 5] = 1.0f;
+}
+
+rtc_status rtc_pattern_init(rtc_pattern* out, int32_t kind, const float a[3], const float b[3],
+                            const float transform[16]) {
+    if (!out || !a || !b) return fail(RTC_ERR_INVALID_ARG, "rtc_pattern_init: null argument");
+    if (kind < RTC_PATTERN_STRIPES || kind > RTC_PATTERN_SINE2D)
+        return fail(RTC_ERR_UNSUPPORTED, "rtc_pattern_init: unknown pattern kind %d", kind);
+    out->kind = kind;
+    std::memcpy(out->a, a, sizeof(float) * 3);
+    std::memcpy(out->b, b, sizeof(float) * 3);
+    if (transform) {
+        inverse4(transform, out->inv);  // pattern.rs:52-54
+    } else {  // BasePattern::default(): the identity (pattern.rs:31-34)
+        std::memset(out->inv, 0, sizeof(out->inv));
+        for (int i = 0; i < 4; i++) out->inv[i * 5] = 1.0f;
+    }
+    return RTC_OK;
 }
 
 rtc_status rtc_object_init(rtc_object* out, int32_t kind, const float transform[16], const rtc_material* m) {
     if (!out || !transform) return fail(RTC_ERR_INVALID_ARG, "rtc_object_init: null argument");
-    if (kind < RTC_SPHERE || kind > RTC_CYLINDER) return fail(RTC_ERR_UNSUPPORTED, "rtc_object_init: unknown shape kind %d", kind);
+    if (kind < RTC_SPHERE || kind > RTC_CONE) return fail(RTC_ERR_UNSUPPORTED, "rtc_object_init: unknown shape kind %d", kind);
     out->kind = kind;
     out->casts_shadow = 1;  // base_shape.rs:31
     out->closed = 0;        // cylinder.rs:41

@@ -38,7 +38,9 @@ typedef unsigned long size_t;
 // rtc.h needs <stddef.h>/<stdint.h>, which hiprtc does not ship: restate the few constants the device
 // code uses (the ahead-of-time build below static_asserts that they agree with rtc.h).
 #define RTC_MAX_DEPTH 8
-enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3 };
+enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3, RTC_CONE = 4 };
+enum { RTC_PATTERN_NONE = 0, RTC_PATTERN_STRIPES = 1, RTC_PATTERN_GRADIENT = 2, RTC_PATTERN_RINGS = 3,
+       RTC_PATTERN_CHECKERS = 4, RTC_PATTERN_SINE2D = 5 };
 enum { RTC_LIGHT_POINT = 0, RTC_LIGHT_RECT = 1 };
 enum { RTC_JITTER_CONSTANT = 0, RTC_JITTER_HASHED = 2 };
 #else
@@ -49,7 +51,8 @@ enum { RTC_JITTER_CONSTANT = 0, RTC_JITTER_HASHED = 2 };
 #include "rtc.h"
 #define RTC_HOSTDEV __host__ __device__
 static_assert(RTC_MAX_DEPTH == 8 && RTC_SPHERE == 0 && RTC_PLANE == 1 && RTC_CUBE == 2 && RTC_CYLINDER == 3 &&
-                  RTC_LIGHT_POINT == 0 && RTC_LIGHT_RECT == 1 && RTC_JITTER_CONSTANT == 0 && RTC_JITTER_HASHED == 2,
+                  RTC_CONE == 4 && RTC_PATTERN_NONE == 0 && RTC_PATTERN_STRIPES == 1 && RTC_PATTERN_GRADIENT == 2 &&
+                  RTC_PATTERN_RINGS == 3 && RTC_PATTERN_CHECKERS == 4 && RTC_PATTERN_SINE2D == 5 && RTC_LIGHT_POINT == 0 && RTC_LIGHT_RECT == 1 && RTC_JITTER_CONSTANT == 0 && RTC_JITTER_HASHED == 2,
               "rtc_kernel_core.h restates these rtc.h constants for the hiprtc build");
 #endif
 
@@ -205,6 +208,89 @@ HDI float powf_glibc(float x, float y, const PowLog2Entry* __restrict__ T, const
 DI float rtc_powf_dev(float x, float y) { return powf_glibc(x, y, d_pow_log2_tab, d_exp2f_tab); }
 
 // ============================================================================
+//  cosf: glibc 2.35 sysdeps/ieee754/flt-32/s_cosf.c + s_sincosf.h (same origin
+//  as powf above), FMA variant (__cosf_fma) -- what f32::cos (pattern/sine_2d.rs:40)
+//  resolves to on an x86-64 Linux host with FMA.  Argument reduction by pi/2
+//  (fast path for |x| < 120, 192-bit 4/pi table above that), then a degree-8
+//  cosine or degree-7 sine polynomial in double precision.
+// ============================================================================
+struct SinCosTab {
+    double sign[4];
+    double hpi_inv, hpi;
+    double c0, c1, c2, c3, c4;
+    double s1, s2, s3;
+};
+// (the initialisers are macros so that rtc_device.hip can build host copies for rtc_cosf_host)
+#define RTC_SINCOSF_TAB_INIT                                                                                     \
+    {{{1.0, -1.0, -1.0, 1.0}, 0x1.45f306dc9c883p+23, 0x1.921fb54442d18p+0,                                        \
+      0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5, -0x1.6c087e89a359dp-10, 0x1.99343027bf8c3p-16,          \
+      -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13},                                       \
+     {{1.0, -1.0, -1.0, 1.0}, 0x1.45f306dc9c883p+23, 0x1.921fb54442d18p+0,                                        \
+      -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5, 0x1.6c087e89a359dp-10, -0x1.99343027bf8c3p-16,         \
+      -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13}}
+// 4/pi as overlapping 32-bit words (__inv_pio4)
+#define RTC_INV_PIO4_INIT                                                                                        \
+    {0xa2,       0xa2f9,     0xa2f983,   0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529,              \
+     0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0,              \
+     0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041}
+__device__ __constant__ SinCosTab d_sincosf_tab[2] = RTC_SINCOSF_TAB_INIT;
+__device__ __constant__ uint32_t d_inv_pio4[24] = RTC_INV_PIO4_INIT;
+// sinf_poly: n even -> sine polynomial of x, n odd -> cosine polynomial of x (x2 = x*x)
+HDI float sincosf_poly(double x, double x2, const SinCosTab* p, int n) {
+    if ((n & 1) == 0) {
+        double x3 = x * x2;
+        double s1 = fma(p->s3, x2, p->s2);
+        double x7 = x3 * x2;
+        double s = fma(x3, p->s1, x);
+        return (float)fma(x7, s1, s);
+    }
+    double x4 = x2 * x2;
+    double c2 = fma(p->c4, x2, p->c3);
+    double c1 = fma(p->c1, x2, p->c0);
+    double x6 = x4 * x2;
+    double c = fma(x4, p->c2, c1);
+    return (float)fma(x6, c2, c);
+}
+HDI float cosf_glibc(float y, const SinCosTab* __restrict__ T, const uint32_t* __restrict__ IP) {
+    double x = (double)y;
+    const uint32_t ix = f2u(y);
+    const uint32_t top = (ix >> 20) & 0x7ffu;  // abstop12
+    if (top < 0x3f4u) {                        // |y| < pi/4
+        double x2 = x * x;
+        if (top < 0x398u) return 1.0f;         // |y| < 2^-12
+        return sincosf_poly(x, x2, &T[0], 1);
+    }
+    if (top < 0x42fu) {  // |y| < 120: reduce_fast
+        double r = x * T[0].hpi_inv;
+        int n = ((int32_t)r + 0x800000) >> 24;
+        x = fma(-(double)n, T[0].hpi, x);
+        double s = T[0].sign[n & 3];
+        const SinCosTab* p = (n & 2) ? &T[1] : &T[0];
+        return sincosf_poly(x * s, x * x, p, n ^ 1);
+    }
+    if (top < 0x7f8u) {  // reduce_large
+        const uint32_t* arr = &IP[(ix >> 26) & 15u];
+        const int shift = (int)((ix >> 23) & 7u);
+        uint32_t xi = ((ix & 0xffffffu) | 0x800000u) << shift;
+        uint64_t res0 = (uint64_t)(uint32_t)(xi * arr[0]);
+        uint64_t res1 = (uint64_t)xi * arr[4];
+        uint64_t res2 = (uint64_t)xi * arr[8];
+        res0 = (res2 >> 32) | (res0 << 32);
+        res0 += res1;
+        uint64_t nn = (res0 + (1ULL << 61)) >> 62;
+        res0 -= nn << 62;
+        x = (double)(long long)res0 * 0x1.921fb54442d18p-62;
+        int n = (int)nn;
+        int sign = (int)(ix >> 31);
+        double s = T[0].sign[(n + sign) & 3];
+        const SinCosTab* p = ((n + sign) & 2) ? &T[1] : &T[0];
+        return sincosf_poly(x * s, x * x, p, n ^ 1);
+    }
+    return RTC_NAN;  // inf or NaN
+}
+DI float rtc_cosf_dev(float x) { return cosf_glibc(x, d_sincosf_tab, d_inv_pio4); }
+
+// ============================================================================
 //  Scene as the kernel sees it
 // ============================================================================
 struct V3 {
@@ -248,6 +334,7 @@ struct SceneHdr {
     float half_w, half_h, pixel_size;
     float cam[12];        // rows 0..2 of transform_inverse
     float cam_origin[3];  // transform_inverse * point(0,0,0), camera.rs:70
+    uint32_t has_patterns;  // some material carries a pattern (wave-uniform switch around the pattern code)
 };
 
 // Structure-of-arrays scene records in HBM: 4 float4 of geometry (64 B) and
@@ -267,6 +354,9 @@ struct SceneSoA {
     const float4* __restrict__ mat_a;  // {r, g, b, ambient}
     const float4* __restrict__ mat_b;  // {diffuse, specular, shininess, reflective}
     const float4* __restrict__ mat_c;  // {transparency, refractive_index, 0, 0}
+    // 5 records per object, read once per shaded hit and only if hdr.has_patterns:
+    //   {a.rgb, kind}, {b.rgb -- or distance = b - a for gradient / sine_2d --, 0}, rows 0..2 of the pattern's t_inverse
+    const float4* __restrict__ pat;
 };
 enum : uint32_t {
     SHAPE_KIND_MASK = 0xffu,
@@ -278,7 +368,7 @@ enum : uint32_t {
 
 // ---- scene specialisation (hiprtc compile only) --------------------------------------------------
 // -DRTC_SPEC_LIST=b0,b1,...  the per-object `bits` words of THIS scene (kind | casts | closed | diag),
-// -DRTC_SPEC_NOBJ=n, -DRTC_SPEC_SIMPLE=0|1, -DRTC_SPEC_LIGHT_KIND=k, -DRTC_SPEC_JITTER=m.
+// -DRTC_SPEC_NOBJ=n, -DRTC_SPEC_SIMPLE=0|1, -DRTC_SPEC_LIGHT_KIND=k, -DRTC_SPEC_JITTER=m, -DRTC_SPEC_PATTERNS=0|1.
 // Inside the fully unrolled object loops `i` is a constant, so spec_bits(i, ...) folds and every
 // `kind == ...` / `bits & flag` test below disappears at compile time.  Values (matrices, materials,
 // light geometry, camera) stay run-time data: one specialisation serves every scene of that shape.
@@ -289,10 +379,12 @@ DI uint32_t spec_bits(uint32_t i, uint32_t) {
 }
 DI int32_t spec_light_kind(int32_t) { return RTC_SPEC_LIGHT_KIND; }
 DI int32_t spec_jitter_mode(int32_t) { return RTC_SPEC_JITTER; }
+DI bool spec_has_patterns(uint32_t) { return RTC_SPEC_PATTERNS != 0; }
 #else
 DI uint32_t spec_bits(uint32_t, uint32_t runtime_bits) { return runtime_bits; }
 DI int32_t spec_light_kind(int32_t k) { return k; }
 DI int32_t spec_jitter_mode(int32_t m) { return m; }
+DI bool spec_has_patterns(uint32_t h) { return h != 0; }
 #endif
 
 constexpr float PLANE_EPS = 1.1920929e-7f * 10000.0f;  // plane.rs:49  f32::EPSILON * 10000.0
@@ -373,6 +465,7 @@ DI V3 obj_normal_to_world(const Obj& b, V3 n) {
 DI float quadratic_c(uint32_t kind, V3 o) {
     if (kind == RTC_SPHERE) return (o.x * o.x + o.y * o.y + o.z * o.z) - 1.0f;  // sphere.rs:56
     if (kind == RTC_CYLINDER) return o.x * o.x + o.z * o.z - 1.0f;              // cylinder.rs:95
+    if (kind == RTC_CONE) return o.x * o.x - o.y * o.y + o.z * o.z;             // cone.rs:143-146
     return 0.0f;
 }
 // HITS_ONLY: the caller only looks at distances >= 0 (hit selection, shadow tests), so an
@@ -449,6 +542,38 @@ DI void local_intersect_c(uint32_t bits, float min_y, float max_y, V3 o, V3 d, f
             cz = o.z + t * d.z;
             if ((cx * cx + cz * cz) <= 1.0f + CLOSE_TO_ZERO) f(t);
         }
+    } else if (kind == RTC_CONE) {  // cone.rs:52-57: sides (:89-141), then -- always -- caps (:156-175)
+        float two_a = 2.0f * (d.x * d.x - d.y * d.y + d.z * d.z);
+        float b = 2.0f * (o.x * d.x - o.y * d.y + o.z * d.z);
+        if (fabsf(two_a) < CLOSE_TO_ZERO) {
+            // ray parallel to one half of the cone: a single root, pushed without a y-range test (:99-107)
+            if (!(fabsf(b) < CLOSE_TO_ZERO)) f(-c / (2.0f * b));
+        } else {
+            float disc = b * b - 2.0f * two_a * c;
+            if (!(disc < 0.0f)) {
+                float sq = sqrtf(disc);
+                float d1 = (-b - sq) / two_a;
+                float d2 = (-b + sq) / two_a;
+                if (d1 > d2) {
+                    float t = d1;
+                    d1 = d2;
+                    d2 = t;
+                }
+                float y1 = o.y + d1 * d.y;
+                if (min_y < y1 && y1 < max_y) f(d1);
+                float y2 = o.y + d2 * d.y;
+                if (min_y < y2 && y2 < max_y) f(d2);
+            }
+        }
+        if (bits & SHAPE_CLOSED) {  // check_cap (:148-154) compares x^2 + z^2 with |y|, as written there
+            float t = (min_y - o.y) / d.y;
+            float cx = o.x + t * d.x, cz = o.z + t * d.z;
+            if ((cx * cx + cz * cz) <= fabsf(min_y) + CLOSE_TO_ZERO) f(t);
+            t = (max_y - o.y) / d.y;
+            cx = o.x + t * d.x;
+            cz = o.z + t * d.z;
+            if ((cx * cx + cz * cz) <= fabsf(max_y) + CLOSE_TO_ZERO) f(t);
+        }
     }
 }
 
@@ -457,7 +582,7 @@ DI void local_intersect(uint32_t bits, float min_y, float max_y, V3 o, V3 d, F&&
     local_intersect_c<HITS_ONLY>(bits, min_y, max_y, o, d, quadratic_c(bits & SHAPE_KIND_MASK, o), f);
 }
 
-// local_norm_at for the four shapes (sphere.rs:71-73, plane.rs:57-59, cube.rs:66-80, cylinder.rs:62-72)
+// local_norm_at (sphere.rs:71-73, plane.rs:57-59, cube.rs:66-80, cylinder.rs:62-72, cone.rs:60-73)
 DI V3 local_normal(uint32_t kind, float min_y, float max_y, V3 p) {
     if (kind == RTC_SPHERE) return p;
     if (kind == RTC_PLANE) return v3(0.0f, 1.0f, 0.0f);
@@ -472,6 +597,11 @@ DI V3 local_normal(uint32_t kind, float min_y, float max_y, V3 p) {
     if (dist_square < 1.0f) {
         if (p.y >= max_y - CLOSE_TO_ZERO) return v3(0.0f, 1.0f, 0.0f);
         if (p.y <= min_y + CLOSE_TO_ZERO) return v3(0.0f, -1.0f, 0.0f);
+    }
+    if (kind == RTC_CONE) {  // the cap test above uses radius 1 for the cone too, as cone.rs:61-68 does
+        float y = sqrtf(dist_square);
+        if (p.y > 0.0f) y = -y;
+        return v3(p.x, y, p.z);
     }
     return v3(p.x, 0.0f, p.z);
 }
@@ -623,7 +753,8 @@ DI void shadow_prepare(const SceneHdr& H, const SceneSoA& S, V3 p, ShadowPre* pr
 //      if there is none, or t_c >= distance, the point is lit whatever the non-casters do;
 //   2. otherwise a non-caster hides that caster iff it has a hit t_n >= 0 that sorts before
 //      (t_c, i_c).  Only then are non-casters (the soft_shadows lampshade) intersected at all.
-// SIMPLE: every object is scale+translate-only and none is a cylinder (decided on the host), so the
+// SIMPLE: every object is scale+translate-only, none is a cylinder or cone and no material has a pattern
+// (decided on the host), so the
 // loop-invariant uniform working set is 4 SGPRs per object and stays resident across the sample loop.
 template <int NOBJ, bool SIMPLE>
 DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* pre, V3 lp, V3 p, Counters& cnt) {
@@ -642,7 +773,7 @@ DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* p
                     c.x * dir.x + c.y * dir.y + g.z * dir.z);
         }
         float mn = 0.0f, mx = 0.0f;
-        if (!SIMPLE && (bits & SHAPE_KIND_MASK) == RTC_CYLINDER) {
+        if (!SIMPLE && ((bits & SHAPE_KIND_MASK) == RTC_CYLINDER || (bits & SHAPE_KIND_MASK) == RTC_CONE)) {
             mn = S.off0[i].w;
             mx = S.off1[i].w;
         }
@@ -732,10 +863,47 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
     return total / H.cells_f;
 }
 
-// light/phong_lighting.rs:12-63 (pattern branch out of scope)
-DI V3 phong(const SceneHdr& H, float4 ma, float4 mb, V3 p, V3 eye, V3 n, float light_intensity) {
+// Rust `f as i32`: saturating, NaN -> 0
+DI int32_t rust_f32_as_i32(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return -2147483647 - 1;
+    return (int32_t)f;
+}
+// Pattern::color_at_world for the five procedural patterns (stripes.rs:39-45, gradient.rs:33-36, rings.rs:38-50,
+// checkers.rs:38-46, sine_2d.rs:39-44).  pa = {a.rgb, kind}, pb = {b.rgb | distance.rgb, 0}.
+// `v % 2 == 0` on an i32 is `(v & 1) == 0` for either sign.
+DI V3 pattern_color_at_world(float4 pa, float4 pb, V3 pt) {
+    const uint32_t kind = __float_as_uint(pa.w);
+    const V3 a = v3(pa.x, pa.y, pa.z), b = v3(pb.x, pb.y, pb.z);
+    if (kind == RTC_PATTERN_GRADIENT) {
+        float fraction = pt.x - floorf(pt.x);
+        return a + (b * fraction);
+    }
+    if (kind == RTC_PATTERN_SINE2D) {
+        float cosine = rtc_cosf_dev(pt.x + pt.z);
+        float fraction = (-cosine + 1.0f) / 2.0f;
+        return a + (b * fraction);
+    }
+    float key = pt.x;  // RTC_PATTERN_STRIPES
+    if (kind == RTC_PATTERN_RINGS) key = sqrtf(pt.x * pt.x + pt.z * pt.z);
+    if (kind == RTC_PATTERN_CHECKERS) key = fabsf(pt.x) + fabsf(pt.y) + fabsf(pt.z);
+    return (rust_f32_as_i32(floorf(key)) & 1) == 0 ? a : b;
+}
+// Pattern::color_at_object (pattern.rs:15-19): world -> object -> pattern space.  Both matrices are affine
+// (checked on the host), so the w component stays exactly 1.
+DI V3 pattern_color_at_object(const float4* __restrict__ pat, const Obj& rec, V3 world_point) {
+    const float4 pa = pat[0], pb = pat[1], r0 = pat[2], r1 = pat[3], r2 = pat[4];
+    V3 op = obj_point(rec, world_point);
+    V3 pp = v3(r0.x * op.x + r0.y * op.y + r0.z * op.z + r0.w, r1.x * op.x + r1.y * op.y + r1.z * op.z + r1.w,
+               r2.x * op.x + r2.y * op.y + r2.z * op.z + r2.w);
+    return pattern_color_at_world(pa, pb, pp);
+}
+
+// light/phong_lighting.rs:12-63; `material_color` is material.color or the pattern's colour (:24-27)
+DI V3 phong(const SceneHdr& H, V3 material_color, float4 ma, float4 mb, V3 p, V3 eye, V3 n, float light_intensity) {
     const V3 li = v3(H.li[0], H.li[1], H.li[2]);
-    V3 effective = v3(ma.x, ma.y, ma.z) * li;
+    V3 effective = material_color * li;
     V3 ambient = effective * ma.w;
     if (light_intensity == 0.0f) return ambient;
     V3 to_light = norm3(v3(H.lpos[0], H.lpos[1], H.lpos[2]) - p);
@@ -913,7 +1081,15 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
             V3 under_point = point - n * SELF_EPS;
             float4 ma = S.mat_a[ob], mb = S.mat_b[ob], mc = S.mat_c[ob];
             const float reflective = mb.w, transparency = mc.x;
-            V3 surface = phong(H, ma, mb, over_point, eye, n, li);
+            V3 material_color = v3(ma.x, ma.y, ma.z);
+            if constexpr (!SIMPLE) {
+                if (spec_has_patterns(H.has_patterns)) {
+                    const float4* pat = S.pat + 5 * ob;
+                    if (__float_as_uint(pat[0].w) != RTC_PATTERN_NONE)
+                        material_color = pattern_color_at_object(pat, load_obj(S, ob), over_point);
+                }
+            }
+            V3 surface = phong(H, material_color, ma, mb, over_point, eye, n, li);
 
             bool has_refl = !(reflective == 0.0f || rem < 1);  // world.rs:126
             bool has_refr = false;
@@ -1283,6 +1459,49 @@ __global__ void powf_kernel(const float* __restrict__ x, const float* __restrict
                             float* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = rtc_powf_dev(x[i], y[i]);
+}
+
+__global__ void cosf_kernel(const float* __restrict__ x, uint32_t n, float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rtc_cosf_dev(x[i]);
+}
+
+// Shape::local_intersect for caller-supplied object-space rays: up to 4 distances per ray, in push order.
+__global__ void local_intersect_kernel(Obj ob, const float4* __restrict__ origins, const float4* __restrict__ directions,
+                                       uint32_t n, float4* __restrict__ out_t, int32_t* __restrict__ out_count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 o = origins[i], d = directions[i];
+    float ts[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int count = 0;
+    local_intersect<false>(ob.bits, ob.min_y(), ob.max_y(), v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), [&](float t) {
+        if (count < 4) ts[count] = t;
+        count++;
+    });
+    out_t[i] = make_float4(ts[0], ts[1], ts[2], ts[3]);
+    out_count[i] = count;
+}
+
+// Shape::normal_at (shape.rs:72-154) for caller-supplied world points.
+__global__ void normal_at_kernel(Obj ob, const float4* __restrict__ points, uint32_t n, float4* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = points[i];
+    V3 op = obj_point(ob, v3(p.x, p.y, p.z));
+    V3 nn = obj_normal_to_world(ob, local_normal(ob.bits & SHAPE_KIND_MASK, ob.min_y(), ob.max_y(), op));
+    out[i] = make_float4(nn.x, nn.y, nn.z, 0.0f);
+}
+
+// Pattern::color_at_object (pattern.rs:15-19) for caller-supplied world points; pat: the 5 pattern records.
+__global__ void pattern_color_kernel(Obj ob, const float4* __restrict__ pat, const float4* __restrict__ points, uint32_t n,
+                                     float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = points[i];
+    V3 c = pattern_color_at_object(pat, ob, v3(p.x, p.y, p.z));
+    out[3 * i + 0] = c.x;
+    out[3 * i + 1] = c.y;
+    out[3 * i + 2] = c.z;
 }
 
 // Diagnostic: sqrt_core / RcpCore against the compiler's sqrtf and '/' on caller-supplied vectors.

@@ -6,8 +6,9 @@ it calls camera.render(world, depth).  Literals are the reference's.
 """
 import numpy as np
 
-from .api import (Camera, Cube, Cylinder, Material, Plane, PointLight, RectangleLight, Sphere, World, chain, color,
-                  identity_4x4, point, rotation_x, rotation_y, scaling, shearing, translation, vector, view_transform)
+from .api import (Camera, Checkers, Cone, Cube, Cylinder, Gradient, Material, Plane, PointLight, RectangleLight, Rings,
+                  Sine2D, Sphere, Stripes, World, chain, color, identity_4x4, metal, point, rotation_x, rotation_y,
+                  rotation_z, scaling, shearing, translation, vector, view_transform)
 
 f32 = np.float32
 PI = f32(3.14159265358979323846264338327950288)  # std::f32::consts::PI
@@ -101,6 +102,85 @@ def first_plane(width=100, height=50):
                   Material(color=(1, 0.8, 0.1), diffuse=0.7, specular=0.3))
     world = World([floor, left, middle, right], PointLight(point(-10, 10, -10), color(1, 1, 1)))
     camera = Camera(width, height, PI / f32(3.0), view_transform(point(0, 1.5, -5), point(0, 1, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
+def _demo_stripes():
+    """first_patterns.rs:29-30 / reflect_refract.rs:37-38"""
+    return Stripes((1.0, 0.2, 0.4), (0.1, 0.1, 0.1),
+                   chain(scaling(0.3, 0.3, 0.3), rotation_z(f32(3.0) * PI / f32(4.0))))
+
+
+def first_patterns(width=100, height=50):
+    """demos/src/bin/first_patterns.rs:28-93 (default 100x50; the commented-out size is 1000x500)."""
+    stripes = _demo_stripes()
+    sine2d = Sine2D((0.1, 1, 0.5), (0.9, 0.2, 0.6), chain(scaling(0.005, 1.0, 0.005), translation(-5.0, 1.0, 0.5)))
+    floor = Plane(scaling(10.0, 0.01, 10.0), Material(pattern=sine2d, specular=0.0))
+    middle = Sphere(translation(-0.5, 1.0, 0.5), Material(pattern=stripes, diffuse=0.7, specular=0.3))
+    right = Sphere(chain(shearing(0.0, 1.0, 0.0, 0.0, 0.0, 1.0), translation(1.5, 0.5, -0.5), scaling(0.5, 0.5, 0.5)),
+                   Material(pattern=stripes, diffuse=0.7, specular=0.3))
+    left = Sphere(chain(translation(-1.5, 0.33, -0.75), scaling(0.33, 0.33, 0.33)),
+                  Material(pattern=stripes, diffuse=0.7, specular=0.3))
+    world = World([floor, left, middle, right], PointLight(point(-10, 10, -10), color(1, 1, 1)))
+    camera = Camera(width, height, PI / f32(3.0), view_transform(point(0, 1.5, -5), point(0, 1, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
+def reflect_refract(width=1000, height=500):
+    """demos/src/bin/reflect_refract.rs:35-158 as shipped (the CSG object is commented out there, :107)."""
+    stripes = _demo_stripes()
+    sine2d = Sine2D((0.1, 1, 0.5), (0.9, 0.2, 0.6), chain(scaling(0.05, 1.0, 0.05), translation(-5.0, 1.0, 0.5)))
+    floor = Plane(scaling(10.0, 0.1, 10.0), Material(pattern=sine2d, specular=0.0, reflective=0.5))
+    middle = Sphere(translation(-0.5, 1.0, 0.5),
+                    Material(color=(0, 0, 0), specular=1.0, shininess=300.0, transparency=1.0, refractive_index=1.52,
+                             reflective=1.0), casts_shadow=False)
+    half = f32(2.0)
+    ring_pattern = Rings(tuple(f32(c) / half for c in (1, 1, 0)), tuple(f32(c) / half for c in (1, 1, 1)),
+                         scaling(0.1, 0.1, 0.1))  # yellow() / 2., white() / 2.
+    right = Sphere(chain(shearing(0.0, 1.0, 0.0, 0.0, 0.0, 1.0), translation(1.5, 0.5, -0.5), scaling(0.5, 0.5, 0.5)),
+                   metal().copy(pattern=ring_pattern))
+    quarter = f32(4.0)
+    stripes2 = Stripes(tuple(f32(c) / quarter for c in stripes.a), tuple(f32(c) / quarter for c in stripes.b),
+                       stripes.transform)
+    left = Sphere(chain(translation(-1.5, 0.33, -0.75), scaling(0.33, 0.33, 0.33)),
+                  Material(pattern=stripes2, diffuse=0.7, specular=1.0, reflective=0.8, shininess=300.0))
+    cylinder = Cylinder(chain(translation(3.7, 0.0, 4.0), scaling(0.33, 1.8, 0.33)),
+                        Material(reflective=1.0, color=(0.5, 0.5, 0.5), shininess=300.0, specular=0.8),
+                        minimum_y=0.0, maximum_y=1.5)
+    cone = Cone(chain(translation(-3.5, 0.0, 4.0), scaling(0.33, 1.8, 0.33)),
+                Material(color=(0.6, 0.3, 0.1), reflective=0.5, shininess=10.0, specular=0.8),
+                minimum_y=0.0, maximum_y=1.5)
+    world = World([floor, left, middle, right, cylinder, cone], PointLight(point(-10, 10, -10), color(1, 1, 1)))
+    camera = Camera(width, height, PI / f32(3.0), view_transform(point(0, 1.5, -5), point(0, 1, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
+def patterns_medley(width=256, height=192, jitter=("hashed", 11)):
+    """All five patterns and open / closed / double cones under an area light: a parity stress scene
+    (not a reference demo)."""
+    floor = Plane(identity_4x4(), Material(pattern=Checkers((0.9, 0.9, 0.9), (0.15, 0.15, 0.2),
+                                                          chain(rotation_y(f32(0.3)), scaling(0.7, 0.7, 0.7))),
+                                           specular=0.1, reflective=0.2))
+    wall = Plane(chain(translation(0.0, 0.0, 6.0), rotation_x(PI / f32(2.0))),
+                 Material(pattern=Sine2D((0.1, 0.3, 0.8), (0.9, 0.8, 0.2), scaling(0.07, 1.0, 0.07)), specular=0.0))
+    closed_cone = Cone(chain(translation(-1.8, 1.2, 0.5), scaling(0.6, 1.2, 0.6)),
+                       Material(pattern=Gradient((1.0, 0.1, 0.1), (0.1, 0.1, 1.0),
+                                                 chain(translation(-1.0, 0.0, 0.0), scaling(2.0, 1.0, 1.0))),
+                                diffuse=0.8, specular=0.4, shininess=40.0),
+                       minimum_y=-1.0, maximum_y=0.0, closed=True)
+    hourglass = Cone(chain(translation(1.9, 1.0, 1.0), rotation_z(f32(0.2)), scaling(0.5, 1.0, 0.5)),
+                     Material(color=(0.1, 0.1, 0.1), transparency=0.8, refractive_index=1.333, reflective=0.4,
+                              diffuse=0.3),
+                     minimum_y=-1.0, maximum_y=1.0, closed=True)
+    ringed = Sphere(chain(translation(0.0, 0.8, -0.5), scaling(0.8, 0.8, 0.8)),
+                    Material(pattern=Rings((0.9, 0.7, 0.1), (0.2, 0.5, 0.3),
+                                           chain(rotation_x(f32(0.9)), scaling(0.15, 0.15, 0.15))),
+                             diffuse=0.7, specular=0.6, reflective=0.15))
+    striped_box = Cube(chain(translation(-0.4, 0.3, -2.2), rotation_y(f32(0.7)), scaling(0.3, 0.3, 0.3)),
+                       Material(pattern=_demo_stripes(), ambient=0.2))
+    light = RectangleLight(color(1.3, 1.3, 1.3), point(-3, 5, -5), vector(2, 0, 0), 3, vector(0, 0, 2), 3, jitter)
+    world = World([floor, wall, closed_cone, hourglass, ringed, striped_box], light)
+    camera = Camera(width, height, PI / f32(3.0), view_transform(point(0.3, 2.4, -6.5), point(0, 0.9, 0), vector(0, 1, 0)))
     return world, camera, 5
 
 

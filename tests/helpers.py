@@ -11,8 +11,9 @@ def oracle_world(world):
     objs = []
     for s in world.objects:
         m = s.material
+        pat = None if m.pattern is None else O.Pattern(m.pattern.kind, m.pattern.a, m.pattern.b, m.pattern.transform)
         om = O.Material(m.color, m.ambient, m.diffuse, m.specular, m.shininess, m.reflective, m.transparency,
-                        m.refractive_index)
+                        m.refractive_index, pat)
         objs.append(O.Shape(s.kind, s.transform, om, casts_shadow=s.casts_shadow, minimum_y=s.minimum_y,
                             maximum_y=s.maximum_y, closed=s.closed))
     lt = world.light

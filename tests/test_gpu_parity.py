@@ -47,6 +47,25 @@ def test_device_powf_equals_libm_powf():
         assert np.array_equal(got, P.powf_host(xs, ys), equal_nan=True)
 
 
+def test_device_cosf_equals_libm_cosf():
+    """f32::cos (pattern/sine_2d.rs:40) on the device == glibc cosf == the host compile of the same code."""
+    libm = C.CDLL("libm.so.6")
+    libm.cosf.restype = C.c_float
+    libm.cosf.argtypes = [C.c_float]
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([
+        rng.uniform(-1, 1, 40_000), rng.uniform(-130, 130, 80_000), rng.uniform(-1e6, 1e6, 40_000),
+        rng.standard_normal(40_000) * 10.0 ** rng.uniform(-20, 38, 40_000),
+        [0.0, -0.0, np.pi, np.pi / 2, np.pi / 4, 120.0, 119.99999, 1e-4, 2.0 ** -12, 3.4e38, -3.4e38, 1e-40, np.inf, np.nan],
+    ]).astype(f32)
+    xs = np.concatenate([xs, rng.integers(0, 2 ** 32, 100_000, dtype=np.uint64).astype(np.uint32).view(f32)])
+    got = P.cosf(xs)
+    exp = np.array([libm.cosf(float(v)) for v in xs], dtype=f32)
+    same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
+    assert same.all(), (xs[~same][:5], got[~same][:5], exp[~same][:5])
+    assert np.array_equal(got, P.cosf_host(xs), equal_nan=True)
+
+
 def test_exact_sqrt_and_divide_cores_equal_ieee_forms():
     """normalize_exact's cheap branch (sqrt_core / RcpCore) must return the same bits as sqrtf and '/'
     everywhere inside its validity range: 12 M random vectors across the whole exponent range it admits,
@@ -203,6 +222,11 @@ def test_render_world_known_answer(kat):  # camera.rs:156-167
     ("sphere_grid", (128, 128), {}),
     ("shapes_medley", (128, 96), {}),
     ("shapes_medley", (64, 48), {"jitter": ("constant", 0.5)}),
+    ("first_patterns", (100, 50), {}),
+    ("first_patterns", (320, 160), {}),
+    ("reflect_refract", (200, 100), {}),
+    ("patterns_medley", (128, 96), {}),
+    ("patterns_medley", (64, 48), {"jitter": ("constant", 0.5)}),
 ])
 def test_render_matches_oracle_bitwise(name, size, kw):
     world, camera, depth = getattr(scenes, name)(*size, **kw)
@@ -268,6 +292,9 @@ def test_boundary_errors_on_device():
     ("first_plane", (100, 50), {}),
     ("glass_and_mirror", (96, 96), {}),
     ("shapes_medley", (128, 96), {}),
+    ("first_patterns", (100, 50), {}),
+    ("reflect_refract", (160, 80), {}),
+    ("patterns_medley", (128, 96), {}),
 ])
 def test_specialised_kernel_matches_generic_and_oracle(name, size, kw, monkeypatch):
     """RTC_AMD_SPECIALIZE=1 compiles the kernel for this scene's shape with hiprtc; the image, the ray
@@ -298,3 +325,129 @@ def test_specialisation_policy_defaults(monkeypatch):
     assert Renderer(world, camera, device=0).kernel_name.startswith("render_kernel_spec[")  # >= 2^18 pixels
     world, camera, _ = scenes.sphere_grid(1024, 512)
     assert Renderer(world, camera, device=0).kernel_name == "render_kernel<0,general>"     # 64 objects: generic
+
+
+# ------------------------------------------------- shapes and patterns on the device
+def _kinds():
+    return {"sphere": (P.Sphere, O.Sphere), "plane": (P.Plane, O.Plane), "cube": (P.Cube, O.Cube),
+            "cylinder": (P.Cylinder, O.Cylinder), "cone": (P.Cone, O.Cone)}
+
+
+def test_cone_known_answers_on_device(kat):  # shape/cone.rs:190-278 through rtc_local_intersect / rtc_normal_at
+    co = kat["cone"]
+    c = P.Cone()
+    rays = [(K.point(o), O.norm(K.vector(d))) for o, d, _, _ in co["sides"]["cases"]]
+    got = c.local_intersect([r[0] for r in rays], [r[1] for r in rays])
+    for ts, (_, _, t0, t1) in zip(got, co["sides"]["cases"]):
+        assert len(ts) == 2
+        K.assert_eps(ts, [t0, t1])
+    blk = co["parallel_to_one_half"]
+    (ts,) = c.local_intersect([K.point(blk["ray"][0])], [O.norm(K.vector(blk["ray"][1]))])
+    assert len(ts) == 1
+    K.assert_eps(ts, blk["expect_eps"])
+    blk = co["caps"]
+    cc = P.Cone(minimum_y=blk["min"], maximum_y=blk["max"], closed=blk["closed"])
+    got = cc.local_intersect([K.point(o) for o, _, _ in blk["cases"]], [O.norm(K.vector(d)) for _, d, _ in blk["cases"]])
+    assert [len(ts) for ts in got] == [n for _, _, n in blk["cases"]]
+    # local_norm_at through normal_at on an untransformed cone: the expected vectors, normalised (shape.rs:72-154)
+    pts = [K.point(p) for p, _ in co["normals"]["cases"]]
+    got = c.normal_at(pts)
+    exp = O.Cone().normal_at
+    for g, p in zip(got, pts):
+        e = exp(p)
+        assert np.array_equal(g, e, equal_nan=True), (p, g, e)
+
+
+@pytest.mark.parametrize("kind", ["sphere", "plane", "cube", "cylinder", "cone"])
+def test_local_intersect_and_normal_at_match_oracle_bitwise(kind):
+    """Shape::local_intersect / normal_at for random rays and points, bounded / closed variants included:
+    the same distances in the same push order, bit for bit."""
+    rng = np.random.default_rng(sorted(_kinds()).index(kind) + 3)
+    pk, ok = _kinds()[kind]
+    variants = [dict()]
+    if kind in ("cylinder", "cone"):
+        variants += [dict(minimum_y=-0.5, maximum_y=0.75, closed=True), dict(minimum_y=0.0, maximum_y=1.5, closed=False),
+                     dict(minimum_y=-2.0, maximum_y=-0.25, closed=True)]
+    t = P.chain(P.translation(0.3, -0.2, 0.1), P.rotation_z(f32(0.4)), P.scaling(0.8, 1.3, 0.6))
+    n = 4000
+    o = np.concatenate([rng.uniform(-3, 3, (n, 3)), np.ones((n, 1))], axis=1).astype(f32)
+    d = np.concatenate([rng.standard_normal((n, 3)), np.zeros((n, 1))], axis=1).astype(f32)
+    d[: n // 8, 1] = 0.0                      # rays parallel to the caps / the plane
+    d[n // 8: n // 4, 0] = d[n // 8: n // 4, 2] = 0.0    # rays along the axis
+    d[n // 4: n // 4 + 200, 1] = np.hypot(d[n // 4: n // 4 + 200, 0], d[n // 4: n // 4 + 200, 2])  # cone: parallel to one half
+    o[n // 2: n // 2 + 300] = [0.0, 0.0, 0.0, 1.0]       # through the apex
+    d = np.array([O.norm(v) for v in d], dtype=f32)
+    d[~np.isfinite(d).all(axis=1)] = [0.0, 1.0, 0.0, 0.0]
+    for kw in variants:
+        ps, os_ = pk(t, None, **kw), ok(t, None, **kw)
+        got = ps.local_intersect(o, d)
+        hits = 0
+        for i in range(n):
+            exp = os_.local_intersect(o[i], d[i])
+            assert len(got[i]) == len(exp), (kind, kw, i, o[i], d[i], got[i], exp)
+            assert np.array_equal(np.array(got[i], dtype=f32), np.array(exp, dtype=f32), equal_nan=True), (kind, kw, i, got[i], exp)
+            hits += len(exp)
+        assert kind == "plane" or hits > n // 8
+        pts = np.concatenate([rng.uniform(-2, 2, (600, 3)), np.ones((600, 1))], axis=1).astype(f32)
+        gn = ps.normal_at(pts)
+        for i in range(600):
+            en = os_.normal_at(pts[i])
+            assert np.array_equal(gn[i], en, equal_nan=True), (kind, kw, pts[i], gn[i], en)
+
+
+PATTERNS = {"stripes": (P.Stripes, O.Stripes), "gradient": (P.Gradient, O.Gradient), "rings": (P.Rings, O.Rings),
+            "checkers": (P.Checkers, O.Checkers), "sine_2d": (P.Sine2D, O.Sine2D)}
+
+
+def test_pattern_known_answers_on_device(kat):  # pattern/*.rs tests through rtc_pattern_color_at
+    for name, (pp, _) in PATTERNS.items():
+        blk = kat["pattern"][name]
+        pat = pp(blk["a"], blk["b"])
+        pts = [K.point(p) for p, _ in blk["cases_exact"]]
+        got = pat.color_at_world(pts)
+        for g, (_, expect) in zip(got, blk["cases_exact"]):
+            K.assert_exact(g, K.vec(expect))
+        for p, expect in blk.get("cases_eps", []):
+            K.assert_eps(pat.color_at_world([K.point(p)])[0], K.vec(expect))
+    # phong_lighting.rs:197-235: ambient-only material, so the lit colour is the pattern colour
+    c = kat["pattern"]["phong_with_pattern"]
+    got = P.Stripes().color_at_object([K.point(p) for p, _ in c["cases_exact"]], P.Sphere())
+    for g, (_, expect) in zip(got, c["cases_exact"]):
+        K.assert_exact(g, expect)
+
+
+@pytest.mark.parametrize("name", sorted(PATTERNS))
+def test_pattern_color_at_object_matches_oracle_bitwise(name):
+    """Pattern::color_at_object (pattern.rs:15-19) with object and pattern transforms, for points near and far
+    (large pattern-space coordinates take cosf's big-argument reduction and the saturating `as i32`)."""
+    rng = np.random.default_rng(len(name))
+    pp, op = PATTERNS[name]
+    a, b = (0.1, 1.0, 0.5), (0.9, 0.2, 0.6)
+    pt = P.chain(P.scaling(0.005, 1.0, 0.005), P.translation(-5.0, 1.0, 0.5), P.rotation_y(f32(0.3)))
+    ot = P.chain(P.shearing(0.0, 1.0, 0.0, 0.0, 0.0, 1.0), P.translation(1.5, 0.5, -0.5), P.scaling(0.5, 0.5, 0.5))
+    pts = np.concatenate([
+        rng.uniform(-4, 4, (3000, 3)), rng.uniform(-300, 300, (2000, 3)), rng.standard_normal((1000, 3)) * 1e7,
+        rng.standard_normal((200, 3)) * 1e15, np.zeros((1, 3))]).astype(f32)
+    # (finite points only: the kernel skips products with a transform's structural zeros, which is exact for
+    # finite operands -- see DESIGN.md "Arithmetic contract" -- but 0 * inf is NaN in the reference)
+    pts = np.concatenate([pts, np.ones((pts.shape[0], 1), dtype=f32)], axis=1)
+    for ptx, otx in ((None, None), (pt, None), (None, ot), (pt, ot)):
+        got = pp(a, b, ptx).color_at_object(pts, P.Sphere(otx))
+        opat, osh = op(a, b, ptx), O.Sphere(otx)
+        for i in range(pts.shape[0]):
+            exp = opat.color_at_object(pts[i], osh)
+            assert np.array_equal(got[i], exp, equal_nan=True), (name, ptx is not None, otx is not None, pts[i], got[i], exp)
+
+
+def test_pattern_boundary_errors_on_device():
+    cam = P.Camera(8, 8, 1.0, P.identity_4x4())
+    proj = np.eye(4, dtype=f32)
+    proj[3, 0] = 0.25
+    w = P.World([P.Sphere(None, P.Material(pattern=P.Stripes(transform=proj)))], P.PointLight(P.point(0, 0, -5), P.color(1, 1, 1)))
+    with pytest.raises(P.RtcError) as e:
+        cam.render(w, 5)
+    assert e.value.status == L.RTC_ERR_UNSUPPORTED
+    bad = P.Pattern(77)
+    with pytest.raises(P.RtcError) as e:
+        bad.color_at_world([P.point(0, 0, 0)])
+    assert e.value.status == L.RTC_ERR_UNSUPPORTED

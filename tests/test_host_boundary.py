@@ -35,11 +35,11 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(L.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert P.lib().rtc_abi_version() == 1
+    assert P.lib().rtc_abi_version() == 2
 
 
 @pytest.mark.parametrize("name", ["soft_shadows", "first_scene", "first_plane", "glass_and_mirror", "shapes_medley",
-                                  "single_sphere"])
+                                  "single_sphere", "first_patterns", "reflect_refract", "patterns_medley"])
 def test_flattened_scene_matches_oracle_bitwise(name):
     world, camera, _ = getattr(scenes, name)(64, 48)
     ow = H.oracle_world(world)
@@ -47,6 +47,10 @@ def test_flattened_scene_matches_oracle_bitwise(name):
         inv, _ = ow.shape_inverse(i)
         assert np.array_equal(s.transformation_inverse(), inv), (name, i)
         assert np.all(inv[3] == np.array([0, 0, 0, 1], dtype=f32))
+        if s.material.pattern is not None:  # pattern.rs:52-54: the stored inverse, same cofactor arithmetic
+            pinv = s.material.pattern.transformation_inverse()
+            assert np.array_equal(pinv, O.inverse(s.material.pattern.transform)), (name, i)
+            assert np.all(pinv[3] == np.array([0, 0, 0, 1], dtype=f32))
     oc = H.oracle_camera(camera)
     assert camera.pixel_size == oc.pixel_size
     assert camera.half_width == oc.half_width and camera.half_height == oc.half_height
@@ -68,6 +72,43 @@ def test_sphere_grid_scene_is_deterministic():
     assert len(w1.objects) == 64
     assert [o.material.color for o in w1.objects] == [o.material.color for o in w2.objects]
     assert sum(1 for o in w1.objects if o.material.reflective > 0) == 32
+
+
+def test_cosf_restatement_equals_libm_cosf():
+    """f32::cos for Sine2D (pattern/sine_2d.rs:40): every reduction path of the glibc routine -- tiny, |x| < pi/4,
+    |x| < 120, the large-argument table -- plus random bit patterns; inf / NaN give NaN."""
+    libm = C.CDLL("libm.so.6")
+    libm.cosf.restype = C.c_float
+    libm.cosf.argtypes = [C.c_float]
+    rng = np.random.default_rng(99)
+    xs = np.concatenate([
+        rng.uniform(-1, 1, 60_000), rng.uniform(-130, 130, 120_000), rng.uniform(-1e6, 1e6, 60_000),
+        rng.standard_normal(60_000) * 10.0 ** rng.uniform(-20, 38, 60_000),
+        [0.0, -0.0, np.pi, np.pi / 2, np.pi / 4, 120.0, 119.99999, 1e-4, 2.0 ** -12, 3.4e38, -3.4e38, 1e-40],
+    ]).astype(f32)
+    xs = np.concatenate([xs, rng.integers(0, 2 ** 32, 100_000, dtype=np.uint64).astype(np.uint32).view(f32)])
+    got = P.cosf_host(xs)
+    exp = np.array([libm.cosf(float(v)) for v in xs], dtype=f32)
+    same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
+    assert same.all(), (xs[~same][:5], got[~same][:5], exp[~same][:5])
+    assert np.isnan(P.cosf_host(np.array([np.inf, -np.inf, np.nan], dtype=f32))).all()
+
+
+def test_pattern_and_cone_boundary_errors_without_gpu():
+    pat = L.rtc_pattern()
+    a = (C.c_float * 3)(1, 1, 1)
+    assert L.lib().rtc_pattern_init(C.byref(pat), 0, a, a, None) == L.RTC_ERR_UNSUPPORTED      # NONE is not a pattern
+    assert L.lib().rtc_pattern_init(C.byref(pat), 6, a, a, None) == L.RTC_ERR_UNSUPPORTED
+    assert L.lib().rtc_pattern_init(C.byref(pat), L.RTC_PATTERN_RINGS, a, a, None) == L.RTC_OK
+    assert list(pat.inv) == list(np.eye(4, dtype=f32).reshape(-1))                               # BasePattern::default
+    m = L.rtc_material()
+    L.lib().rtc_material_default(C.byref(m))
+    assert m.pattern.kind == L.RTC_PATTERN_NONE
+    obj = L.rtc_object()
+    ident = np.eye(4, dtype=f32).reshape(-1)
+    assert L.lib().rtc_object_init(C.byref(obj), L.RTC_CONE, ident.ctypes.data_as(L.FP), None) == L.RTC_OK
+    assert obj.min_y == -np.inf and obj.max_y == np.inf and obj.closed == 0                      # cone.rs:33-42
+    assert L.lib().rtc_object_init(C.byref(obj), 5, ident.ctypes.data_as(L.FP), None) == L.RTC_ERR_UNSUPPORTED
 
 
 def _libm_powf():
