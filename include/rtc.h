@@ -10,7 +10,7 @@
  * and everything it calls per pixel (ray_for_pixel, World::color_at / intersect /
  * shade_hit / is_shadowed / reflected_color / refracted_color, the Sphere /
  * Plane / Cube / Cylinder / Cone intersectors, phong_lighting with the
- * procedural patterns of pattern/*.rs).  The reference has no
+ * procedural patterns of the pattern module).  The reference has no
  * FFI of its own; INTEGRATION.md shows the `extern "C"` block a maintainer
  * would add to camera.rs to bind these entry points.
  *

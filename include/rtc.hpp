@@ -40,7 +40,11 @@ struct Color {
 };
 inline Color color(float r, float g, float b) { return {r, g, b}; }  // color!()
 inline Color white() { return {1, 1, 1}; }                           // constants.rs:19-21
+inline Color black() { return {0, 0, 0}; }                           // constants.rs:22-24
 inline Color red() { return {1, 0, 0}; }                             // constants.rs:25-27
+inline Color yellow() { return {1, 1, 0}; }                          // constants.rs:34-36
+inline Color gray() { return {0.5f, 0.5f, 0.5f}; }                   // constants.rs:43-45
+inline Color operator/(Color c, float s) { return {c.r / s, c.g / s, c.b / s}; }  // color.rs:61-67
 
 // ---- matrix.rs / transformations.rs ----------------------------------------------------------------
 struct Matrix {
@@ -81,12 +85,45 @@ RTC_HPP_MAT(shearing, (float xy, float xz, float yx, float yz, float zx, float z
 RTC_HPP_MAT(view_transform, (Tuple from, Tuple to, Tuple up), rtc_view_transform(from.data(), to.data(), up.data(), r.m))
 #undef RTC_HPP_MAT
 
+// ---- pattern/*.rs -----------------------------------------------------------------------------------
+// A boxed Pattern: kind, the two colours (pub fields a / b as in stripes.rs:11-12) and the transform given to
+// set_transformation (pattern.rs:20-22); the inverse is taken when the material is flattened.
+struct Pattern {
+    int32_t kind;
+    Color a, b;
+    Matrix transform = identity_4x4();
+    Pattern(int32_t k, Color a_, Color b_) : kind(k), a(a_), b(b_) {}
+    void set_transformation(Matrix t) { transform = t; }
+    rtc_pattern c() const {
+        rtc_pattern p;
+        check(rtc_pattern_init(&p, kind, a.data(), b.data(), transform.m));
+        return p;
+    }
+};
+struct Stripes : Pattern {   // stripes.rs:17-31 (default: white, black)
+    Stripes(Color a_ = white(), Color b_ = black()) : Pattern(RTC_PATTERN_STRIPES, a_, b_) {}
+};
+struct Gradient : Pattern {  // gradient.rs:16-23
+    Gradient(Color a_ = white(), Color b_ = black()) : Pattern(RTC_PATTERN_GRADIENT, a_, b_) {}
+};
+struct Rings : Pattern {     // rings.rs:16-22
+    Rings(Color a_ = white(), Color b_ = black()) : Pattern(RTC_PATTERN_RINGS, a_, b_) {}
+};
+struct Checkers : Pattern {  // checkers.rs:16-22
+    Checkers(Color a_ = white(), Color b_ = black()) : Pattern(RTC_PATTERN_CHECKERS, a_, b_) {}
+};
+struct Sine2D : Pattern {    // sine_2d.rs:16-23
+    Sine2D(Color a_ = white(), Color b_ = black()) : Pattern(RTC_PATTERN_SINE2D, a_, b_) {}
+};
+
 // ---- material.rs:18-51 (TypedBuilder defaults) -------------------------------------------------------
 struct Material {
     Color color_{1, 1, 1};
     float ambient_ = 0.1f, diffuse_ = 0.9f, specular_ = 0.9f, shininess_ = 200.0f;
     float reflective_ = 0.0f, transparency_ = 0.0f, refractive_index_ = 1.0f;
+    std::shared_ptr<Pattern> pattern_;  // material.rs:50 Option<BoxedPattern>
     static Material builder() { return Material(); }
+    Material& pattern(const Pattern& p) { pattern_ = std::make_shared<Pattern>(p); return *this; }
     Material& color(Color c) { color_ = c; return *this; }
     Material& ambient(float v) { ambient_ = v; return *this; }
     Material& diffuse(float v) { diffuse_ = v; return *this; }
@@ -97,10 +134,18 @@ struct Material {
     Material& refractive_index(float v) { refractive_index_ = v; return *this; }
     Material build() const { return *this; }
     rtc_material c() const {
-        return {{color_.r, color_.g, color_.b}, ambient_, diffuse_, specular_, shininess_, reflective_, transparency_,
-                refractive_index_};
+        rtc_material m;
+        rtc_material_default(&m);
+        m.color[0] = color_.r, m.color[1] = color_.g, m.color[2] = color_.b;
+        m.ambient = ambient_, m.diffuse = diffuse_, m.specular = specular_, m.shininess = shininess_;
+        m.reflective = reflective_, m.transparency = transparency_, m.refractive_index = refractive_index_;
+        if (pattern_) m.pattern = pattern_->c();
+        return m;
     }
 };
+inline Material metal() {  // constants.rs:50-62
+    return Material::builder().color(gray()).ambient(1.0f).diffuse(0.6f).reflective(0.1f).specular(0.4f).shininess(10.0f).build();
+}
 
 // ---- shape/*.rs -----------------------------------------------------------------------------------
 struct Shape {
@@ -142,6 +187,10 @@ struct Cube : Shape {
 struct Cylinder : Shape {
     Cylinder() : Shape(RTC_CYLINDER) {}
     static Cylinder build(Matrix t, Material m) { Cylinder s; s.transform = t; s.material = m; return s; }
+};
+struct Cone : Shape {  // cone.rs:12-42: minimum_y / maximum_y / closed are pub fields, as on Cylinder
+    Cone() : Shape(RTC_CONE) {}
+    static Cone build(Matrix t, Material m) { Cone s; s.transform = t; s.material = m; return s; }
 };
 
 // ---- light/*.rs -----------------------------------------------------------------------------------
