@@ -96,6 +96,11 @@ def lib():
         L.rtco_render.restype = C.c_uint64
         L.rtco_render_rows.restype = C.c_uint64
         L.rtco_scale_color.restype = C.c_uint8
+        L.rtco_world_new_nodes.restype = C.c_void_p
+        L.rtco_node_shininess.restype = C.c_float
+        L.rtco_node_set_transformation.argtypes = [C.c_int, _FP]
+        L.rtco_node_transformation.argtypes = [C.c_int, _FP]
+        L.rtco_node_divide.argtypes = [C.c_int, C.c_uint32]
         L.rtco_to_ppm.restype = C.c_void_p
         L.rtco_jitter_hash.restype = C.c_uint32
         L.rtco_jitter_value.restype = C.c_float
@@ -494,6 +499,158 @@ def TestShape(transform=None, material=None, **kw):
 TestShape.__test__ = False
 
 
+# ---------------------------------------------------------------- bounding_box.rs
+class BoundingBox:
+    """bounding_box.rs:7-11; min / max are points (w = 1)."""
+
+    def __init__(self, mn, mx):
+        self.min, self.max = _a(mn, 4).copy(), _a(mx, 4).copy()
+
+    @staticmethod
+    def empty():
+        mn, mx = np.zeros(4, dtype=f32), np.zeros(4, dtype=f32)
+        lib().rtco_bbox_empty(_p(mn), _p(mx))
+        return BoundingBox(mn, mx)
+
+    with_bounds = staticmethod(lambda mn, mx: BoundingBox(mn, mx))
+
+    def add_point(self, p):
+        a = _a(p, 4)
+        lib().rtco_bbox_add_point(_p(self.min), _p(self.max), _p(a))
+
+    def add_bounding_box(self, other):
+        lib().rtco_bbox_add(_p(self.min), _p(self.max), _p(other.min), _p(other.max))
+
+    def contains_point(self, p):
+        a = _a(p, 4)
+        return bool(lib().rtco_bbox_contains_point(_p(self.min), _p(self.max), _p(a)))
+
+    def contains_bounding_box(self, other):
+        return bool(lib().rtco_bbox_contains(_p(self.min), _p(self.max), _p(other.min), _p(other.max)))
+
+    def transform(self, m):
+        mm, mn, mx = _a(m, 16), np.zeros(4, dtype=f32), np.zeros(4, dtype=f32)
+        lib().rtco_bbox_transform(_p(self.min), _p(self.max), _p(mm), _p(mn), _p(mx))
+        return BoundingBox(mn, mx)
+
+    def intersects(self, o, d):
+        return aabb_intersection(o, d, self.min, self.max) is not None
+
+    def split(self):
+        out = [np.zeros(4, dtype=f32) for _ in range(4)]
+        lib().rtco_bbox_split(_p(self.min), _p(self.max), *[_p(x) for x in out])
+        return BoundingBox(out[0], out[1]), BoundingBox(out[2], out[3])
+
+
+def _shape_bounds(shape, parent_space):
+    s, mn, mx = shape._c(), np.zeros(4, dtype=f32), np.zeros(4, dtype=f32)
+    lib().rtco_shape_bounding_box(C.byref(s), int(parent_space), _p(mn), _p(mx))
+    return BoundingBox(mn, mx)
+
+
+Shape.bounding_box = lambda self: _shape_bounds(self, False)
+Shape.parent_space_bounding_box = lambda self: _shape_bounds(self, True)
+
+
+# ---------------------------------------------------------------- shape/group.rs
+def _node_of(x):
+    """Arena node of a shape handed to a group (the Box<dyn Shape> moves into the tree)."""
+    if isinstance(x, (GroupShape, NodeRef)):
+        return x.node
+    if getattr(x, "_node", None) is None:
+        c = x._c()
+        x._node = int(lib().rtco_node_shape(C.byref(c)))
+    return x._node
+
+
+class NodeRef:
+    """A leaf shape living inside a group tree (what get_children() hands back)."""
+
+    is_group = False
+
+    def __init__(self, node):
+        self.node = node
+
+    def get_unique_id(self):
+        return self.node
+
+    def transformation(self):
+        out = np.zeros(16, dtype=f32)
+        lib().rtco_node_transformation(self.node, _p(out))
+        return out.reshape(4, 4)
+
+    @property
+    def shininess(self):
+        return f32(lib().rtco_node_shininess(self.node))
+
+    def world_to_object_point(self, p):
+        a, out = _a(p, 4), np.zeros(4, dtype=f32)
+        lib().rtco_node_world_to_object(self.node, _p(a), _p(out))
+        return out
+
+    def normal_at(self, p):
+        a, out = _a(p, 4), np.zeros(4, dtype=f32)
+        lib().rtco_node_normal_at(self.node, _p(a), _p(out))
+        return out
+
+    def _bbox(self, fn):
+        mn, mx = np.zeros(4, dtype=f32), np.zeros(4, dtype=f32)
+        fn(self.node, _p(mn), _p(mx))
+        return BoundingBox(mn, mx)
+
+    def bounding_box(self):
+        return self._bbox(lib().rtco_node_bounding_box)
+
+    def parent_space_bounding_box(self):
+        return self._bbox(lib().rtco_node_parent_space_bounding_box)
+
+    def set_transformation(self, t):
+        m = _a(t, 16)
+        lib().rtco_node_set_transformation(self.node, _p(m))
+
+    def set_material(self, material):
+        m = material._c()
+        lib().rtco_node_set_material(self.node, C.byref(m))
+
+    def divide(self, threshold):
+        lib().rtco_node_divide(self.node, int(threshold))
+
+    def intersect(self, o, d):
+        """Shape::intersect: [(distance, leaf NodeRef)] in push order."""
+        a, b = _a(o, 4), _a(d, 4)
+        cap = 256
+        ts, leaves = np.zeros(cap, dtype=f32), (C.c_int * cap)()
+        n = lib().rtco_node_intersect(self.node, _p(a), _p(b), _p(ts), leaves, cap)
+        return [(ts[i], NodeRef(leaves[i])) for i in range(min(n, cap))]
+
+
+class GroupShape(NodeRef):
+    """shape/group.rs: add_child / set_transformation bake the group's transform into the children."""
+
+    is_group = True
+
+    def __init__(self, node=None):
+        super().__init__(int(lib().rtco_node_group()) if node is None else node)
+
+    @staticmethod
+    def with_children(children):
+        ids = [_node_of(c) for c in children]
+        arr = (C.c_int * max(len(ids), 1))(*ids)
+        return GroupShape(int(lib().rtco_node_group_with_children(arr, len(ids))))
+
+    def add_child(self, child):
+        lib().rtco_node_add_child(self.node, _node_of(child))
+
+    def get_children(self):
+        cap = 4096
+        arr = (C.c_int * cap)()
+        n = lib().rtco_node_children(self.node, arr, cap)
+        assert n <= cap
+        return [GroupShape(arr[i]) if lib().rtco_node_is_group(arr[i]) else NodeRef(arr[i]) for i in range(n)]
+
+    local_intersect = NodeRef.intersect
+
+
 class PointLight:
     def __init__(self, position, intensity):
         self.position, self.intensity = _a(position, 4), _a(intensity, 3)
@@ -520,7 +677,8 @@ class World:
             n = len(self.objects)
             arr = (_Shape * max(n, 1))()
             for i, o in enumerate(self.objects):
-                arr[i] = o._c()
+                if not isinstance(o, NodeRef):
+                    arr[i] = o._c()
             l = _Light()
             lt = self.light
             if isinstance(lt, PointLight):
@@ -545,7 +703,11 @@ class World:
                     l.jitter_mode, l.jitter_seed = JITTER_HASHED, int(arg)
             else:
                 raise ValueError("World light should be set")  # world.rs:66
-            self._h = C.c_void_p(lib().rtco_world_new(arr, n, C.byref(l)))
+            if any(isinstance(o, NodeRef) for o in self.objects):
+                roots = [_node_of(o) for o in self.objects]
+                self._h = C.c_void_p(lib().rtco_world_new_nodes((C.c_int * len(roots))(*roots), len(roots), C.byref(l)))
+            else:
+                self._h = C.c_void_p(lib().rtco_world_new(arr, n, C.byref(l)))
         return self._h
 
     def invalidate(self):

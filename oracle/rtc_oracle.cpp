@@ -531,10 +531,222 @@ struct Light {
     std::vector<float> seq;
 };
 
+// ------------------------------------------------------------ bounding_box.rs
+struct BBox {
+    Tuple min, max;
+};
+BBox bbox_empty() {  // :13-20
+    const float inf = std::numeric_limits<float>::infinity();
+    return {point(inf, inf, inf), point(-inf, -inf, -inf)};
+}
+// :37-45.  Rust f32::min / max return the non-NaN operand, like fminf / fmaxf.
+void bbox_add_point(BBox& b, Tuple p) {
+    b.min.x = fminf(b.min.x, p.x);
+    b.min.y = fminf(b.min.y, p.y);
+    b.min.z = fminf(b.min.z, p.z);
+    b.max.x = fmaxf(b.max.x, p.x);
+    b.max.y = fmaxf(b.max.y, p.y);
+    b.max.z = fmaxf(b.max.z, p.z);
+}
+void bbox_add(BBox& b, const BBox& o) {  // :47-50
+    bbox_add_point(b, o.min);
+    bbox_add_point(b, o.max);
+}
+bool between_inclusive(float v, float lo, float hi) { return v >= lo && v <= hi; }  // :23-31
+bool bbox_contains_point(const BBox& b, Tuple p) {                                   // :52-56
+    return between_inclusive(p.x, b.min.x, b.max.x) && between_inclusive(p.y, b.min.y, b.max.y) &&
+           between_inclusive(p.z, b.min.z, b.max.z);
+}
+bool bbox_contains(const BBox& b, const BBox& o) {  // :58-60
+    return bbox_contains_point(b, o.min) && bbox_contains_point(b, o.max);
+}
+BBox bbox_transform(const BBox& b, const Matrix& m) {  // :62-79 (eight corners, full 4x4 product each)
+    BBox out = bbox_empty();
+    const Tuple ps[8] = {b.min,
+                         point(b.min.x, b.min.y, b.max.z),
+                         point(b.min.x, b.max.y, b.min.z),
+                         point(b.min.x, b.max.y, b.max.z),
+                         point(b.max.x, b.min.y, b.min.z),
+                         point(b.max.x, b.min.y, b.max.z),
+                         point(b.max.x, b.max.y, b.min.z),
+                         b.max};
+    for (const Tuple& p : ps) bbox_add_point(out, m * p);
+    return out;
+}
+bool bbox_intersects(const BBox& b, const Ray& r) {  // :81-83
+    float t0, t1;
+    return aabb_intersection(r, b.min, b.max, &t0, &t1);
+}
+void bbox_split(const BBox& b, BBox* left, BBox* right) {  // :85-113
+    float dx = b.max.x - b.min.x;
+    float dy = b.max.y - b.min.y;
+    float dz = b.max.z - b.min.z;
+    float greatest = fmaxf(fmaxf(dx, dy), dz);
+    float x0 = b.min.x, y0 = b.min.y, z0 = b.min.z;
+    float x1 = b.max.x, y1 = b.max.y, z1 = b.max.z;
+    if (greatest == dx) {
+        x0 = x0 + dx / 2.0f;
+        x1 = x0;
+    } else if (greatest == dy) {
+        y0 = y0 + dy / 2.0f;
+        y1 = y0;
+    } else {
+        z0 = z0 + dz / 2.0f;
+        z1 = z0;
+    }
+    *left = {b.min, point(x1, y1, z1)};
+    *right = {point(x0, y0, z0), b.max};
+}
+// Shape::bounding_box per kind: sphere.rs:75-80, plane.rs:61-66, cube.rs:82-87, cylinder.rs:74-79,
+// cone.rs:75-85, test_shape.rs:47-53
+BBox shape_bounding_box(const Shape& s) {
+    const float inf = std::numeric_limits<float>::infinity();
+    switch (s.kind) {
+        case RTCO_PLANE:
+            return {point(-inf, 0, -inf), point(inf, 0, inf)};
+        case RTCO_CYLINDER:
+            return {point(-1, s.min_y, -1), point(1, s.max_y, 1)};
+        case RTCO_CONE: {
+            float limit = fmaxf(std::fabs(s.min_y), std::fabs(s.max_y));
+            return {point(-limit, s.min_y, -limit), point(limit, s.max_y, limit)};
+        }
+        default:
+            return {point(-1, -1, -1), point(1, 1, 1)};
+    }
+}
+
+// ------------------------------------------------------------ shape/group.rs
+// Nodes of shape trees live in one arena; a node is a leaf (index into `leaves`) or a GroupShape.
+struct TNode {
+    bool group = false;
+    int leaf = -1;
+    Matrix t, t_inverse;  // the group's own BaseShape fields (base_shape.rs:16-17); leaves keep theirs in Shape
+    std::vector<int> children;
+    bool has_cache = false;  // cached_bounding_box: RefCell<Option<BoundingBox>>, group.rs:15 -- never invalidated
+    BBox cache;
+};
+struct Tree {
+    std::vector<Shape> leaves;
+    std::vector<TNode> nodes;
+};
+void leaf_set_transformation(Shape& sh, const Matrix& t) {  // base_shape.rs:56-60
+    sh.t = t;
+    sh.t_inverse = inverse(t);
+    sh.t_inverse_transpose = transpose(inverse(t));
+}
+const Matrix& node_transformation(const Tree& tr, int n) {
+    return tr.nodes[n].group ? tr.nodes[n].t : tr.leaves[tr.nodes[n].leaf].t;
+}
+void node_set_transformation(Tree& tr, int n, const Matrix& t) {
+    TNode& nd = tr.nodes[n];
+    if (!nd.group) {
+        leaf_set_transformation(tr.leaves[nd.leaf], t);
+        return;
+    }
+    // group.rs:101-114: re-bake the children, then store the group's own transform
+    if (!nd.children.empty()) {
+        Matrix child_transformer = t * nd.t_inverse;
+        std::vector<int> kids = nd.children;
+        for (int c : kids) {
+            Matrix old_child_transform = node_transformation(tr, c);
+            node_set_transformation(tr, c, child_transformer * old_child_transform);
+        }
+    }
+    TNode& nd2 = tr.nodes[n];
+    nd2.t = t;
+    nd2.t_inverse = inverse(t);
+}
+void group_add_child(Tree& tr, int g, int child) {  // group.rs:39-44
+    Matrix old_child_transform = node_transformation(tr, child);
+    node_set_transformation(tr, child, tr.nodes[g].t * old_child_transform);
+    tr.nodes[g].children.push_back(child);
+}
+void node_set_material(Tree& tr, int n, const Material& m) {  // group.rs:96-100; base_shape.rs:64-66
+    if (!tr.nodes[n].group) {
+        tr.leaves[tr.nodes[n].leaf].m = m;
+        return;
+    }
+    for (int c : tr.nodes[n].children) node_set_material(tr, c, m);
+}
+BBox node_parent_space_bounding_box(Tree& tr, int n);
+BBox node_bounding_box(Tree& tr, int n) {
+    TNode& nd = tr.nodes[n];
+    if (!nd.group) return shape_bounding_box(tr.leaves[nd.leaf]);
+    if (!nd.has_cache) {  // group.rs:138-151
+        BBox b = bbox_empty();
+        std::vector<int> kids = nd.children;
+        for (int c : kids) bbox_add(b, node_parent_space_bounding_box(tr, c));
+        tr.nodes[n].cache = b;
+        tr.nodes[n].has_cache = true;
+    }
+    return tr.nodes[n].cache;
+}
+BBox node_parent_space_bounding_box(Tree& tr, int n) {
+    if (tr.nodes[n].group) return node_bounding_box(tr, n);  // group.rs:153-155
+    const Shape& sh = tr.leaves[tr.nodes[n].leaf];
+    return bbox_transform(shape_bounding_box(sh), sh.t);     // shape.rs:162-164
+}
+int tree_new_group(Tree& tr) {
+    TNode nd;
+    nd.group = true;
+    nd.t = identity_4x4();
+    nd.t_inverse = identity_4x4();  // BaseShape::default(): no inversion
+    tr.nodes.push_back(nd);
+    return (int)tr.nodes.size() - 1;
+}
+void group_partition_children(Tree& tr, int g, std::vector<int>* left, std::vector<int>* right) {  // group.rs:46-64
+    BBox lb, rb;
+    bbox_split(node_bounding_box(tr, g), &lb, &rb);
+    std::vector<int> kids;
+    kids.swap(tr.nodes[g].children);
+    std::vector<int> keep;
+    for (int c : kids) {
+        BBox cb = node_parent_space_bounding_box(tr, c);
+        if (bbox_contains(lb, cb)) left->push_back(c);
+        else if (bbox_contains(rb, cb)) right->push_back(c);
+        else keep.push_back(c);
+    }
+    tr.nodes[g].children = keep;
+}
+void group_make_subgroup(Tree& tr, int g, const std::vector<int>& kids) {  // group.rs:66-73
+    if (kids.size() == 1) {
+        tr.nodes[g].children.push_back(kids[0]);
+    } else {
+        int sub = tree_new_group(tr);  // GroupShape::with_children: identity transform, nothing re-baked
+        tr.nodes[sub].children = kids;
+        tr.nodes[g].children.push_back(sub);
+    }
+}
+void node_divide(Tree& tr, int n, size_t threshold) {  // group.rs:157-172; shape.rs:167 (no-op for leaves)
+    if (!tr.nodes[n].group) return;
+    if (threshold <= tr.nodes[n].children.size()) {
+        std::vector<int> left, right;
+        group_partition_children(tr, n, &left, &right);
+        if (!left.empty()) group_make_subgroup(tr, n, left);
+        if (!right.empty()) group_make_subgroup(tr, n, right);
+    }
+    std::vector<int> kids = tr.nodes[n].children;
+    for (int c : kids) node_divide(tr, c, threshold);
+}
+// Shape::intersect for a node: group.rs:115-133 (the ray is NOT transformed: transforms are baked into
+// the children) / shape.rs:67-70
+void node_intersect(Tree& tr, int n, const Ray& r, std::vector<Intersection>& out) {
+    if (!tr.nodes[n].group) {
+        shape_intersect(tr.leaves[tr.nodes[n].leaf], r, out, nullptr);
+        return;
+    }
+    BBox b = node_bounding_box(tr, n);
+    if (!bbox_intersects(b, r)) return;
+    std::vector<int> kids = tr.nodes[n].children;
+    for (int c : kids) node_intersect(tr, c, r, out);
+}
+
 }  // namespace
 
 struct rtco_world {
-    std::vector<Shape> objects;
+    std::vector<Shape> objects;  // every leaf shape; Intersection.object indexes this
+    Tree tree;                   // used when `roots` is non-empty: World.objects = the root nodes (leaves or groups)
+    std::vector<int> roots;
     Light light;
     // jitter state
     size_t seq_cursor = 0;
@@ -573,7 +785,11 @@ Tuple point_on_light(World& w, int u, int v, uint32_t path) {
 std::vector<Intersection> intersect(World& w, const Ray& r) {
     w.rays++;
     std::vector<Intersection> xs;
-    for (const Shape& o : w.objects) shape_intersect(o, r, xs);
+    if (w.roots.empty()) {
+        for (const Shape& o : w.objects) shape_intersect(o, r, xs);
+    } else {
+        for (int n : w.roots) node_intersect(w.tree, n, r, xs);
+    }
     std::stable_sort(xs.begin(), xs.end(),
                      [](const Intersection& a, const Intersection& b) { return a.distance < b.distance; });
     return xs;
@@ -859,6 +1075,7 @@ uint64_t render_rows_serial(World& w, const Camera& c, int depth, uint32_t y0, u
 }  // namespace
 
 extern "C" {
+static void fill_light(rtco_world* w, const rtco_light* light);
 
 float rtco_magnitude(const float v[4]) { return magnitude(T(v)); }
 void rtco_norm(const float v[4], float out[4]) { put(norm(T(v)), out); }
@@ -947,6 +1164,10 @@ int rtco_hit(const float* ts, int n) {
 rtco_world* rtco_world_new(const rtco_shape* shapes, int n, const rtco_light* light) {
     rtco_world* w = new rtco_world();
     for (int i = 0; i < n; i++) w->objects.push_back(shape_from(shapes[i], i));
+    fill_light(w, light);
+    return w;
+}
+static void fill_light(rtco_world* w, const rtco_light* light) {
     Light& l = w->light;
     l.kind = light->kind;
     l.intensity = {light->intensity[0], light->intensity[1], light->intensity[2]};
@@ -970,8 +1191,119 @@ rtco_world* rtco_world_new(const rtco_shape* shapes, int n, const rtco_light* li
         if (light->jitter_seq && light->jitter_seq_len > 0)
             l.seq.assign(light->jitter_seq, light->jitter_seq + light->jitter_seq_len);
     }
+}
+// ---- shape trees (shape/group.rs).  One process-wide arena: this is test infrastructure. ----
+static Tree g_arena;
+
+int rtco_node_shape(const rtco_shape* s) {  // Shape::new() + set_transformation + set_material + pub fields
+    Shape sh = shape_from(*s, (int)g_arena.leaves.size());
+    g_arena.leaves.push_back(sh);
+    TNode nd;
+    nd.leaf = sh.id;
+    g_arena.nodes.push_back(nd);
+    return (int)g_arena.nodes.size() - 1;
+}
+int rtco_node_group(void) { return tree_new_group(g_arena); }                        // GroupShape::new()
+int rtco_node_group_with_children(const int* children, int n) {                      // group.rs:23-27
+    int g = tree_new_group(g_arena);
+    g_arena.nodes[g].children.assign(children, children + n);
+    return g;
+}
+void rtco_node_add_child(int group, int child) { group_add_child(g_arena, group, child); }
+void rtco_node_set_transformation(int node, const float t[16]) { node_set_transformation(g_arena, node, mat_from(t, 4)); }
+void rtco_node_set_material(int node, const rtco_material* m) { node_set_material(g_arena, node, material_from(*m)); }
+void rtco_node_divide(int node, uint32_t threshold) { node_divide(g_arena, node, threshold); }
+int rtco_node_is_group(int node) { return g_arena.nodes[node].group ? 1 : 0; }
+int rtco_node_children(int node, int* out, int cap) {
+    const std::vector<int>& c = g_arena.nodes[node].children;
+    for (int i = 0; i < (int)c.size() && i < cap; i++) out[i] = c[i];
+    return (int)c.size();
+}
+void rtco_node_transformation(int node, float out[16]) { mat_to(node_transformation(g_arena, node), out); }
+float rtco_node_shininess(int node) { return g_arena.leaves[g_arena.nodes[node].leaf].m.shininess; }
+void rtco_node_bounding_box(int node, float mn[4], float mx[4]) {
+    BBox b = node_bounding_box(g_arena, node);
+    put(b.min, mn);
+    put(b.max, mx);
+}
+void rtco_node_parent_space_bounding_box(int node, float mn[4], float mx[4]) {
+    BBox b = node_parent_space_bounding_box(g_arena, node);
+    put(b.min, mn);
+    put(b.max, mx);
+}
+// Shape::intersect on a node (group.rs:115-133): distances in push order + the leaf node each belongs to
+int rtco_node_intersect(int node, const float o[4], const float d[4], float* ts, int* leaf_nodes, int cap) {
+    std::vector<Intersection> xs;
+    node_intersect(g_arena, node, ray_new(T(o), T(d)), xs);
+    for (int i = 0; i < (int)xs.size() && i < cap; i++) {
+        ts[i] = xs[i].distance;
+        int found = -1;
+        for (int k = 0; k < (int)g_arena.nodes.size(); k++)
+            if (!g_arena.nodes[k].group && g_arena.nodes[k].leaf == xs[i].object) found = k;
+        leaf_nodes[i] = found;
+    }
+    return (int)xs.size();
+}
+void rtco_node_world_to_object(int node, const float p[4], float out[4]) {  // shape.rs:57-61
+    put(g_arena.leaves[g_arena.nodes[node].leaf].t_inverse * T(p), out);
+}
+void rtco_node_normal_at(int node, const float p[4], float out[4]) {
+    put(normal_at(g_arena.leaves[g_arena.nodes[node].leaf], T(p)), out);
+}
+// World { objects: roots, light }: the arena's state is copied, so later edits do not reach this world
+rtco_world* rtco_world_new_nodes(const int* roots, int n, const rtco_light* light) {
+    rtco_world* w = new rtco_world();
+    w->tree = g_arena;
+    w->objects = g_arena.leaves;
+    w->roots.assign(roots, roots + n);
+    fill_light(w, light);
     return w;
 }
+/* ---- bounding_box.rs ---- */
+void rtco_bbox_add(float mn[4], float mx[4], const float omn[4], const float omx[4]) {
+    BBox b = {T(mn), T(mx)};
+    bbox_add(b, {T(omn), T(omx)});
+    put(b.min, mn);
+    put(b.max, mx);
+}
+void rtco_bbox_add_point(float mn[4], float mx[4], const float p[4]) {
+    BBox b = {T(mn), T(mx)};
+    bbox_add_point(b, T(p));
+    put(b.min, mn);
+    put(b.max, mx);
+}
+void rtco_bbox_empty(float mn[4], float mx[4]) {
+    BBox b = bbox_empty();
+    put(b.min, mn);
+    put(b.max, mx);
+}
+int rtco_bbox_contains_point(const float mn[4], const float mx[4], const float p[4]) {
+    return bbox_contains_point({T(mn), T(mx)}, T(p)) ? 1 : 0;
+}
+int rtco_bbox_contains(const float mn[4], const float mx[4], const float omn[4], const float omx[4]) {
+    return bbox_contains({T(mn), T(mx)}, {T(omn), T(omx)}) ? 1 : 0;
+}
+void rtco_bbox_transform(const float mn[4], const float mx[4], const float m[16], float omn[4], float omx[4]) {
+    BBox b = bbox_transform({T(mn), T(mx)}, mat_from(m, 4));
+    put(b.min, omn);
+    put(b.max, omx);
+}
+void rtco_bbox_split(const float mn[4], const float mx[4], float lmn[4], float lmx[4], float rmn[4], float rmx[4]) {
+    BBox l, r;
+    bbox_split({T(mn), T(mx)}, &l, &r);
+    put(l.min, lmn);
+    put(l.max, lmx);
+    put(r.min, rmn);
+    put(r.max, rmx);
+}
+void rtco_shape_bounding_box(const rtco_shape* s, int parent_space, float mn[4], float mx[4]) {
+    Shape sh = shape_from(*s, 0);
+    BBox b = shape_bounding_box(sh);
+    if (parent_space) b = bbox_transform(b, sh.t);
+    put(b.min, mn);
+    put(b.max, mx);
+}
+
 void rtco_world_free(rtco_world* w) { delete w; }
 void rtco_world_set_pixel(rtco_world* w, uint32_t pixel_index) { w->pixel = pixel_index; }
 uint64_t rtco_world_ray_count(const rtco_world* w) { return w->rays; }

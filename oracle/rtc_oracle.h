@@ -142,6 +142,34 @@ int rtco_hit(const float* ts, int n);
 /* ---- world.rs / lights ---- */
 rtco_world* rtco_world_new(const rtco_shape* shapes, int n, const rtco_light* light);
 void rtco_world_free(rtco_world* w);
+
+/* ---- shape/group.rs + bounding_box.rs.  Nodes (leaf shapes and GroupShapes) live in one process-wide
+ * arena and are addressed by integer ids; the functions restate the reference methods of the same name. ---- */
+int rtco_node_shape(const rtco_shape* s);
+int rtco_node_group(void);                                        /* GroupShape::new(), group.rs:19-21 */
+int rtco_node_group_with_children(const int* children, int n);    /* group.rs:23-27 (nothing re-baked) */
+void rtco_node_add_child(int group, int child);                   /* group.rs:39-44 */
+void rtco_node_set_transformation(int node, const float t[16]);   /* group.rs:101-114 / base_shape.rs:56-60 */
+void rtco_node_set_material(int node, const rtco_material* m);    /* group.rs:96-100 */
+void rtco_node_divide(int node, uint32_t threshold);              /* group.rs:157-172 */
+int rtco_node_is_group(int node);
+int rtco_node_children(int node, int* out, int cap);
+void rtco_node_transformation(int node, float out[16]);
+float rtco_node_shininess(int node);
+void rtco_node_bounding_box(int node, float mn[4], float mx[4]);               /* group.rs:138-151 (cached) */
+void rtco_node_parent_space_bounding_box(int node, float mn[4], float mx[4]);  /* shape.rs:162-164 / group.rs:153-155 */
+int rtco_node_intersect(int node, const float o[4], const float d[4], float* ts, int* leaf_nodes, int cap);
+void rtco_node_world_to_object(int node, const float p[4], float out[4]);
+void rtco_node_normal_at(int node, const float p[4], float out[4]);
+rtco_world* rtco_world_new_nodes(const int* roots, int n, const rtco_light* light);
+void rtco_bbox_empty(float mn[4], float mx[4]);
+void rtco_bbox_add_point(float mn[4], float mx[4], const float p[4]);
+void rtco_bbox_add(float mn[4], float mx[4], const float omn[4], const float omx[4]);
+int rtco_bbox_contains_point(const float mn[4], const float mx[4], const float p[4]);
+int rtco_bbox_contains(const float mn[4], const float mx[4], const float omn[4], const float omx[4]);
+void rtco_bbox_transform(const float mn[4], const float mx[4], const float m[16], float omn[4], float omx[4]);
+void rtco_bbox_split(const float mn[4], const float mx[4], float lmn[4], float lmx[4], float rmn[4], float rmx[4]);
+void rtco_shape_bounding_box(const rtco_shape* s, int parent_space, float mn[4], float mx[4]);
 void rtco_world_set_pixel(rtco_world* w, uint32_t pixel_index); /* key for hashed jitter */
 uint64_t rtco_world_ray_count(const rtco_world* w);
 void rtco_world_shape_inverse(const rtco_world* w, int i, float inv[16], float inv_t[16]);

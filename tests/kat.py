@@ -16,6 +16,7 @@ CONSTS = {
     "FRAC_PI_2": f32(1.57079632679489661923132169163975144),
     "FRAC_PI_4": f32(0.785398163397448309615660845819875721),
 }
+CONSTS["INF"] = f32(np.inf)
 CONSTS["sqrt14"] = np.sqrt(f32(14.0))
 CONSTS["0.1+0.9*FRAC_1_SQRT_2"] = f32(0.1) + f32(0.9) * CONSTS["FRAC_1_SQRT_2"]
 

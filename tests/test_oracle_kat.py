@@ -442,3 +442,172 @@ def test_refracted_color_with_refracted_ray(kat):  # world.rs:716-744
     w.objects[1].material = w.objects[1].material.copy(transparency=1.0, refractive_index=1.5)
     comps = w.precompute_values(K.point(c["ray"][0]), K.vector(c["ray"][1]), c["hit_index"], [tuple(x) for x in c["xs"]])
     K.assert_eps(w.refracted_color(comps, c["depth"]), c["expect_eps"])
+
+
+# ----------------------------------------------------------- bounding_box.rs / shape/group.rs
+def _box(pair):
+    return O.BoundingBox(K.point(pair[0]), K.point(pair[1]))
+
+
+def test_bounding_box(kat):  # bounding_box.rs:136-288
+    B = kat["bounding_box"]
+    c = B["add_points"]
+    b = O.BoundingBox.empty()
+    for p in c["points"]:
+        b.add_point(K.point(p))
+    K.assert_exact(b.min, K.point(c["min"]))
+    K.assert_exact(b.max, K.point(c["max"]))
+    c = B["add_box"]
+    b = _box(c["box1"])
+    b.add_bounding_box(_box(c["box2"]))
+    K.assert_exact(b.min, K.point(c["min"]))
+    K.assert_exact(b.max, K.point(c["max"]))
+    c = B["contains_point"]
+    for p, expect in c["cases"]:
+        assert _box(c["box"]).contains_point(K.point(p)) == expect, p
+    c = B["contains_box"]
+    for mn, mx, expect in c["cases"]:
+        assert _box(c["box"]).contains_bounding_box(_box([mn, mx])) == expect, (mn, mx)
+    c = B["transform"]
+    b2 = _box(c["box"]).transform(O.mat_mul(O.rotation_x(K.CONSTS["PI"] / f32(4.0)), O.rotation_y(K.CONSTS["PI"] / f32(4.0))))
+    K.assert_eps(b2.min[:3], c["min_eps"])
+    K.assert_eps(b2.max[:3], c["max_eps"])
+    for c in B["split"]["cases"]:
+        left, right = _box(c["box"]).split()
+        K.assert_exact(left.min, K.point(c["left"][0]))
+        K.assert_exact(left.max, K.point(c["left"][1]))
+        K.assert_exact(right.min, K.point(c["right"][0]))
+        K.assert_exact(right.max, K.point(c["right"][1]))
+    # the same ray tables as cube's aabb_intersection (bounding_box.rs:199-247)
+    for key in ("at_origin", "off_origin"):
+        blk = kat["aabb"][key]
+        b = O.BoundingBox(K.point(blk["min"]), K.point(blk["max"]))
+        for o, d, expected in blk["cases"]:
+            assert b.intersects(K.point(o), O.norm(K.vector(d))) == expected
+    c = B["shape_in_parent_space"]
+    b = O.Sphere(O.mat_mul(O.translation(1.0, -3.0, 5.0), O.scaling(0.5, 2.0, 4.0))).parent_space_bounding_box()
+    K.assert_exact(b.min, K.point(c["min"]))
+    K.assert_exact(b.max, K.point(c["max"]))
+    c = B["cone_unbounded"]
+    b = O.Cone().bounding_box()
+    K.assert_exact(b.min, K.point(c["min"]))
+    K.assert_exact(b.max, K.point(c["max"]))
+    c = B["cone_bounded"]
+    b = O.Cone(minimum_y=c["min_y"], maximum_y=c["max_y"]).bounding_box()
+    K.assert_exact(b.min, K.point(c["min"]))
+    K.assert_exact(b.max, K.point(c["max"]))
+
+
+def test_group_transform_baking(kat):  # shape/group.rs:216-340
+    G = kat["group"]
+    g = O.GroupShape.with_children([O.Sphere(), O.Sphere(), O.Sphere()])
+    g.set_material(O.Material(shininess=123.456))
+    assert [c.shininess for c in g.get_children()] == [f32(123.456)] * 3
+    assert O.GroupShape().local_intersect(O.point(0, 0, 0), O.vector(0, 0, 1)) == []
+    c = G["nonempty_group"]
+    s1, s2, s3 = O.Sphere(), O.Sphere(O.translation(0.0, 0.0, -3.0)), O.Sphere(O.translation(5.0, 0.0, 0.0))
+    g = O.GroupShape()
+    for s in (s1, s2, s3):
+        g.add_child(s)
+    xs = sorted(g.local_intersect(K.point(c["ray"][0]), K.vector(c["ray"][1])), key=lambda x: x[0])
+    assert len(xs) == c["hits"]
+    assert [x[1].node for x in xs] == [s2._node, s2._node, s1._node, s1._node]
+    c = G["baked_child_transform"]
+    expect = K.mat(c["expect_exact"])
+
+    def check(g):
+        K.assert_exact(g.get_children()[0].transformation(), expect)
+        assert len(g.intersect(K.point(c["ray"][0]), K.vector(c["ray"][1]))) == c["hits"]
+    g = O.GroupShape()
+    g.set_transformation(O.scaling(2.0, 2.0, 2.0))
+    g.add_child(O.Sphere(O.translation(5.0, 0.0, 0.0)))
+    check(g)
+    g = O.GroupShape()
+    g.add_child(O.Sphere(O.translation(5.0, 0.0, 0.0)))
+    g.set_transformation(O.scaling(2.0, 2.0, 2.0))
+    check(g)
+    g = O.GroupShape()
+    g.set_transformation(O.scaling(3.0, 4.0, 8.0))
+    g.add_child(O.Sphere(O.translation(5.0, 0.0, 0.0)))
+    g.set_transformation(O.scaling(2.0, 2.0, 2.0))
+    check(g)
+
+
+def _nested(api):
+    g1 = api.GroupShape()
+    g1.set_transformation(api.rotation_y(K.CONSTS["PI"] / f32(2.0)))
+    g2 = api.GroupShape()
+    g2.set_transformation(api.scaling(1.0, 2.0, 3.0))
+    g2.add_child(api.Sphere(api.translation(5.0, 0.0, 0.0)))
+    g1.add_child(g2)
+    return g1
+
+
+def test_group_child_spaces_and_bounds(kat):  # shape/group.rs:342-455, shape/shape.rs:253-276
+    G = kat["group"]
+    s = _nested(O).get_children()[0].get_children()[0]
+    K.assert_eps(s.world_to_object_point(K.point(G["world_to_object"]["point"])), G["world_to_object"]["expect_eps"])
+    K.assert_eps(s.normal_at(K.point(G["normal_on_child"]["point"])), G["normal_on_child"]["expect_eps"])
+    c = G["bounding_box_contains_children"]
+    g = O.GroupShape()
+    g.add_child(O.Sphere(O.mat_mul(O.translation(2.0, 5.0, -3.0), O.scaling(2.0, 2.0, 2.0))))
+    g.add_child(O.Cylinder(O.mat_mul(O.translation(-4.0, -1.0, 4.0), O.scaling(0.5, 1.0, 0.5)), minimum_y=-2.0, maximum_y=2.0))
+    b = g.bounding_box()
+    K.assert_exact(b.min, K.point(c["min"]))
+    K.assert_exact(b.max, K.point(c["max"]))
+    g = O.GroupShape()
+    g.add_child(O.Sphere(O.scaling(2.0, 2.0, 2.0)))
+    g.add_child(O.Cylinder(O.scaling(2.0, 2.0, 2.0), minimum_y=-1.0, maximum_y=1.0))
+    g.set_transformation(O.scaling(0.5, 0.5, 0.5))
+    b1, b2 = g.bounding_box(), g.parent_space_bounding_box()
+    assert np.array_equal(b1.min, b2.min) and np.array_equal(b1.max, b2.max)
+    # the box gates the children (:432-455): a test shape's unit box, missed and hit
+    g = O.GroupShape()
+    g.add_child(O.Sphere())
+    assert g.intersect(O.point(0, 0, -5), O.vector(0, 1, 0)) == []
+    assert len(g.intersect(O.point(0, 0, -5), O.vector(0, 0, 1))) == 2
+
+
+def test_group_divide(kat):  # shape/group.rs:458-639
+    G = kat["group"]
+    s1, s2, s3 = O.Sphere(O.translation(-2.0, -2.0, 0.0)), O.Sphere(O.translation(-2.0, 2.0, 0.0)), O.Sphere(O.scaling(4.0, 4.0, 4.0))
+    g = O.GroupShape()
+    for s in (s1, s2, s3):
+        g.add_child(s)
+    g.divide(1)
+    ch = g.get_children()
+    assert ch[0].node == s3._node and ch[1].is_group
+    assert [c.node for c in ch[1].get_children()] == [s1._node, s2._node]
+    # partitioning_children (:458-489) seen through divide(3): left / right singletons are pushed back as themselves
+    s1, s2, s3 = O.Sphere(O.translation(-2.0, 0.0, 0.0)), O.Sphere(O.translation(2.0, 0.0, 0.0)), O.Sphere()
+    g = O.GroupShape()
+    for s in (s1, s2, s3):
+        g.add_child(s)
+    g.divide(3)
+    assert [c.node for c in g.get_children()] == [s3._node, s1._node, s2._node]
+    # subdividing_group_with_too_few_children (:551-604)
+    s1, s2, s3, s4 = (O.Sphere(O.translation(-2.0, 0.0, 0.0)), O.Sphere(O.translation(2.0, 1.0, 0.0)),
+                      O.Sphere(O.translation(2.0, -1.0, 0.0)), O.Sphere())
+    sub = O.GroupShape()
+    for s in (s1, s2, s3):
+        sub.add_child(s)
+    g = O.GroupShape()
+    g.add_child(sub)
+    g.add_child(s4)
+    g.divide(3)
+    ch = g.get_children()
+    assert ch[0].node == sub.node and ch[1].node == s4._node
+    sc = ch[0].get_children()
+    assert sc[0].node == s1._node and [c.node for c in sc[1].get_children()] == [s2._node, s3._node]
+    # divide_preserves_pushed_down_transformation (:607-639)
+    c = G["divide_preserves_transformation"]
+    group = O.GroupShape()
+    group.set_transformation(O.translation(1.0, 1.0, 0.0))
+    for t in ((-2.0, 0.0, 0.0), (2.0, -1.0, 0.0), (2.0, 1.0, 0.0)):
+        group.add_child(O.Sphere(O.translation(*t)))
+    group.divide(2)
+    ch = group.get_children()
+    K.assert_exact(ch[0].transformation(), O.translation(*c["s1"]))
+    sub = ch[1].get_children()
+    K.assert_exact(sub[0].transformation(), O.translation(*c["s2"]))
+    K.assert_exact(sub[1].transformation(), O.translation(*c["s3"]))
