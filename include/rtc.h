@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTC_ABI_VERSION 2
+#define RTC_ABI_VERSION 3
 /* maximum reflection_recursion_depth accepted (reference default: 5, constants.rs:4) */
 #define RTC_MAX_DEPTH 8
 
@@ -112,11 +112,26 @@ typedef struct rtc_light {
     uint32_t jitter_seed;
 } rtc_light;
 
+/* One GroupShape (shape/group.rs:12-16) of the flattened world.  add_child / set_transformation bake a
+ * group's transform into its children (group.rs:39-44,101-114) and Shape::intersect on a group does not
+ * transform the ray (:115-117), so a tree of groups flattens to its leaf shapes -- listed in `objects` in
+ * depth-first order, which is the order the reference's child loops push intersections in -- plus, per
+ * group, the contiguous run of leaves under it and the bounding box that gates them (:119-133).
+ * Groups are listed in pre-order (a group before the groups nested inside it); runs nest properly. */
+typedef struct rtc_group {
+    uint32_t first_object;
+    uint32_t n_objects;   /* 0: an empty group (never hit; ignored) */
+    float bounds_min[3];  /* GroupShape::bounding_box(), group.rs:138-151 (world space) */
+    float bounds_max[3];
+} rtc_group;
+
 /* world.rs:18-21 */
 typedef struct rtc_scene {
     uint32_t n_objects;
     const rtc_object* objects;
     const rtc_light* light; /* NULL -> RTC_ERR_NO_LIGHT */
+    uint32_t n_groups;      /* 0: World.objects is a flat list of shapes */
+    const rtc_group* groups;
 } rtc_scene;
 
 /* camera.rs:8-21 after Camera::new.  Build with rtc_camera_new(). */
@@ -186,6 +201,20 @@ rtc_status rtc_pattern_init(rtc_pattern* out, int32_t kind, const float a[3], co
 /* Shape::build(transform, material): stores transform.inverse() (base_shape.rs:56-60).
  * Cylinder / Cone bounds default to -inf/+inf, open (cylinder.rs:34-43, cone.rs:33-42). */
 rtc_status rtc_object_init(rtc_object* out, int32_t kind, const float transform[16], const rtc_material* m);
+/* bounding_box.rs, operation for operation (f32::min / max ignore a NaN operand; points carry w = 1).
+ * Host-side helpers for building rtc_group records the way GroupShape::bounding_box / divide do. */
+void rtc_bounds_empty(float mn[4], float mx[4]);                                                  /* :13-20  */
+void rtc_bounds_add(float mn[4], float mx[4], const float other_mn[4], const float other_mx[4]);  /* :37-50  */
+int32_t rtc_bounds_contains(const float mn[4], const float mx[4], const float other_mn[4],
+                            const float other_mx[4]);                                             /* :52-60  */
+void rtc_bounds_transform(const float mn[4], const float mx[4], const float m[16], float out_mn[4],
+                          float out_mx[4]);                                                       /* :62-79  */
+void rtc_bounds_split(const float mn[4], const float mx[4], float left_mn[4], float left_mx[4],
+                      float right_mn[4], float right_mx[4]);                                      /* :85-113 */
+/* Shape::bounding_box (sphere.rs:75-80, plane.rs:61-66, cube.rs:82-87, cylinder.rs:74-79, cone.rs:75-85);
+ * with transform != NULL, Shape::parent_space_bounding_box (shape.rs:162-164) for that transformation(). */
+rtc_status rtc_shape_bounds(int32_t kind, float min_y, float max_y, const float transform[16], float mn[4],
+                            float mx[4]);
 void rtc_point_light(const float position[4], const float intensity[3], rtc_light* out);   /* point_light.rs:12-19 */
 rtc_status rtc_rectangle_light(const float intensity[3], const float corner[4], const float u_vec[4],
                                int32_t u_steps, const float v_vec[4], int32_t v_steps, int32_t jitter_mode,

@@ -47,9 +47,14 @@ class rtc_light(C.Structure):
                 ("jitter_const", C.c_float), ("jitter_seed", C.c_uint32)]
 
 
+class rtc_group(C.Structure):
+    _fields_ = [("first_object", C.c_uint32), ("n_objects", C.c_uint32), ("bounds_min", C.c_float * 3),
+                ("bounds_max", C.c_float * 3)]
+
+
 class rtc_scene(C.Structure):
     _fields_ = [("n_objects", C.c_uint32), ("objects", C.POINTER(rtc_object)),
-                ("light", C.POINTER(rtc_light))]
+                ("light", C.POINTER(rtc_light)), ("n_groups", C.c_uint32), ("groups", C.POINTER(rtc_group))]
 
 
 class rtc_camera(C.Structure):
@@ -92,6 +97,12 @@ SIGNATURES = {
     "rtc_material_default": (None, [C.POINTER(rtc_material)]),
     "rtc_pattern_init": (C.c_int, [C.POINTER(rtc_pattern), C.c_int32, FP, FP, FP]),
     "rtc_object_init": (C.c_int, [C.POINTER(rtc_object), C.c_int32, FP, C.POINTER(rtc_material)]),
+    "rtc_bounds_empty": (None, [FP, FP]),
+    "rtc_bounds_add": (None, [FP, FP, FP, FP]),
+    "rtc_bounds_contains": (C.c_int32, [FP, FP, FP, FP]),
+    "rtc_bounds_transform": (None, [FP, FP, FP, FP, FP]),
+    "rtc_bounds_split": (None, [FP, FP, FP, FP, FP, FP]),
+    "rtc_shape_bounds": (C.c_int, [C.c_int32, C.c_float, C.c_float, FP, FP, FP]),
     "rtc_point_light": (None, [FP, FP, C.POINTER(rtc_light)]),
     "rtc_rectangle_light": (C.c_int, [FP, FP, FP, C.c_int32, FP, C.c_int32, C.c_int32, C.c_float, C.c_uint32,
                                       C.POINTER(rtc_light)]),

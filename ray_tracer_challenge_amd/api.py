@@ -356,6 +356,155 @@ def Cylinder(transform=None, material=None, **kw):
     return Shape(L.RTC_CYLINDER, transform, material, **kw)
 
 
+# ------------------------------------------------- bounding_box.rs / shape/group.rs
+class BoundingBox:
+    """bounding_box.rs:7-11 over the library's host helpers (rtc_bounds_*)."""
+
+    def __init__(self, mn, mx):
+        self.min, self.max = _a(mn, 4).copy(), _a(mx, 4).copy()
+
+    @staticmethod
+    def empty():
+        mn, mx = np.zeros(4, dtype=f32), np.zeros(4, dtype=f32)
+        L.lib().rtc_bounds_empty(_p(mn), _p(mx))
+        return BoundingBox(mn, mx)
+
+    @staticmethod
+    def with_bounds(mn, mx):
+        return BoundingBox(mn, mx)
+
+    def add_bounding_box(self, other):
+        L.lib().rtc_bounds_add(_p(self.min), _p(self.max), _p(other.min), _p(other.max))
+
+    def contains_bounding_box(self, other):
+        return bool(L.lib().rtc_bounds_contains(_p(self.min), _p(self.max), _p(other.min), _p(other.max)))
+
+    def transform(self, m):
+        mm, mn, mx = _a(m, 16), np.zeros(4, dtype=f32), np.zeros(4, dtype=f32)
+        L.lib().rtc_bounds_transform(_p(self.min), _p(self.max), _p(mm), _p(mn), _p(mx))
+        return BoundingBox(mn, mx)
+
+    def split(self):
+        out = [np.zeros(4, dtype=f32) for _ in range(4)]
+        L.lib().rtc_bounds_split(_p(self.min), _p(self.max), *[_p(x) for x in out])
+        return BoundingBox(out[0], out[1]), BoundingBox(out[2], out[3])
+
+
+def _shape_bounds(shape, parent_space):
+    mn, mx = np.zeros(4, dtype=f32), np.zeros(4, dtype=f32)
+    t = _a(shape.transform, 16) if parent_space else None
+    L.check(L.lib().rtc_shape_bounds(shape.kind, float(f32(shape.minimum_y)), float(f32(shape.maximum_y)),
+                                     _p(t) if t is not None else None, _p(mn), _p(mx)))
+    return BoundingBox(mn, mx)
+
+
+# Shape::bounding_box / parent_space_bounding_box (shape.rs:23,162-164); divide is a no-op for leaves (:167)
+Shape.bounding_box = lambda self: _shape_bounds(self, False)
+Shape.parent_space_bounding_box = lambda self: _shape_bounds(self, True)
+Shape.divide = lambda self, threshold: None
+Shape.transformation = lambda self: self.transform
+
+
+class GroupShape:
+    """shape/group.rs.  add_child / set_transformation bake the group's transform into the children, so a world
+    with groups flattens to its leaf shapes plus one bounding box per group (what the device path consumes)."""
+
+    def __init__(self):
+        self.transform = identity_4x4()
+        self._t_inverse = identity_4x4()  # BaseShape::default(): not an inversion
+        self.children = []
+        self._cached_box = None           # cached_bounding_box (:15): filled on first use, never invalidated
+
+    @staticmethod
+    def with_children(children):
+        """group.rs:23-27: adopts the children as they are (nothing is re-baked)."""
+        g = GroupShape()
+        g.children = list(children)
+        return g
+
+    def get_children(self):
+        return self.children
+
+    def transformation(self):
+        return self.transform
+
+    def add_child(self, child):
+        """group.rs:39-44"""
+        old_child_transform = child.transformation().copy()
+        child.set_transformation(mat_mul(self.transform, old_child_transform))
+        self.children.append(child)
+
+    def set_transformation(self, t):
+        """group.rs:101-114"""
+        t = np.asarray(t, dtype=f32).reshape(4, 4)
+        if self.children:
+            child_transformer = mat_mul(t, self._t_inverse)
+            for c in self.children:
+                old_child_transform = c.transformation().copy()
+                c.set_transformation(mat_mul(child_transformer, old_child_transform))
+        self.transform = t.copy()
+        self._t_inverse = inverse(t)
+
+    def set_material(self, m):
+        """group.rs:96-100"""
+        for c in self.children:
+            c.set_material(m.copy())
+
+    def set_casts_shadow(self, flag):
+        raise NotImplementedError("GroupShape has no shadow flag of its own; set it on the leaves")
+
+    def bounding_box(self):
+        """group.rs:138-151"""
+        if self._cached_box is None:
+            b = BoundingBox.empty()
+            for child in self.children:
+                b.add_bounding_box(child.parent_space_bounding_box())
+            self._cached_box = b
+        return self._cached_box
+
+    def parent_space_bounding_box(self):
+        return self.bounding_box()  # group.rs:153-155
+
+    def _partition_children(self):
+        """group.rs:46-64"""
+        left_bounds, right_bounds = self.bounding_box().split()
+        left, right, keep = [], [], []
+        for c in self.children:
+            child_bounds = c.parent_space_bounding_box()
+            if left_bounds.contains_bounding_box(child_bounds):
+                left.append(c)
+            elif right_bounds.contains_bounding_box(child_bounds):
+                right.append(c)
+            else:
+                keep.append(c)
+        self.children = keep
+        return left, right
+
+    def _make_subgroup(self, new_group_children):
+        """group.rs:66-73"""
+        if len(new_group_children) == 1:
+            self.children.append(new_group_children[0])
+        else:
+            self.children.append(GroupShape.with_children(new_group_children))
+
+    def divide(self, threshold):
+        """group.rs:157-172"""
+        if threshold <= len(self.children):
+            left, right = self._partition_children()
+            if left:
+                self._make_subgroup(left)
+            if right:
+                self._make_subgroup(right)
+        for child in self.children:
+            child.divide(threshold)
+
+    def leaves(self):
+        out = []
+        for c in self.children:
+            out.extend(c.leaves() if isinstance(c, GroupShape) else [c])
+        return out
+
+
 def Cone(transform=None, material=None, **kw):
     """Cone::build; minimum_y / maximum_y / closed are its pub fields (shape/cone.rs:12-17)"""
     return Shape(L.RTC_CONE, transform, material, **kw)
@@ -424,18 +573,40 @@ class RectangleLight:
 
 # --------------------------------------------------------------------- world.rs
 class _CScene:
-    """Keeps the ctypes arrays alive for the lifetime of a call."""
+    """Keeps the ctypes arrays alive for the lifetime of a call.  World.objects may hold GroupShapes: the tree is
+    written out as its leaves in depth-first order plus one rtc_group (leaf run + bounding box) per group."""
 
     def __init__(self, world):
-        n = len(world.objects)
+        leaves, groups = [], []
+
+        def walk(node):
+            if isinstance(node, GroupShape):
+                rec = L.rtc_group()
+                rec.first_object = len(leaves)
+                box = node.bounding_box()
+                rec.bounds_min[:] = [float(v) for v in box.min[:3]]
+                rec.bounds_max[:] = [float(v) for v in box.max[:3]]
+                groups.append(rec)
+                for child in node.children:
+                    walk(child)
+                rec.n_objects = len(leaves) - rec.first_object
+            else:
+                leaves.append(node)
+        for o in world.objects:
+            walk(o)
+        n = len(leaves)
+        self.leaves = leaves
         self.objects = (L.rtc_object * max(n, 1))()
-        for i, o in enumerate(world.objects):
+        for i, o in enumerate(leaves):
             self.objects[i] = o._c()
+        self.groups = (L.rtc_group * max(len(groups), 1))(*groups)
         self.light = world.light._c() if world.light is not None else None
         self.scene = L.rtc_scene()
         self.scene.n_objects = n
         self.scene.objects = C.cast(self.objects, C.POINTER(L.rtc_object))
         self.scene.light = C.pointer(self.light) if self.light is not None else None
+        self.scene.n_groups = len(groups)
+        self.scene.groups = C.cast(self.groups, C.POINTER(L.rtc_group))
 
 
 class World:

@@ -150,6 +150,53 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
             pack_pattern(pt, &(*soa)[7 * (size_t)np + 5 * (size_t)i]);
         }
     }
+    // GroupShapes: write the depth-first traversal out as an entry list (see SceneSoA::trav)
+    if (scene->n_groups) {
+        if (!scene->groups) return fail(RTC_ERR_INVALID_ARG, "scene.groups is NULL");
+        struct Open {
+            uint32_t end;
+            size_t entry;
+        };
+        std::vector<float4> trav;
+        std::vector<Open> open;
+        uint32_t gi = 0;
+        bool any = false;
+        auto as_f = [](uint32_t u) {
+            float f;
+            std::memcpy(&f, &u, 4);
+            return f;
+        };
+        for (uint32_t p = 0; p <= n; p++) {
+            while (!open.empty() && open.back().end == p) {  // close: skip index = next entry
+                trav[2 * open.back().entry].w = as_f((uint32_t)(trav.size() / 2));
+                open.pop_back();
+            }
+            for (;;) {
+                while (gi < scene->n_groups && scene->groups[gi].n_objects == 0) gi++;  // empty groups never hit
+                if (gi >= scene->n_groups || scene->groups[gi].first_object != p) break;
+                const rtc_group& g = scene->groups[gi];
+                const uint64_t end = (uint64_t)g.first_object + g.n_objects;
+                if (end > n || (!open.empty() && end > open.back().end))
+                    return fail(RTC_ERR_INVALID_ARG, "group %u: objects [%u, %u) do not nest inside the enclosing group / the world",
+                                gi, g.first_object, (unsigned)end);
+                open.push_back({(uint32_t)end, trav.size() / 2});
+                trav.push_back(make_float4(g.bounds_min[0], g.bounds_min[1], g.bounds_min[2], 0.0f));
+                trav.push_back(make_float4(g.bounds_max[0], g.bounds_max[1], g.bounds_max[2], as_f(TRAV_GROUP)));
+                any = true;
+                gi++;
+            }
+            if (p < n) {
+                trav.push_back(make_float4(0.0f, 0.0f, 0.0f, as_f(p)));
+                trav.push_back(make_float4(0.0f, 0.0f, 0.0f, as_f(TRAV_LEAF)));
+            }
+        }
+        if (gi != scene->n_groups)
+            return fail(RTC_ERR_INVALID_ARG, "group %u: groups must be listed in pre-order with first_object inside [0, n_objects)", gi);
+        if (any) {
+            hdr->n_trav = (uint32_t)(trav.size() / 2);
+            soa->insert(soa->end(), trav.begin(), trav.end());
+        }
+    }
     const rtc_light& l = *scene->light;
     hdr->light_kind = l.kind;
     for (int k = 0; k < 3; k++) {
@@ -366,6 +413,7 @@ static SceneSoA soa_view(const float4* base, uint32_t n) {
     s.mat_b = base + 5 * (size_t)m;
     s.mat_c = base + 6 * (size_t)m;
     s.pat = base + 7 * (size_t)m;
+    s.trav = base + 12 * (size_t)m;
     return s;
 }
 
@@ -432,6 +480,10 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     char nm[96];
     snprintf(nm, sizeof(nm), "render_kernel<%d,%s>", n <= 4 ? 4 : n <= 8 ? 8 : 0, (n <= 8 && c->simple) ? "simple" : "general");
     c->kernel_name = nm;
+    if (hdr.n_trav) {  // GroupShapes: packet traversal of the group tree; no per-scene specialisation
+        c->kernel_name = "render_kernel<tree>";
+        return RTC_OK;
+    }
     const int policy = specialise_policy();
     const uint64_t pixels = (uint64_t)hdr.width * hdr.height;
     if (n >= 1 && n <= 8 && (policy == 1 || (policy == 2 && pixels >= (1ull << 18)))) {
@@ -523,7 +575,8 @@ rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, 
     if (c->spec_fn) {
         void* params[] = {&a};
         HIP_TRY(hipModuleLaunchKernel(c->spec_fn, grid.x, grid.y, 1, block.x, 1, 1, 0, stream, params, nullptr));
-    } else if (c->n_objects <= 4 && c->simple) hipLaunchKernelGGL((render_kernel<4, true>), grid, block, 0, stream, a);
+    } else if (c->hdr.n_trav) hipLaunchKernelGGL((render_kernel<-1, false>), grid, block, 0, stream, a);
+    else if (c->n_objects <= 4 && c->simple) hipLaunchKernelGGL((render_kernel<4, true>), grid, block, 0, stream, a);
     else if (c->n_objects <= 4) hipLaunchKernelGGL((render_kernel<4, false>), grid, block, 0, stream, a);
     else if (c->n_objects <= 8 && c->simple) hipLaunchKernelGGL((render_kernel<8, true>), grid, block, 0, stream, a);
     else if (c->n_objects <= 8) hipLaunchKernelGGL((render_kernel<8, false>), grid, block, 0, stream, a);
@@ -710,7 +763,7 @@ rtc_status rtc_intensity_at(const rtc_scene* scene, const float* points, uint32_
     HIP_TRY(d_p.alloc((size_t)n * 16));
     HIP_TRY(d_out.alloc((size_t)n * 4));
     HIP_TRY(hipMemcpy(d_p.p, points, (size_t)n * 16, hipMemcpyHostToDevice));
-    if (hdr.n_objects <= 4)
+    if (hdr.n_objects <= 4 && !hdr.n_trav)
         hipLaunchKernelGGL(intensity_at_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, hdr,
                            soa_view((const float4*)soa.p, hdr.n_objects), (const float4*)d_p.p, n, (float*)d_out.p);
     else

@@ -248,6 +248,104 @@ rtc_status rtc_object_init(rtc_object* out, int32_t kind, const float transform[
     return RTC_OK;
 }
 
+// ---- bounding_box.rs ----
+static void bounds_add_point(float mn[4], float mx[4], const float p[4]) {  // :37-45
+    for (int k = 0; k < 3; k++) {
+        mn[k] = fminf(mn[k], p[k]);
+        mx[k] = fmaxf(mx[k], p[k]);
+    }
+}
+void rtc_bounds_empty(float mn[4], float mx[4]) {  // :13-20
+    for (int k = 0; k < 3; k++) {
+        mn[k] = INFINITY;
+        mx[k] = -INFINITY;
+    }
+    mn[3] = mx[3] = 1.0f;
+}
+void rtc_bounds_add(float mn[4], float mx[4], const float omn[4], const float omx[4]) {  // :47-50
+    bounds_add_point(mn, mx, omn);
+    bounds_add_point(mn, mx, omx);
+}
+static bool bounds_contains_point(const float mn[4], const float mx[4], const float p[4]) {  // :52-56
+    for (int k = 0; k < 3; k++)
+        if (!(p[k] >= mn[k] && p[k] <= mx[k])) return false;
+    return true;
+}
+int32_t rtc_bounds_contains(const float mn[4], const float mx[4], const float omn[4], const float omx[4]) {  // :58-60
+    return bounds_contains_point(mn, mx, omn) && bounds_contains_point(mn, mx, omx) ? 1 : 0;
+}
+void rtc_bounds_transform(const float mn[4], const float mx[4], const float m[16], float out_mn[4], float out_mx[4]) {
+    // :62-79: the eight corners in the reference's order, each through the full 4x4 product
+    float amn[4], amx[4];
+    rtc_bounds_empty(amn, amx);
+    for (int c = 0; c < 8; c++) {
+        const float p[4] = {(c & 4) ? mx[0] : mn[0], (c & 2) ? mx[1] : mn[1], (c & 1) ? mx[2] : mn[2], 1.0f};
+        float q[4];
+        mat_vec4(m, p, q);
+        bounds_add_point(amn, amx, q);
+    }
+    std::memcpy(out_mn, amn, sizeof(amn));
+    std::memcpy(out_mx, amx, sizeof(amx));
+}
+void rtc_bounds_split(const float mn[4], const float mx[4], float lmn[4], float lmx[4], float rmn[4], float rmx[4]) {
+    // :85-113
+    float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    float greatest = fmaxf(fmaxf(dx, dy), dz);
+    float x0 = mn[0], y0 = mn[1], z0 = mn[2];
+    float x1 = mx[0], y1 = mx[1], z1 = mx[2];
+    if (greatest == dx) {
+        x0 = x0 + dx / 2.0f;
+        x1 = x0;
+    } else if (greatest == dy) {
+        y0 = y0 + dy / 2.0f;
+        y1 = y0;
+    } else {
+        z0 = z0 + dz / 2.0f;
+        z1 = z0;
+    }
+    const float a[4] = {mn[0], mn[1], mn[2], 1.0f}, b[4] = {mx[0], mx[1], mx[2], 1.0f};
+    const float mid_min[4] = {x0, y0, z0, 1.0f}, mid_max[4] = {x1, y1, z1, 1.0f};
+    std::memcpy(lmn, a, sizeof(a));
+    std::memcpy(lmx, mid_max, sizeof(a));
+    std::memcpy(rmn, mid_min, sizeof(a));
+    std::memcpy(rmx, b, sizeof(a));
+}
+rtc_status rtc_shape_bounds(int32_t kind, float min_y, float max_y, const float transform[16], float mn[4], float mx[4]) {
+    if (!mn || !mx) return fail(RTC_ERR_INVALID_ARG, "rtc_shape_bounds: null argument");
+    float a[4] = {-1.0f, -1.0f, -1.0f, 1.0f}, b[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // sphere.rs:75-80, cube.rs:82-87
+    switch (kind) {
+        case RTC_SPHERE:
+        case RTC_CUBE:
+            break;
+        case RTC_PLANE:  // plane.rs:61-66
+            a[0] = a[2] = -INFINITY;
+            b[0] = b[2] = INFINITY;
+            a[1] = b[1] = 0.0f;
+            break;
+        case RTC_CYLINDER:  // cylinder.rs:74-79
+            a[1] = min_y;
+            b[1] = max_y;
+            break;
+        case RTC_CONE: {  // cone.rs:75-85
+            float limit = fmaxf(fabsf(min_y), fabsf(max_y));
+            a[0] = a[2] = -limit;
+            b[0] = b[2] = limit;
+            a[1] = min_y;
+            b[1] = max_y;
+            break;
+        }
+        default:
+            return fail(RTC_ERR_UNSUPPORTED, "rtc_shape_bounds: unknown shape kind %d", kind);
+    }
+    if (transform) {
+        rtc_bounds_transform(a, b, transform, mn, mx);  // shape.rs:162-164
+    } else {
+        std::memcpy(mn, a, sizeof(a));
+        std::memcpy(mx, b, sizeof(b));
+    }
+    return RTC_OK;
+}
+
 void rtc_point_light(const float position[4], const float intensity[3], rtc_light* out) {
     std::memset(out, 0, sizeof(*out));
     out->kind = RTC_LIGHT_POINT;

@@ -335,6 +335,7 @@ struct SceneHdr {
     float cam[12];        // rows 0..2 of transform_inverse
     float cam_origin[3];  // transform_inverse * point(0,0,0), camera.rs:70
     uint32_t has_patterns;  // some material carries a pattern (wave-uniform switch around the pattern code)
+    uint32_t n_trav;        // entries in SceneSoA::trav; 0: the world is a flat object list
 };
 
 // Structure-of-arrays scene records in HBM: 4 float4 of geometry (64 B) and
@@ -357,7 +358,13 @@ struct SceneSoA {
     // 5 records per object, read once per shaded hit and only if hdr.has_patterns:
     //   {a.rgb, kind}, {b.rgb -- or distance = b - a for gradient / sine_2d --, 0}, rows 0..2 of the pattern's t_inverse
     const float4* __restrict__ pat;
+    // Worlds with GroupShapes (shape/group.rs): the object records are the tree's leaves in depth-first order and
+    // `trav` is that traversal written out, two float4 per entry:
+    //   group: { bounds.min.xyz, skip }, { bounds.max.xyz, TRAV_GROUP }   skip = entry index after the group's subtree
+    //   leaf : { 0, 0, 0, object index }, { 0, 0, 0, TRAV_LEAF }
+    const float4* __restrict__ trav;
 };
+enum : uint32_t { TRAV_GROUP = 0u, TRAV_LEAF = 1u };
 enum : uint32_t {
     SHAPE_KIND_MASK = 0xffu,
     SHAPE_NONE = 0xffu,      // padding record: never intersects (arrays are padded to a multiple of 8)
@@ -617,12 +624,57 @@ struct Counters {
     uint32_t shaded;  // shade_hit evaluations
 };
 
-// Applies `body(i)` to every object.  NOBJ > 0: the scene has at most NOBJ
-// objects and the loop is fully unrolled (record loads become loop-invariant
-// SGPR values, per-object state can live in registers); NOBJ == 0: any count.
+// cube.rs:90-129 aabb_intersection(..).is_some() for a world-space box: `inv` are the reciprocals Ray::new keeps
+// (ray.rs:16).  fminf / fmaxf return the non-NaN operand, as Rust's f32::min / max do.
+DI bool aabb_hit(V3 o, V3 inv, float4 mn, float4 mx) {
+    float x0 = (mn.x - o.x) * inv.x, x1 = (mx.x - o.x) * inv.x;
+    float tmin = fminf(x0, x1), tmax = fmaxf(x0, x1);
+    float y0 = (mn.y - o.y) * inv.y, y1 = (mx.y - o.y) * inv.y;
+    tmin = fmaxf(tmin, fminf(y0, y1));
+    tmax = fminf(tmax, fmaxf(y0, y1));
+    float z0 = (mn.z - o.z) * inv.z, z1 = (mx.z - o.z) * inv.z;
+    tmin = fmaxf(tmin, fminf(z0, z1));
+    tmax = fminf(tmax, fmaxf(z0, z1));
+    return tmax >= fmaxf(0.0f, tmin);
+}
+// The world-space ray as GroupShape::local_intersect sees it (group.rs:115-133: groups do not transform the ray).
+struct WorldRay {
+    V3 o, inv;
+};
+template <int NOBJ>
+DI WorldRay world_ray(V3 o, V3 d) {
+    if constexpr (NOBJ < 0) return {o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z)};
+    else return {o, o};  // unused
+}
+
+// Applies `body(i)` to every object the reference's World::intersect would reach.  NOBJ > 0: the scene has at
+// most NOBJ objects and the loop is fully unrolled (record loads become loop-invariant SGPR values, per-object
+// state can live in registers); NOBJ == 0: any count; NOBJ < 0: the world contains GroupShapes -- the depth-first
+// entry list is walked as a PACKET: the entry index k is wave-uniform (records still arrive through scalar
+// loads), a lane that misses a group's bounding box sits out until k reaches that group's skip index, and the
+// wave jumps over a subtree only when no lane is inside it.  Every lane therefore visits exactly the leaves, in
+// exactly the order, the reference's recursive child loop visits for its ray.
 template <int NOBJ, class F>
-DI void for_each_object(const SceneHdr& H, F&& body) {
-    if constexpr (NOBJ > 0) {
+DI void for_each_object(const SceneHdr& H, const SceneSoA& S, const WorldRay& wr, F&& body) {
+    if constexpr (NOBJ < 0) {
+        uint32_t resume = 0;  // this lane ignores entries below `resume`
+        for (uint32_t k = 0; k < H.n_trav;) {
+            const float4 e0 = load_uniform(S.trav, 2u * k), e1 = load_uniform(S.trav, 2u * k + 1u);
+            const bool active = k >= resume;
+            if (__float_as_uint(e1.w) == TRAV_GROUP) {
+                const uint32_t skip = __float_as_uint(e0.w);
+                bool inside = false;
+                if (active) {
+                    inside = aabb_hit(wr.o, wr.inv, e0, e1);
+                    if (!inside) resume = skip;
+                }
+                k = __any(inside) ? k + 1u : skip;
+            } else {
+                if (active) body(__float_as_uint(e0.w));
+                k++;
+            }
+        }
+    } else if constexpr (NOBJ > 0) {
         // no `i < n_objects` guard: the record arrays are padded with SHAPE_NONE entries, so every
         // load is unconditional and can be hoisted / issued ahead of the arithmetic that needs it
 #pragma unroll
@@ -647,8 +699,9 @@ DI void for_each_object(const SceneHdr& H, F&& body) {
 template <int NOBJ>
 DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d) {
     Hit best = {0.0f, -1};
-    for_each_object<NOBJ>(H, [&](uint32_t i) {
-        Obj ob = load_obj_static<NOBJ == 0>(S, i);
+    const WorldRay wr = world_ray<NOBJ>(o, d);
+    for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) {
+        Obj ob = load_obj_static<NOBJ <= 0>(S, i);
         if ((ob.bits & SHAPE_KIND_MASK) == SHAPE_NONE) return;  // padding record (wave-uniform)
         V3 po = obj_point(ob, o);
         V3 pd = obj_vector(ob, d);
@@ -738,8 +791,10 @@ struct ShadowPre {
 };
 template <int NOBJ>
 DI void shadow_prepare(const SceneHdr& H, const SceneSoA& S, V3 p, ShadowPre* pre) {
-    for_each_object<NOBJ>(H, [&](uint32_t i) {
-        Obj ob = load_obj_static<NOBJ == 0>(S, i);
+    static_assert(NOBJ > 0, "flat unrolled scenes only");
+    const WorldRay wr = world_ray<NOBJ>(p, p);
+    for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) {
+        Obj ob = load_obj_static<NOBJ <= 0>(S, i);
         pre[i].o = obj_point(ob, p);
         pre[i].c = quadratic_c(ob.bits & SHAPE_KIND_MASK, pre[i].o);
     });
@@ -763,6 +818,7 @@ DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* p
     V3 dir;
     normalize_exact(v, distance, dir);  // == mag3(v), norm3(v)
     cnt.rays++;
+    const WorldRay wr = world_ray<NOBJ>(p, dir);  // unused: NOBJ > 0 here
     auto object_ts = [&](uint32_t i, const float4 g, uint32_t bits, auto&& f) {
         V3 pd;
         if (SIMPLE || (bits & SHAPE_DIAG)) {
@@ -783,7 +839,7 @@ DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* p
     bool found = false;
     float t_c = 0.0f;
     uint32_t i_c = 0;
-    for_each_object<NOBJ>(H, [&](uint32_t i) {
+    for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) {
         const float4 g = S.geo[i];
         const uint32_t bits = spec_bits(i, __float_as_uint(g.w));
         if ((bits & SHAPE_KIND_MASK) == SHAPE_NONE || !(bits & SHAPE_CASTS)) return;  // wave-uniform
@@ -798,7 +854,7 @@ DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* p
     bool shadowed = found && t_c < distance;
     // pass 2: can a non-caster hide that caster?
     if (shadowed) {
-        for_each_object<NOBJ>(H, [&](uint32_t i) {
+        for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) {
             const float4 g = S.geo[i];
             const uint32_t bits = spec_bits(i, __float_as_uint(g.w));
             if ((bits & SHAPE_KIND_MASK) == SHAPE_NONE || (bits & SHAPE_CASTS)) return;
@@ -931,11 +987,12 @@ DI V3 phong(const SceneHdr& H, V3 material_color, float4 ma, float4 mb, V3 p, V3
 // (t_max_negative, index); toggling the hit object then gives n2.
 template <int NOBJ>
 DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int hit_obj, float& n1, float& n2) {
+    const WorldRay wr = world_ray<NOBJ>(o, d);
     float t1 = 0.0f, t2 = 0.0f;  // best and runner-up container keys
     int c1 = -1, c2 = -1;
     bool hit_inside = false;
-    for_each_object<NOBJ>(H, [&](uint32_t i) {
-        Obj ob = load_obj_static<NOBJ == 0>(S, i);
+    for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) {
+        Obj ob = load_obj_static<NOBJ <= 0>(S, i);
         V3 po = obj_point(ob, o);
         V3 pd = obj_vector(ob, d);
         int negatives = 0;
@@ -1423,7 +1480,8 @@ __global__ void color_at_kernel(SceneHdr H, SceneSoA S, const float4* __restrict
     __shared__ float stash_lds[STASH_SLOTS * 64];
     const LaneStash stash = {stash_lds + threadIdx.x, 64u};
     float4 o = origins[i], d = directions[i];
-    V3 c = color_at<0, false>(H, S, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), depth, i, cnt, stash);
+    V3 c = H.n_trav ? color_at<-1, false>(H, S, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), depth, i, cnt, stash)
+                    : color_at<0, false>(H, S, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), depth, i, cnt, stash);
     out[i * 3 + 0] = c.x;
     out[i * 3 + 1] = c.y;
     out[i * 3 + 2] = c.z;
@@ -1443,7 +1501,8 @@ __global__ void intensity_at_kernel_generic(SceneHdr H, SceneSoA S, const float4
     if (i >= n) return;
     Counters cnt = {0u, 0u};
     float4 p = points[i];
-    out[i] = intensity_at<0, false>(H, S, v3(p.x, p.y, p.z), i, 1u, cnt);
+    out[i] = H.n_trav ? intensity_at<-1, false>(H, S, v3(p.x, p.y, p.z), i, 1u, cnt)
+                      : intensity_at<0, false>(H, S, v3(p.x, p.y, p.z), i, 1u, cnt);
 }
 
 __global__ void is_shadowed_kernel(SceneHdr H, SceneSoA S, const float4* __restrict__ lights,
@@ -1452,7 +1511,9 @@ __global__ void is_shadowed_kernel(SceneHdr H, SceneSoA S, const float4* __restr
     if (i >= n) return;
     Counters cnt = {0u, 0u};
     float4 l = lights[i], p = points[i];
-    out[i] = is_shadowed<0>(H, S, v3(l.x, l.y, l.z), v3(p.x, p.y, p.z), cnt) ? 1 : 0;
+    const bool s = H.n_trav ? is_shadowed<-1>(H, S, v3(l.x, l.y, l.z), v3(p.x, p.y, p.z), cnt)
+                            : is_shadowed<0>(H, S, v3(l.x, l.y, l.z), v3(p.x, p.y, p.z), cnt);
+    out[i] = s ? 1 : 0;
 }
 
 __global__ void powf_kernel(const float* __restrict__ x, const float* __restrict__ y, uint32_t n,

@@ -184,6 +184,116 @@ def patterns_medley(width=256, height=192, jitter=("hashed", 11)):
     return world, camera, 5
 
 
+def _hex_color(code):
+    """Color::from_str, color.rs:93-107: '#rrggbb' -> u8 / 255.0 per channel"""
+    return tuple(f32(int(code[i:i + 2], 16)) / f32(255.0) for i in (1, 3, 5))
+
+
+def hexagon(api, material):
+    """demos/src/bin/hexagons.rs:67-105: six sides, each a group of a corner sphere and an edge cylinder.
+    `api` is the module providing GroupShape / Sphere / Cylinder and the transforms (this package, or the oracle's
+    mirror of the same names in tests -- both then run their own transform-baking code)."""
+    hexa = api.GroupShape()
+    for n in range(6):
+        side = api.GroupShape()
+        side.add_child(api.Sphere(api.chain(api.translation(0.0, 0.0, -1.0), api.scaling(0.25, 0.25, 0.25)), material))
+        side.add_child(api.Cylinder(api.chain(api.translation(0.0, 0.0, -1.0), api.rotation_y(-PI / f32(6.0)),
+                                              api.rotation_z(-PI / f32(2.0)), api.scaling(0.25, 1.0, 0.25)),
+                                    material, minimum_y=0.0, maximum_y=1.0))
+        side.set_transformation(api.rotation_y(f32(n) * PI / f32(3.0)))
+        hexa.add_child(side)
+    return hexa
+
+
+def hexagons_objects(api):
+    """World.objects of demos/src/bin/hexagons.rs:32-51: a checkered wall and a glass hexagon."""
+    floor = api.Plane(api.chain(api.translation(0.0, 0.0, 5.0), api.rotation_x(PI / f32(2.0))),
+                      api.Material(pattern=api.Checkers(_hex_color("#C5D86D"), _hex_color("#261C15"))))
+    hex1 = hexagon(api, api.Material(transparency=1.0, refractive_index=1.52))  # constants.rs glass()
+    hex1.set_transformation(api.chain(api.translation(0.0, 0.75, 0.0), api.rotation_x(PI / f32(2.0))))
+    return [floor, hex1]
+
+
+def hexagons(width=1000, height=500):
+    """demos/src/bin/hexagons.rs:32-65."""
+    from . import api
+    world = World(hexagons_objects(api), PointLight(point(-10, 10, -10), color(1, 1, 1)))
+    camera = Camera(width, height, PI / f32(3.0), view_transform(point(0, 1.5, -5), point(0, 1, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
+def grouped_grid_objects(api, n=8, threshold=4):
+    """C5's n*n sphere grid held in ONE GroupShape and subdivided with divide(threshold) (group.rs:157-172):
+    the reference's own bounding-volume hierarchy over the same spheres."""
+    grid = api.GroupShape()
+    s = 0x9E3779B9
+    for j in range(n):
+        for i in range(n):
+            rgb = []
+            for _ in range(3):
+                s = _xorshift32(s)
+                rgb.append(f32(s >> 8) / f32(1 << 24))
+            reflective = 0.3 if (i + j) % 2 == 0 else 0.0
+            grid.add_child(api.Sphere(api.chain(api.translation(f32(i) - f32(n - 1) / f32(2.0), 0.4, f32(j) - f32(n - 1) / f32(2.0)),
+                                                api.scaling(0.4, 0.4, 0.4)),
+                                      api.Material(color=tuple(rgb), diffuse=0.7, specular=0.3, reflective=reflective)))
+    grid.divide(threshold)
+    floor = api.Plane(api.identity_4x4(), api.Material(color=(0.9, 0.9, 0.9), specular=0.0, reflective=0.1))
+    return [floor, grid]
+
+
+def grouped_grid(width=8192, height=8192, n=8, threshold=4):
+    from . import api
+    world = World(grouped_grid_objects(api, n, threshold), PointLight(point(-10, 10, -10), color(1, 1, 1)))
+    camera = Camera(width, height, PI / f32(3.0), view_transform(point(0, 6.0, -9.0), point(0, 0, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
+def groups_medley_objects(api):
+    """Nested, transformed and subdivided groups of every shape kind with patterns, a non-casting leaf, an empty
+    group and a plane inside a group (infinite bounds): a parity stress scene (not a reference demo)."""
+    inner = api.GroupShape()
+    inner.set_transformation(api.scaling(0.6, 0.6, 0.6))
+    inner.add_child(api.Cube(api.translation(0.0, 1.0, 0.0), api.Material(color=(1.0, 0.5, 0.1), reflective=0.2)))
+    inner.add_child(api.Cone(api.chain(api.translation(0.0, 3.2, 0.0), api.scaling(0.7, 1.2, 0.7)),
+                             api.Material(pattern=api.Gradient((0.9, 0.1, 0.1), (0.1, 0.1, 0.9))),
+                             minimum_y=-1.0, maximum_y=0.0, closed=True))
+    outer = api.GroupShape()
+    outer.add_child(api.Sphere(api.translation(-2.0, 1.0, 0.0),
+                               api.Material(color=(0.05, 0.05, 0.05), transparency=0.9, refractive_index=1.52, reflective=0.6)))
+    outer.add_child(inner)
+    outer.add_child(api.Cylinder(api.chain(api.translation(2.2, 0.0, 0.5), api.scaling(0.5, 1.0, 0.5)),
+                                 api.Material(pattern=api.Stripes((0.2, 0.8, 0.3), (0.9, 0.9, 0.9), api.scaling(0.25, 0.25, 0.25))),
+                                 minimum_y=0.0, maximum_y=2.0, closed=True))
+    outer.add_child(api.GroupShape())  # empty group
+    outer.set_transformation(api.chain(api.translation(0.3, 0.0, 1.0), api.rotation_y(f32(0.4))))
+    swarm = api.GroupShape()
+    s = 12345
+    for k in range(24):
+        s = _xorshift32(s)
+        x = f32(s & 0xFFFF) / f32(65536.0) * f32(8.0) - f32(4.0)
+        s = _xorshift32(s)
+        z = f32(s & 0xFFFF) / f32(65536.0) * f32(6.0) - f32(4.0)
+        s = _xorshift32(s)
+        y = f32(s & 0xFFFF) / f32(65536.0) * f32(2.5) + f32(0.2)
+        swarm.add_child(api.Sphere(api.chain(api.translation(x, y, z), api.scaling(0.18, 0.18, 0.18)),
+                                   api.Material(color=(0.3 + 0.03 * k, 0.9 - 0.03 * k, 0.5), reflective=0.1 * (k % 3)),
+                                   casts_shadow=(k % 5 != 0)))
+    swarm.divide(3)
+    ground = api.GroupShape()
+    ground.add_child(api.Plane(api.identity_4x4(), api.Material(pattern=api.Checkers((0.8, 0.8, 0.8), (0.3, 0.3, 0.35)),
+                                                               reflective=0.15)))
+    return [ground, outer, swarm]
+
+
+def groups_medley(width=256, height=192, jitter=("hashed", 3)):
+    from . import api
+    light = RectangleLight(color(1.2, 1.2, 1.2), point(-4, 6, -5), vector(2, 0, 0), 3, vector(0, 0, 2), 2, jitter)
+    world = World(groups_medley_objects(api), light)
+    camera = Camera(width, height, PI / f32(3.0), view_transform(point(0.5, 3.0, -7.5), point(0, 1.0, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
 def shapes_medley(width=256, height=192, jitter=("hashed", 7)):
     """All four shape kinds, nested transparent objects, a non-casting object and an area light:
     a parity stress scene (not a reference demo).  The cylinders are the reflect_refract.rs one

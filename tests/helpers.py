@@ -7,15 +7,21 @@ from oracle import oracle as O
 f32 = np.float32
 
 
+def oracle_shape(s):
+    """Product-API shape -> oracle shape.  A GroupShape is handed over as the reference's
+    GroupShape::with_children of its (already baked) children: the oracle derives the bounding boxes itself."""
+    if hasattr(s, "children"):
+        return O.GroupShape.with_children([oracle_shape(c) for c in s.children])
+    m = s.material
+    pat = None if m.pattern is None else O.Pattern(m.pattern.kind, m.pattern.a, m.pattern.b, m.pattern.transform)
+    om = O.Material(m.color, m.ambient, m.diffuse, m.specular, m.shininess, m.reflective, m.transparency,
+                    m.refractive_index, pat)
+    return O.Shape(s.kind, s.transform, om, casts_shadow=s.casts_shadow, minimum_y=s.minimum_y,
+                   maximum_y=s.maximum_y, closed=s.closed)
+
+
 def oracle_world(world):
-    objs = []
-    for s in world.objects:
-        m = s.material
-        pat = None if m.pattern is None else O.Pattern(m.pattern.kind, m.pattern.a, m.pattern.b, m.pattern.transform)
-        om = O.Material(m.color, m.ambient, m.diffuse, m.specular, m.shininess, m.reflective, m.transparency,
-                        m.refractive_index, pat)
-        objs.append(O.Shape(s.kind, s.transform, om, casts_shadow=s.casts_shadow, minimum_y=s.minimum_y,
-                            maximum_y=s.maximum_y, closed=s.closed))
+    objs = [oracle_shape(s) for s in world.objects]
     lt = world.light
     if lt is None:
         light = None
