@@ -13,6 +13,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "rtc.h"
@@ -143,12 +144,36 @@ struct Material {
         return m;
     }
 };
+inline Material glass() {  // constants.rs:12-17
+    return Material::builder().transparency(1.0f).refractive_index(1.52f).build();
+}
 inline Material metal() {  // constants.rs:50-62
     return Material::builder().color(gray()).ambient(1.0f).diffuse(0.6f).reflective(0.1f).specular(0.4f).shininess(10.0f).build();
 }
 
+// ---- bounding_box.rs --------------------------------------------------------------------------------
+struct BoundingBox {
+    Tuple min, max;
+    static BoundingBox empty() {
+        BoundingBox b;
+        rtc_bounds_empty(&b.min.x, &b.max.x);
+        return b;
+    }
+    void add_bounding_box(const BoundingBox& o) { rtc_bounds_add(&min.x, &max.x, o.min.data(), o.max.data()); }
+    bool contains_bounding_box(const BoundingBox& o) const {
+        return rtc_bounds_contains(min.data(), max.data(), o.min.data(), o.max.data()) != 0;
+    }
+    std::pair<BoundingBox, BoundingBox> split() const {
+        BoundingBox l, r;
+        rtc_bounds_split(min.data(), max.data(), &l.min.x, &l.max.x, &r.min.x, &r.max.x);
+        return {l, r};
+    }
+};
+
 // ---- shape/*.rs -----------------------------------------------------------------------------------
+// One value type for every Box<dyn Shape>: a leaf of some kind, or (kind == GROUP) a GroupShape holding children.
 struct Shape {
+    static constexpr int32_t GROUP = -1;
     int32_t kind;
     Matrix transform = identity_4x4();
     Material material;
@@ -156,11 +181,78 @@ struct Shape {
     float minimum_y = -std::numeric_limits<float>::infinity();  // cylinder.rs:39-41
     float maximum_y = std::numeric_limits<float>::infinity();
     bool closed = false;
+    // GroupShape state (shape/group.rs:12-16)
+    std::vector<Shape> children;
+    Matrix group_t_inverse = identity_4x4();   // BaseShape.t_inverse of the group itself (default: not an inversion)
+    std::shared_ptr<BoundingBox> cached_box;  // cached_bounding_box: filled on first use, never invalidated
+
     explicit Shape(int32_t k) : kind(k) {}
     Shape(int32_t k, Matrix t, Material m) : kind(k), transform(t), material(m) {}
-    void set_transformation(Matrix t) { transform = t; }
-    void set_material(Material m) { material = m; }
+    bool is_group() const { return kind == GROUP; }
+    const Matrix& transformation() const { return transform; }
+    void set_transformation(Matrix t) {
+        if (is_group()) {  // group.rs:101-114: re-bake the children
+            if (!children.empty()) {
+                Matrix child_transformer = t * group_t_inverse;
+                for (Shape& c : children) c.set_transformation(child_transformer * c.transform);
+            }
+            group_t_inverse = t.inverse();
+        }
+        transform = t;
+    }
+    void set_material(Material m) {
+        if (is_group()) {  // group.rs:96-100
+            for (Shape& c : children) c.set_material(m);
+        } else {
+            material = m;
+        }
+    }
     void set_casts_shadow(bool v) { casts_shadow = v; }
+    BoundingBox bounding_box() {  // group.rs:138-151 / the leaf kinds' bounding_box()
+        BoundingBox b;
+        if (!is_group()) {
+            check(rtc_shape_bounds(kind, minimum_y, maximum_y, nullptr, &b.min.x, &b.max.x));
+            return b;
+        }
+        if (!cached_box) {
+            b = BoundingBox::empty();
+            for (Shape& c : children) b.add_bounding_box(c.parent_space_bounding_box());
+            cached_box = std::make_shared<BoundingBox>(b);
+        }
+        return *cached_box;
+    }
+    BoundingBox parent_space_bounding_box() {  // shape.rs:162-164 / group.rs:153-155
+        if (is_group()) return bounding_box();
+        BoundingBox b;
+        check(rtc_shape_bounds(kind, minimum_y, maximum_y, transform.m, &b.min.x, &b.max.x));
+        return b;
+    }
+    void divide(size_t threshold) {  // group.rs:157-172; a no-op for leaves (shape.rs:167)
+        if (!is_group()) return;
+        if (threshold <= children.size()) {
+            auto halves = bounding_box().split();  // partition_children, :46-64
+            std::vector<Shape> left, right, keep;
+            for (Shape& c : children) {
+                BoundingBox cb = c.parent_space_bounding_box();
+                if (halves.first.contains_bounding_box(cb)) left.push_back(c);
+                else if (halves.second.contains_bounding_box(cb)) right.push_back(c);
+                else keep.push_back(c);
+            }
+            children = keep;
+            if (!left.empty()) make_subgroup(left);
+            if (!right.empty()) make_subgroup(right);
+        }
+        for (Shape& c : children) c.divide(threshold);
+    }
+    void make_subgroup(const std::vector<Shape>& kids) {  // group.rs:66-73
+        if (kids.size() == 1) {
+            children.push_back(kids[0]);
+        } else {
+            Shape g(GROUP);
+            g.children = kids;
+            children.push_back(g);
+        }
+    }
     rtc_object c() const {
         rtc_object o;
         rtc_material m = material.c();
@@ -191,6 +283,15 @@ struct Cylinder : Shape {
 struct Cone : Shape {  // cone.rs:12-42: minimum_y / maximum_y / closed are pub fields, as on Cylinder
     Cone() : Shape(RTC_CONE) {}
     static Cone build(Matrix t, Material m) { Cone s; s.transform = t; s.material = m; return s; }
+};
+struct GroupShape : Shape {  // shape/group.rs
+    GroupShape() : Shape(GROUP) {}
+    static GroupShape with_children(std::vector<Shape> kids) { GroupShape g; g.children = std::move(kids); return g; }  // :23-27
+    const std::vector<Shape>& get_children() const { return children; }
+    void add_child(Shape child) {  // :39-44 (the child moves into the group, as the Box does)
+        child.set_transformation(transform * child.transform);
+        children.push_back(std::move(child));
+    }
 };
 
 // ---- light/*.rs -----------------------------------------------------------------------------------
@@ -250,15 +351,28 @@ struct Canvas {
 struct Camera {
     rtc_camera c;
     rtc_stats last_stats{};
+    // depth-first leaves + one rtc_group (leaf run, bounding box) per GroupShape -- see rtc_group in rtc.h
+    static void flatten(Shape& s, std::vector<rtc_object>& objs, std::vector<rtc_group>& groups) {
+        if (!s.is_group()) {
+            objs.push_back(s.c());
+            return;
+        }
+        const size_t gi = groups.size();
+        BoundingBox b = s.bounding_box();
+        groups.push_back({(uint32_t)objs.size(), 0u, {b.min.x, b.min.y, b.min.z}, {b.max.x, b.max.y, b.max.z}});
+        for (Shape& c : s.children) flatten(c, objs, groups);
+        groups[gi].n_objects = (uint32_t)objs.size() - groups[gi].first_object;
+    }
     Camera(uint32_t width_pixels, uint32_t height_pixels, float field_of_view, Matrix transform) {  // camera.rs:23-56
         check(rtc_camera_new(width_pixels, height_pixels, field_of_view, transform.m, &c));
     }
     // Camera::render (camera.rs:76-91) on the MI355X
-    Canvas render(const World& world, int16_t reflection_recursion_depth, int device = 0) {
+    Canvas render(World world, int16_t reflection_recursion_depth, int device = 0) {  // takes the World by value, as the reference does
         std::vector<rtc_object> objs;
-        objs.reserve(world.objects.size());
-        for (const Shape& s : world.objects) objs.push_back(s.c());
-        rtc_scene scene{(uint32_t)objs.size(), objs.data(), world.light ? &world.light->l : nullptr};
+        std::vector<rtc_group> groups;
+        for (Shape& s : world.objects) flatten(s, objs, groups);
+        rtc_scene scene{(uint32_t)objs.size(), objs.data(), world.light ? &world.light->l : nullptr,
+                        (uint32_t)groups.size(), groups.data()};
         Canvas canvas(c.width, c.height);
         check(rtc_render(&scene, &c, reflection_recursion_depth, device, canvas.data.data(), &last_stats));
         return canvas;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for bench.py's dominant kernel (render_kernel).
-# Usage (on the GPU box, from the repo root):  bash profiles/run_profile.sh <tag>
+# Usage (on the GPU box, from the repo root):  bash profiles/run_profile.sh <tag> ["extra bench.py args"] [trace]
+#   e.g.  bash profiles/run_profile.sh r01e_groups "--scene hexagons" trace     (third arg: durations only)
 # Pass 1: --kernel-trace --stats (durations).  Passes 2..: --pmc counters, each in its own run
 # (gpurun refuses --pmc combined with the trace domains that crash nodes on this pool).
 set -u
@@ -8,9 +9,10 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="python3 bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-verify"
+BENCH="python3 bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-verify ${2:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace exit $?"
+if [ "${3:-}" = "trace" ]; then find "$OUT" -name "*.csv" | head; exit 0; fi
 for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_INSTS_VALU_TRANS_F32" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT"; do

@@ -23,7 +23,7 @@ def built():
 
 
 def test_demos_build_and_refuse_to_run_without_gpu(built):
-    for name in ("soft_shadows", "first_scene", "first_plane", "first_patterns", "reflect_refract"):
+    for name in ("soft_shadows", "first_scene", "first_plane", "first_patterns", "reflect_refract", "hexagons"):
         assert os.access(os.path.join(built, name), os.X_OK)
     if P.device_count() == 0:
         p = subprocess.run([os.path.join(built, "first_plane"), "8x8"], capture_output=True, text=True)
@@ -32,7 +32,8 @@ def test_demos_build_and_refuse_to_run_without_gpu(built):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,size", [("soft_shadows", (100, 40)), ("first_scene", (100, 50)), ("first_plane", (100, 50)),
-                                       ("first_patterns", (100, 50)), ("reflect_refract", (200, 100))])
+                                       ("first_patterns", (100, 50)), ("reflect_refract", (200, 100)),
+                                       ("hexagons", (200, 100))])
 def test_demo_stdout_is_the_oracles_ppm(built, name, size):
     p = subprocess.run([os.path.join(built, name), "%dx%d" % size], capture_output=True)
     assert p.returncode == 0, p.stderr
