@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTC_ABI_VERSION 3
+#define RTC_ABI_VERSION 4
 /* maximum reflection_recursion_depth accepted (reference default: 5, constants.rs:4) */
 #define RTC_MAX_DEPTH 8
 
@@ -43,8 +43,10 @@ typedef enum rtc_status {
     RTC_ERR_NO_DEVICE = -5    /* no gfx950 device visible: there is NO CPU fallback      */
 } rtc_status;
 
-/* shape/{sphere,plane,cube,cylinder,cone}.rs */
-enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3, RTC_CONE = 4 };
+/* shape/{sphere,plane,cube,cylinder,cone,triangle}.rs.  A SmoothTriangle is passed as RTC_TRIANGLE: its
+ * local_intersect hands out intersections whose object is the inner flat Triangle (smooth_triangle.rs:37-39), so
+ * inside Camera::render it is shaded exactly like one. */
+enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3, RTC_CONE = 4, RTC_TRIANGLE = 5 };
 /* pattern/{stripes,gradient,rings,checkers,sine_2d}.rs; NONE = Material.pattern is None (material.rs:50) */
 enum { RTC_PATTERN_NONE = 0, RTC_PATTERN_STRIPES = 1, RTC_PATTERN_GRADIENT = 2, RTC_PATTERN_RINGS = 3,
        RTC_PATTERN_CHECKERS = 4, RTC_PATTERN_SINE2D = 5 };
@@ -92,6 +94,8 @@ typedef struct rtc_object {
     float max_y;          /* Cylinder/Cone.maximum_y */
     float inv[16];
     rtc_material material;
+    float p1[3], p2[3], p3[3]; /* Triangle.p1..p3 (triangle.rs:11-13); e1, e2 and the normal are re-derived by
+                                  the library exactly as Triangle::new does (:20-22).  Ignored for other kinds. */
 } rtc_object;
 
 /* light/point_light.rs:7-10 and light/rectangle_light.rs:12-31 AFTER
@@ -215,6 +219,12 @@ void rtc_bounds_split(const float mn[4], const float mx[4], float left_mn[4], fl
  * with transform != NULL, Shape::parent_space_bounding_box (shape.rs:162-164) for that transformation(). */
 rtc_status rtc_shape_bounds(int32_t kind, float min_y, float max_y, const float transform[16], float mn[4],
                             float mx[4]);
+/* the same for a Triangle (triangle.rs:74-80) */
+void rtc_triangle_bounds(const float p1[3], const float p2[3], const float p3[3], const float transform[16],
+                         float mn[4], float mx[4]);
+/* Triangle::new's derived fields (triangle.rs:20-22): e1 = p2 - p1, e2 = p3 - p1, normal = e2.cross(e1).norm() */
+void rtc_triangle_fields(const float p1[3], const float p2[3], const float p3[3], float e1[3], float e2[3],
+                         float normal[3]);
 void rtc_point_light(const float position[4], const float intensity[3], rtc_light* out);   /* point_light.rs:12-19 */
 rtc_status rtc_rectangle_light(const float intensity[3], const float corner[4], const float u_vec[4],
                                int32_t u_steps, const float v_vec[4], int32_t v_steps, int32_t jitter_mode,

@@ -17,7 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "librtc_oracle.so")
 
-SPHERE, PLANE, CUBE, CYLINDER, CONE = 0, 1, 2, 3, 4
+SPHERE, PLANE, CUBE, CYLINDER, CONE, TRIANGLE, SMOOTH_TRIANGLE = 0, 1, 2, 3, 4, 5, 6
 TEST_SHAPE = 100
 PATTERN_NONE, PATTERN_STRIPES, PATTERN_GRADIENT, PATTERN_RINGS, PATTERN_CHECKERS, PATTERN_SINE2D = 0, 1, 2, 3, 4, 5
 PATTERN_TEST = 100
@@ -52,7 +52,8 @@ class _Material(C.Structure):
 class _Shape(C.Structure):
     _fields_ = [("kind", C.c_int32), ("casts_shadow", C.c_int32), ("closed", C.c_int32),
                 ("min_y", C.c_float), ("max_y", C.c_float), ("transform", C.c_float * 16),
-                ("material", _Material)]
+                ("material", _Material), ("p1", C.c_float * 4), ("p2", C.c_float * 4), ("p3", C.c_float * 4),
+                ("n1", C.c_float * 4), ("n2", C.c_float * 4), ("n3", C.c_float * 4)]
 
 
 class _Light(C.Structure):
@@ -114,6 +115,7 @@ def lib():
         L.rtco_phong.argtypes = [C.c_void_p, C.POINTER(_Material), _FP, _FP, _FP, C.c_float, _FP]
         L.rtco_phong_on.argtypes = [C.c_void_p, C.POINTER(_Shape), _FP, _FP, _FP, C.c_float, _FP]
         L.rtco_scale_color.argtypes = [C.c_float]
+        L.rtco_normal_at_uv.argtypes = [C.POINTER(_Shape), _FP, C.c_float, C.c_float, _FP]
         L.rtco_jitter_value.argtypes = [C.c_uint32]
         _lib = L
     return _lib
@@ -433,6 +435,13 @@ class Shape:
         self.material = Material() if material is None else material
         self.casts_shadow = casts_shadow
         self.minimum_y, self.maximum_y, self.closed = minimum_y, maximum_y, closed
+        self.points, self.normals = None, None  # triangles
+
+    def set_transformation(self, t):
+        self.transform = np.asarray(t, dtype=f32)
+
+    def set_material(self, m):
+        self.material = m
 
     def _c(self):
         s = _Shape()
@@ -443,7 +452,32 @@ class Shape:
         s.max_y = f32(self.maximum_y)
         s.transform[:] = [f32(v) for v in self.transform.reshape(-1)]
         s.material = self.material._c()
+        if self.points is not None:
+            for name, p in zip(("p1", "p2", "p3"), self.points):
+                getattr(s, name)[:] = [f32(v) for v in p]
+        if self.normals is not None:
+            for name, n in zip(("n1", "n2", "n3"), self.normals):
+                getattr(s, name)[:] = [f32(v) for v in n]
         return s
+
+    # triangle.rs / smooth_triangle.rs
+    def local_intersect_uv(self, o, d):
+        s, a, b = self._c(), _a(o, 4), _a(d, 4)
+        ts, us, vs = np.zeros(4, dtype=f32), np.zeros(4, dtype=f32), np.zeros(4, dtype=f32)
+        n = lib().rtco_local_intersect_uv(C.byref(s), _p(a), _p(b), _p(ts), _p(us), _p(vs))
+        return [(ts[i], us[i], vs[i]) for i in range(n)]
+
+    def normal_at_uv(self, p, u, v):
+        s, a = self._c(), _a(p, 4)
+        out = np.zeros(4, dtype=f32)
+        lib().rtco_normal_at_uv(C.byref(s), _p(a), f32(u), f32(v), _p(out))
+        return out
+
+    def triangle_fields(self):
+        s = self._c()
+        out = [np.zeros(4, dtype=f32) for _ in range(3)]
+        lib().rtco_triangle_fields(C.byref(s), *[_p(x) for x in out])
+        return out
 
     # Shape::local_intersect / intersect / local_norm_at / normal_at
     def local_intersect(self, o, d):
@@ -489,6 +523,21 @@ def Cylinder(transform=None, material=None, **kw):
 
 def Cone(transform=None, material=None, **kw):
     return Shape(CONE, transform, material, **kw)
+
+
+def Triangle(p1, p2, p3, transform=None, material=None, **kw):
+    """Triangle::new(p1, p2, p3) -- shape/triangle.rs:19-33"""
+    t = Shape(TRIANGLE, transform, material, **kw)
+    t.points = [_a(p, 4) for p in (p1, p2, p3)]
+    return t
+
+
+def SmoothTriangle(p1, p2, p3, n1, n2, n3, transform=None, material=None, **kw):
+    """SmoothTriangle::new -- shape/smooth_triangle.rs:17-26"""
+    t = Shape(SMOOTH_TRIANGLE, transform, material, **kw)
+    t.points = [_a(p, 4) for p in (p1, p2, p3)]
+    t.normals = [_a(n, 4) for n in (n1, n2, n3)]
+    return t
 
 
 def TestShape(transform=None, material=None, **kw):

@@ -301,6 +301,8 @@ struct Shape {
     Matrix t, t_inverse, t_inverse_transpose;  // base_shape.rs:56-60
     Material m;
     int id;
+    Tuple p1, p2, p3, e1, e2, normal;  // triangle.rs:9-17
+    Tuple n1, n2, n3;                  // smooth_triangle.rs:11-15
 };
 Shape shape_from(const rtco_shape& s, int id) {
     Shape sh;
@@ -314,6 +316,18 @@ Shape shape_from(const rtco_shape& s, int id) {
     sh.t_inverse_transpose = transpose(inverse(sh.t));   // base_shape.rs:59
     sh.m = material_from(s.material);
     sh.id = id;
+    sh.p1 = sh.p2 = sh.p3 = sh.e1 = sh.e2 = sh.normal = sh.n1 = sh.n2 = sh.n3 = vector(0, 0, 0);
+    if (s.kind == RTCO_TRIANGLE || s.kind == RTCO_SMOOTH_TRIANGLE) {  // triangle.rs:19-33
+        sh.p1 = {s.p1[0], s.p1[1], s.p1[2], s.p1[3]};
+        sh.p2 = {s.p2[0], s.p2[1], s.p2[2], s.p2[3]};
+        sh.p3 = {s.p3[0], s.p3[1], s.p3[2], s.p3[3]};
+        sh.e1 = sh.p2 - sh.p1;
+        sh.e2 = sh.p3 - sh.p1;
+        sh.normal = norm(cross(sh.e2, sh.e1));
+        sh.n1 = {s.n1[0], s.n1[1], s.n1[2], s.n1[3]};
+        sh.n2 = {s.n2[0], s.n2[1], s.n2[2], s.n2[3]};
+        sh.n3 = {s.n3[0], s.n3[1], s.n3[2], s.n3[3]};
+    }
     return sh;
 }
 
@@ -409,6 +423,22 @@ void local_intersect(const Shape& s, const Ray& r, std::vector<Intersection>& ou
             }
             return;
         }
+        case RTCO_TRIANGLE:
+        case RTCO_SMOOTH_TRIANGLE: {  // triangle.rs:45-68 (smooth_triangle.rs:37-39 delegates to it)
+            Tuple dir_cross_e2 = cross(r.direction, s.e2);
+            float determinant = dot(s.e1, dir_cross_e2);
+            if (std::fabs(determinant) < 0.0000001f) return;
+            float f = 1.0f / determinant;
+            Tuple p1_to_origin = r.origin - s.p1;
+            float u = f * dot(p1_to_origin, dir_cross_e2);
+            if (u < 0.0f || u > 1.0f) return;
+            Tuple origin_cross_e1 = cross(p1_to_origin, s.e1);
+            float v = f * dot(r.direction, origin_cross_e1);
+            if (v < 0.0f || (u + v) > 1.0f) return;
+            float distance = f * dot(s.e2, origin_cross_e1);
+            out.push_back({distance, s.id, u, v});
+            return;
+        }
         case RTCO_CONE: {  // cone.rs:52-57 (sides, then caps -- always, unlike the cylinder), :89-175
             do {  // intersect_sides :89-141
                 float two_a = 2.0f * (r.direction.x * r.direction.x - r.direction.y * r.direction.y +
@@ -458,6 +488,9 @@ Tuple local_norm_at(const Shape& s, Tuple p) {
         }
         case RTCO_TEST_SHAPE:  // shape/test_shape.rs:38-45 (test double)
             return vector(2.0f * p.x, 3.0f * p.y, 4.0f * p.z);
+        case RTCO_TRIANGLE:         // triangle.rs:70-72
+        case RTCO_SMOOTH_TRIANGLE:  // the hit object of a smooth triangle is its inner Triangle (see rtc_oracle.h)
+            return s.normal;
         case RTCO_CYLINDER: {  // cylinder.rs:62-72
             float dist_square = p.x * p.x + p.z * p.z;
             if (dist_square < 1.0f) {
@@ -609,6 +642,14 @@ BBox shape_bounding_box(const Shape& s) {
         case RTCO_CONE: {
             float limit = fmaxf(std::fabs(s.min_y), std::fabs(s.max_y));
             return {point(-limit, s.min_y, -limit), point(limit, s.max_y, limit)};
+        }
+        case RTCO_TRIANGLE:
+        case RTCO_SMOOTH_TRIANGLE: {  // triangle.rs:74-80
+            BBox b = bbox_empty();
+            bbox_add_point(b, s.p1);
+            bbox_add_point(b, s.p2);
+            bbox_add_point(b, s.p3);
+            return b;
         }
         default:
             return {point(-1, -1, -1), point(1, 1, 1)};
@@ -1136,6 +1177,34 @@ int rtco_local_intersect(const rtco_shape* s, const float o[4], const float d[4]
 }
 void rtco_local_normal_at(const rtco_shape* s, const float p[4], float out[4]) {
     put(local_norm_at(shape_from(*s, 0), T(p)), out);
+}
+int rtco_local_intersect_uv(const rtco_shape* s, const float o[4], const float d[4], float ts[4], float us[4],
+                            float vs[4]) {
+    Shape sh = shape_from(*s, 0);
+    std::vector<Intersection> xs;
+    local_intersect(sh, ray_new(T(o), T(d)), xs);
+    for (size_t i = 0; i < xs.size() && i < 4; i++) {
+        ts[i] = xs[i].distance;
+        us[i] = xs[i].u;
+        vs[i] = xs[i].v;
+    }
+    return (int)xs.size();
+}
+void rtco_normal_at_uv(const rtco_shape* s, const float world_point[4], float u, float v, float out[4]) {
+    Shape sh = shape_from(*s, 0);
+    if (sh.kind != RTCO_SMOOTH_TRIANGLE) {
+        put(normal_at(sh, T(world_point)), out);
+        return;
+    }
+    // smooth_triangle.rs:41-43, then shape.rs:72-154 normal_to_world
+    Tuple object_normal = sh.n2 * u + sh.n3 * v + sh.n1 * (1.0f - u - v);
+    put(normal_to_world(sh, object_normal), out);
+}
+void rtco_triangle_fields(const rtco_shape* s, float e1[4], float e2[4], float normal[4]) {
+    Shape sh = shape_from(*s, 0);
+    put(sh.e1, e1);
+    put(sh.e2, e2);
+    put(sh.normal, normal);
 }
 int rtco_shape_intersect(const rtco_shape* s, const float o[4], const float d[4], float ts[4], float obj_o[4],
                          float obj_d[4]) {

@@ -24,6 +24,9 @@ extern "C" {
 #endif
 
 enum { RTCO_SPHERE = 0, RTCO_PLANE = 1, RTCO_CUBE = 2, RTCO_CYLINDER = 3, RTCO_CONE = 4,
+       RTCO_TRIANGLE = 5,        /* shape/triangle.rs */
+       RTCO_SMOOTH_TRIANGLE = 6, /* shape/smooth_triangle.rs: intersects through its inner Triangle (:37-39), so
+                                    in World::intersect the hit object -- and the normal -- are the flat triangle's */
        RTCO_TEST_SHAPE = 100 /* shape/test_shape.rs: no hits, local normal (2x,3y,4z) */ };
 enum { RTCO_LIGHT_POINT = 0, RTCO_LIGHT_RECT = 1 };
 /* jitter sources for RectangleLight (light/rectangle_light.rs:44-47, test/utils.rs:15-24) */
@@ -58,6 +61,8 @@ typedef struct rtco_shape {
     float min_y, max_y;
     float transform[16];
     rtco_material material;
+    float p1[4], p2[4], p3[4]; /* Triangle::new(p1, p2, p3), triangle.rs:19-33 */
+    float n1[4], n2[4], n3[4]; /* SmoothTriangle::new(.., n1, n2, n3), smooth_triangle.rs:17-26 */
 } rtco_shape;
 
 /* light/point_light.rs:7-10, light/rectangle_light.rs:12-31.  u_vec/v_vec are
@@ -131,6 +136,14 @@ void rtco_ray_for_pixel(const rtco_camera* c, uint32_t x, uint32_t y, float o[4]
 /* ---- shapes ---- */
 int rtco_local_intersect(const rtco_shape* s, const float o[4], const float d[4], float ts[4]);
 void rtco_local_normal_at(const rtco_shape* s, const float p[4], float out[4]);
+/* local_intersect with the (u, v) each intersection carries (intersection.rs:8-9) */
+int rtco_local_intersect_uv(const rtco_shape* s, const float o[4], const float d[4], float ts[4], float us[4],
+                            float vs[4]);
+/* Shape::normal_at(point, hit) for a hit constructed by hand with (u, v) -- the only way the reference ever
+ * reaches SmoothTriangle::local_norm_at (smooth_triangle.rs:41-43) */
+void rtco_normal_at_uv(const rtco_shape* s, const float world_point[4], float u, float v, float out[4]);
+/* Triangle's derived fields e1, e2, normal (triangle.rs:20-22) */
+void rtco_triangle_fields(const rtco_shape* s, float e1[4], float e2[4], float normal[4]);
 int rtco_shape_intersect(const rtco_shape* s, const float o[4], const float d[4], float ts[4],
                          float obj_o[4], float obj_d[4]);
 void rtco_normal_at(const rtco_shape* s, const float world_point[4], float out[4]);

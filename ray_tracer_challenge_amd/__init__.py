@@ -10,5 +10,5 @@ top of that ABI.  The shared library must be built first
 from ._lib import RtcError, lib  # noqa: F401
 from .api import *  # noqa: F401,F403
 from .api import (BoundingBox, Camera, Canvas, Checkers, Cone, Cube, Cylinder, Gradient, GroupShape, Material,  # noqa: F401
-                  Pattern, Plane, PointLight, RectangleLight, Rings, Shape, Sine2D, Sphere, Stripes, World, cosf, cosf_host,
+                  Pattern, Plane, PointLight, RectangleLight, Rings, Shape, Sine2D, SmoothTriangle, Sphere, Stripes, Triangle, World, cosf, cosf_host,
                   default_world, device_count, glass, metal, powf, powf_host)

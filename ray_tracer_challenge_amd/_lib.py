@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("RTC_AMD_LIB") or os.path.join(HERE, "librtc_amd.so")
 
 RTC_OK = 0
 RTC_ERR_INVALID_ARG, RTC_ERR_UNSUPPORTED, RTC_ERR_NO_LIGHT, RTC_ERR_DEVICE, RTC_ERR_NO_DEVICE = -1, -2, -3, -4, -5
-RTC_SPHERE, RTC_PLANE, RTC_CUBE, RTC_CYLINDER, RTC_CONE = 0, 1, 2, 3, 4
+RTC_SPHERE, RTC_PLANE, RTC_CUBE, RTC_CYLINDER, RTC_CONE, RTC_TRIANGLE = 0, 1, 2, 3, 4, 5
 (RTC_PATTERN_NONE, RTC_PATTERN_STRIPES, RTC_PATTERN_GRADIENT, RTC_PATTERN_RINGS, RTC_PATTERN_CHECKERS,
  RTC_PATTERN_SINE2D) = 0, 1, 2, 3, 4, 5
 RTC_LIGHT_POINT, RTC_LIGHT_RECT = 0, 1
@@ -37,7 +37,7 @@ class rtc_material(C.Structure):
 class rtc_object(C.Structure):
     _fields_ = [("kind", C.c_int32), ("casts_shadow", C.c_int32), ("closed", C.c_int32),
                 ("min_y", C.c_float), ("max_y", C.c_float), ("inv", C.c_float * 16),
-                ("material", rtc_material)]
+                ("material", rtc_material), ("p1", C.c_float * 3), ("p2", C.c_float * 3), ("p3", C.c_float * 3)]
 
 
 class rtc_light(C.Structure):
@@ -103,6 +103,8 @@ SIGNATURES = {
     "rtc_bounds_transform": (None, [FP, FP, FP, FP, FP]),
     "rtc_bounds_split": (None, [FP, FP, FP, FP, FP, FP]),
     "rtc_shape_bounds": (C.c_int, [C.c_int32, C.c_float, C.c_float, FP, FP, FP]),
+    "rtc_triangle_bounds": (None, [FP, FP, FP, FP, FP, FP]),
+    "rtc_triangle_fields": (None, [FP, FP, FP, FP, FP, FP]),
     "rtc_point_light": (None, [FP, FP, C.POINTER(rtc_light)]),
     "rtc_rectangle_light": (C.c_int, [FP, FP, FP, C.c_int32, FP, C.c_int32, C.c_int32, C.c_float, C.c_uint32,
                                       C.POINTER(rtc_light)]),

@@ -289,6 +289,7 @@ class Shape:
         self.material = Material() if material is None else material
         self.casts_shadow = casts_shadow
         self.minimum_y, self.maximum_y, self.closed = minimum_y, maximum_y, closed
+        self.points = None  # Triangle: (p1, p2, p3)
 
     # reference setter names
     def set_transformation(self, t):
@@ -312,6 +313,9 @@ class Shape:
         o.closed = int(bool(self.closed))
         o.min_y = float(f32(self.minimum_y))
         o.max_y = float(f32(self.maximum_y))
+        if self.points is not None:
+            for name, p in zip(("p1", "p2", "p3"), self.points):
+                getattr(o, name)[:] = [float(v) for v in p[:3]]
         return o
 
     def local_intersect(self, origins, directions, device=0):
@@ -356,6 +360,36 @@ def Cylinder(transform=None, material=None, **kw):
     return Shape(L.RTC_CYLINDER, transform, material, **kw)
 
 
+def Triangle(p1, p2, p3, transform=None, material=None, **kw):
+    """Triangle::new(p1, p2, p3) -- shape/triangle.rs:19-33.  e1 / e2 / normal: see triangle_fields()."""
+    t = Shape(L.RTC_TRIANGLE, transform, material, **kw)
+    t.points = [_a(p, 4).copy() for p in (p1, p2, p3)]
+    return t
+
+
+def triangle_fields(tri):
+    """(e1, e2, normal) exactly as Triangle::new derives them (triangle.rs:20-22)."""
+    p1, p2, p3 = [_a(p[:3], 3) for p in tri.points]
+    out = [np.zeros(3, dtype=f32) for _ in range(3)]
+    L.lib().rtc_triangle_fields(_p(p1), _p(p2), _p(p3), *[_p(x) for x in out])
+    return [np.append(x, f32(0.0)) for x in out]
+
+
+def SmoothTriangle(p1, p2, p3, n1, n2, n3, transform=None, material=None, **kw):
+    """SmoothTriangle::new -- shape/smooth_triangle.rs:17-26.  Its local_intersect returns intersections whose
+    object is the inner flat Triangle (:37-39), so Camera::render shades it as one; that is what this does too.
+    The vertex normals are kept for local_norm_at_uv(), which restates :41-43 for hand-made hits."""
+    t = Triangle(p1, p2, p3, transform, material, **kw)
+    t.normals = [_a(n, 4).copy() for n in (n1, n2, n3)]
+
+    def local_norm_at_uv(u, v):
+        u, v = f32(u), f32(v)
+        n1_, n2_, n3_ = t.normals
+        return n2_ * u + n3_ * v + n1_ * (f32(1.0) - u - v)
+    t.local_norm_at_uv = local_norm_at_uv
+    return t
+
+
 # ------------------------------------------------- bounding_box.rs / shape/group.rs
 class BoundingBox:
     """bounding_box.rs:7-11 over the library's host helpers (rtc_bounds_*)."""
@@ -393,6 +427,10 @@ class BoundingBox:
 def _shape_bounds(shape, parent_space):
     mn, mx = np.zeros(4, dtype=f32), np.zeros(4, dtype=f32)
     t = _a(shape.transform, 16) if parent_space else None
+    if shape.points is not None:
+        p1, p2, p3 = [_a(p[:3], 3) for p in shape.points]
+        L.lib().rtc_triangle_bounds(_p(p1), _p(p2), _p(p3), _p(t) if t is not None else None, _p(mn), _p(mx))
+        return BoundingBox(mn, mx)
     L.check(L.lib().rtc_shape_bounds(shape.kind, float(f32(shape.minimum_y)), float(f32(shape.maximum_y)),
                                      _p(t) if t is not None else None, _p(mn), _p(mx)))
     return BoundingBox(mn, mx)

@@ -94,6 +94,14 @@ static void pack_geometry(const rtc_object& o, float4 g[4]) {
     g[2] = make_float4(o.inv[4], o.inv[6], o.inv[7], o.max_y);
     g[3] = make_float4(o.inv[8], o.inv[9], o.inv[11], 0.0f);
 }
+// The three triangle records of one object (see SceneSoA::tri); e1, e2, normal as Triangle::new derives them.
+static void pack_triangle(const rtc_object& o, float4 rec[3]) {
+    float e1[3], e2[3], nrm[3];
+    rtc_triangle_fields(o.p1, o.p2, o.p3, e1, e2, nrm);
+    rec[0] = make_float4(o.p1[0], o.p1[1], o.p1[2], nrm[0]);
+    rec[1] = make_float4(e1[0], e1[1], e1[2], nrm[1]);
+    rec[2] = make_float4(e2[0], e2[1], e2[2], nrm[2]);
+}
 // The five pattern records of one material (see SceneSoA::pat).
 static void pack_pattern(const rtc_pattern& pt, float4 rec[5]) {
     uint32_t kind = (uint32_t)pt.kind;
@@ -118,7 +126,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     const uint32_t n = scene->n_objects;
     hdr->n_objects = n;
     const uint32_t np = padded_count(n);  // stride of each SoA array
-    soa->assign((size_t)12 * np, make_float4(0, 0, 0, 0));
+    soa->assign((size_t)15 * np, make_float4(0, 0, 0, 0));
     {
         uint32_t none = SHAPE_NONE;
         float none_f;
@@ -127,8 +135,9 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     }
     for (uint32_t i = 0; i < n; i++) {
         const rtc_object& o = scene->objects[i];
-        if (o.kind < RTC_SPHERE || o.kind > RTC_CONE)
+        if (o.kind < RTC_SPHERE || o.kind > RTC_TRIANGLE)
             return fail(RTC_ERR_UNSUPPORTED, "object %u: shape kind %d is not on the device path", i, o.kind);
+        if (o.kind == RTC_TRIANGLE) pack_triangle(o, &(*soa)[12 * (size_t)np + 3 * (size_t)i]);
         if (!is_affine(o.inv))
             return fail(RTC_ERR_UNSUPPORTED,
                         "object %u: inverse transform's last row is not exactly [0,0,0,1] (projective transforms "
@@ -413,7 +422,8 @@ static SceneSoA soa_view(const float4* base, uint32_t n) {
     s.mat_b = base + 5 * (size_t)m;
     s.mat_c = base + 6 * (size_t)m;
     s.pat = base + 7 * (size_t)m;
-    s.trav = base + 12 * (size_t)m;
+    s.tri = base + 12 * (size_t)m;
+    s.trav = base + 15 * (size_t)m;
     return s;
 }
 
@@ -471,7 +481,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         uint32_t bits;
         std::memcpy(&bits, &soa[i].w, 4);  // geo[i].w
         const uint32_t kind = bits & SHAPE_KIND_MASK;
-        if (!(bits & SHAPE_DIAG) || kind == RTC_CYLINDER || kind == RTC_CONE) c->simple = false;
+        if (!(bits & SHAPE_DIAG) || kind == RTC_CYLINDER || kind == RTC_CONE || kind == RTC_TRIANGLE) c->simple = false;
     }
     c->has_scene = true;
     // which kernel will render this scene
@@ -831,7 +841,7 @@ rtc_status rtc_cosf(const float* x, uint32_t n, int32_t device, float* out) {
 }
 
 // One object's geometry as a kernel argument for the batched shape / pattern entry points.
-static rtc_status object_arg(const rtc_object* object, const char* who, Obj* ob) {
+static rtc_status object_arg(const rtc_object* object, const char* who, Obj* ob, DevBuf* d_tri) {
     rtc_object unit;
     if (!object) {  // an untransformed unit sphere
         std::memset(&unit, 0, sizeof(unit));
@@ -842,7 +852,7 @@ static rtc_status object_arg(const rtc_object* object, const char* who, Obj* ob)
         for (int i = 0; i < 4; i++) unit.inv[i * 5] = 1.0f;
         object = &unit;
     }
-    if (object->kind < RTC_SPHERE || object->kind > RTC_CONE)
+    if (object->kind < RTC_SPHERE || object->kind > RTC_TRIANGLE)
         return fail(RTC_ERR_UNSUPPORTED, "%s: shape kind %d is not on the device path", who, object->kind);
     if (!is_affine(object->inv)) return fail(RTC_ERR_UNSUPPORTED, "%s: inverse transform is not affine", who);
     float4 g[4];
@@ -852,6 +862,10 @@ static rtc_status object_arg(const rtc_object* object, const char* who, Obj* ob)
     ob->off1 = g[2];
     ob->off2 = g[3];
     std::memcpy(&ob->bits, &g[0].w, 4);
+    float4 tri[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    if (object->kind == RTC_TRIANGLE) pack_triangle(*object, tri);
+    HIP_TRY(d_tri->alloc(sizeof(tri)));
+    HIP_TRY(hipMemcpy(d_tri->p, tri, sizeof(tri), hipMemcpyHostToDevice));
     return RTC_OK;
 }
 
@@ -860,9 +874,10 @@ rtc_status rtc_local_intersect(const rtc_object* object, const float* origins, c
     if (!object || !origins || !directions || !out_t || !out_count)
         return fail(RTC_ERR_INVALID_ARG, "rtc_local_intersect: null argument");
     Obj ob;
-    rtc_status st = object_arg(object, "rtc_local_intersect", &ob);
+    DevBuf d_tri;
+    rtc_status st = select_device(device);
     if (st != RTC_OK) return st;
-    if ((st = select_device(device)) != RTC_OK) return st;
+    if ((st = object_arg(object, "rtc_local_intersect", &ob, &d_tri)) != RTC_OK) return st;
     if (n == 0) return RTC_OK;
     DevBuf d_o, d_d, d_t, d_c;
     HIP_TRY(d_o.alloc((size_t)n * 16));
@@ -871,7 +886,7 @@ rtc_status rtc_local_intersect(const rtc_object* object, const float* origins, c
     HIP_TRY(d_c.alloc((size_t)n * 4));
     HIP_TRY(hipMemcpy(d_o.p, origins, (size_t)n * 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_d.p, directions, (size_t)n * 16, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(local_intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, ob, (const float4*)d_o.p,
+    hipLaunchKernelGGL(local_intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, ob, (const float4*)d_tri.p, (const float4*)d_o.p,
                        (const float4*)d_d.p, n, (float4*)d_t.p, (int32_t*)d_c.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out_t, d_t.p, (size_t)n * 16, hipMemcpyDeviceToHost));
@@ -882,15 +897,16 @@ rtc_status rtc_local_intersect(const rtc_object* object, const float* origins, c
 rtc_status rtc_normal_at(const rtc_object* object, const float* world_points, uint32_t n, int32_t device, float* out) {
     if (!object || !world_points || !out) return fail(RTC_ERR_INVALID_ARG, "rtc_normal_at: null argument");
     Obj ob;
-    rtc_status st = object_arg(object, "rtc_normal_at", &ob);
+    DevBuf d_tri;
+    rtc_status st = select_device(device);
     if (st != RTC_OK) return st;
-    if ((st = select_device(device)) != RTC_OK) return st;
+    if ((st = object_arg(object, "rtc_normal_at", &ob, &d_tri)) != RTC_OK) return st;
     if (n == 0) return RTC_OK;
     DevBuf d_p, d_out;
     HIP_TRY(d_p.alloc((size_t)n * 16));
     HIP_TRY(d_out.alloc((size_t)n * 16));
     HIP_TRY(hipMemcpy(d_p.p, world_points, (size_t)n * 16, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(normal_at_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, ob, (const float4*)d_p.p, n,
+    hipLaunchKernelGGL(normal_at_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, ob, (const float4*)d_tri.p, (const float4*)d_p.p, n,
                        (float4*)d_out.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 16, hipMemcpyDeviceToHost));
@@ -904,9 +920,10 @@ rtc_status rtc_pattern_color_at(const rtc_pattern* pattern, const rtc_object* ob
         return fail(RTC_ERR_UNSUPPORTED, "rtc_pattern_color_at: pattern kind %d is not on the device path", pattern->kind);
     if (!is_affine(pattern->inv)) return fail(RTC_ERR_UNSUPPORTED, "rtc_pattern_color_at: pattern inverse transform is not affine");
     Obj ob;
-    rtc_status st = object_arg(object, "rtc_pattern_color_at", &ob);
+    DevBuf d_tri;
+    rtc_status st = select_device(device);
     if (st != RTC_OK) return st;
-    if ((st = select_device(device)) != RTC_OK) return st;
+    if ((st = object_arg(object, "rtc_pattern_color_at", &ob, &d_tri)) != RTC_OK) return st;
     if (n == 0) return RTC_OK;
     float4 rec[5];
     pack_pattern(*pattern, rec);

@@ -236,7 +236,10 @@ rtc_status rtc_pattern_init(rtc_pattern* out, int32_t kind, const float a[3], co
 
 rtc_status rtc_object_init(rtc_object* out, int32_t kind, const float transform[16], const rtc_material* m) {
     if (!out || !transform) return fail(RTC_ERR_INVALID_ARG, "rtc_object_init: null argument");
-    if (kind < RTC_SPHERE || kind > RTC_CONE) return fail(RTC_ERR_UNSUPPORTED, "rtc_object_init: unknown shape kind %d", kind);
+    if (kind < RTC_SPHERE || kind > RTC_TRIANGLE) return fail(RTC_ERR_UNSUPPORTED, "rtc_object_init: unknown shape kind %d", kind);
+    std::memset(out->p1, 0, sizeof(out->p1));
+    std::memset(out->p2, 0, sizeof(out->p2));
+    std::memset(out->p3, 0, sizeof(out->p3));
     out->kind = kind;
     out->casts_shadow = 1;  // base_shape.rs:31
     out->closed = 0;        // cylinder.rs:41
@@ -344,6 +347,34 @@ rtc_status rtc_shape_bounds(int32_t kind, float min_y, float max_y, const float 
         std::memcpy(mx, b, sizeof(b));
     }
     return RTC_OK;
+}
+
+void rtc_triangle_bounds(const float p1[3], const float p2[3], const float p3[3], const float transform[16], float mn[4],
+                         float mx[4]) {
+    float a[4], b[4];
+    rtc_bounds_empty(a, b);  // triangle.rs:74-80
+    const float* ps[3] = {p1, p2, p3};
+    for (const float* p : ps) {
+        const float q[4] = {p[0], p[1], p[2], 1.0f};
+        bounds_add_point(a, b, q);
+    }
+    if (transform) {
+        rtc_bounds_transform(a, b, transform, mn, mx);
+    } else {
+        std::memcpy(mn, a, sizeof(a));
+        std::memcpy(mx, b, sizeof(b));
+    }
+}
+void rtc_triangle_fields(const float p1[3], const float p2[3], const float p3[3], float e1[3], float e2[3], float normal[3]) {
+    for (int k = 0; k < 3; k++) {
+        e1[k] = p2[k] - p1[k];
+        e2[k] = p3[k] - p1[k];
+    }
+    const float a[4] = {e2[0], e2[1], e2[2], 0.0f}, b[4] = {e1[0], e1[1], e1[2], 0.0f};
+    float c[4], n[4];
+    rtc_cross(a, b, c);
+    rtc_norm(c, n);
+    for (int k = 0; k < 3; k++) normal[k] = n[k];
 }
 
 void rtc_point_light(const float position[4], const float intensity[3], rtc_light* out) {

@@ -38,7 +38,7 @@ typedef unsigned long size_t;
 // rtc.h needs <stddef.h>/<stdint.h>, which hiprtc does not ship: restate the few constants the device
 // code uses (the ahead-of-time build below static_asserts that they agree with rtc.h).
 #define RTC_MAX_DEPTH 8
-enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3, RTC_CONE = 4 };
+enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3, RTC_CONE = 4, RTC_TRIANGLE = 5 };
 enum { RTC_PATTERN_NONE = 0, RTC_PATTERN_STRIPES = 1, RTC_PATTERN_GRADIENT = 2, RTC_PATTERN_RINGS = 3,
        RTC_PATTERN_CHECKERS = 4, RTC_PATTERN_SINE2D = 5 };
 enum { RTC_LIGHT_POINT = 0, RTC_LIGHT_RECT = 1 };
@@ -51,7 +51,7 @@ enum { RTC_JITTER_CONSTANT = 0, RTC_JITTER_HASHED = 2 };
 #include "rtc.h"
 #define RTC_HOSTDEV __host__ __device__
 static_assert(RTC_MAX_DEPTH == 8 && RTC_SPHERE == 0 && RTC_PLANE == 1 && RTC_CUBE == 2 && RTC_CYLINDER == 3 &&
-                  RTC_CONE == 4 && RTC_PATTERN_NONE == 0 && RTC_PATTERN_STRIPES == 1 && RTC_PATTERN_GRADIENT == 2 &&
+                  RTC_CONE == 4 && RTC_TRIANGLE == 5 && RTC_PATTERN_NONE == 0 && RTC_PATTERN_STRIPES == 1 && RTC_PATTERN_GRADIENT == 2 &&
                   RTC_PATTERN_RINGS == 3 && RTC_PATTERN_CHECKERS == 4 && RTC_PATTERN_SINE2D == 5 && RTC_LIGHT_POINT == 0 && RTC_LIGHT_RECT == 1 && RTC_JITTER_CONSTANT == 0 && RTC_JITTER_HASHED == 2,
               "rtc_kernel_core.h restates these rtc.h constants for the hiprtc build");
 #endif
@@ -363,6 +363,9 @@ struct SceneSoA {
     //   group: { bounds.min.xyz, skip }, { bounds.max.xyz, TRAV_GROUP }   skip = entry index after the group's subtree
     //   leaf : { 0, 0, 0, object index }, { 0, 0, 0, TRAV_LEAF }
     const float4* __restrict__ trav;
+    // Triangles (shape/triangle.rs:9-17), 3 records per object, read only for RTC_TRIANGLE objects:
+    //   { p1.xyz, normal.x }, { e1.xyz, normal.y }, { e2.xyz, normal.z }
+    const float4* __restrict__ tri;
 };
 enum : uint32_t { TRAV_GROUP = 0u, TRAV_LEAF = 1u };
 enum : uint32_t {
@@ -478,8 +481,13 @@ DI float quadratic_c(uint32_t kind, V3 o) {
 // HITS_ONLY: the caller only looks at distances >= 0 (hit selection, shadow tests), so an
 // intersection that is provably negative need not be evaluated; refraction_indices() needs the
 // negative ones too and passes false.
+// tuple.rs:47-55
+DI V3 cross3(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+// `tri` / `i`: the triangle records and this object's index (wave-uniform); only read for RTC_TRIANGLE.
 template <bool HITS_ONLY, class F>
-DI void local_intersect_c(uint32_t bits, float min_y, float max_y, V3 o, V3 d, float c, F&& f) {
+DI void local_intersect_c(uint32_t bits, float min_y, float max_y, const float4* __restrict__ tri, uint32_t i, V3 o, V3 d,
+                          float c, F&& f) {
     const uint32_t kind = bits & SHAPE_KIND_MASK;
     if (kind == RTC_SPHERE) {  // sphere.rs:47-70
         float a = d.x * d.x + d.y * d.y + d.z * d.z;
@@ -549,6 +557,21 @@ DI void local_intersect_c(uint32_t bits, float min_y, float max_y, V3 o, V3 d, f
             cz = o.z + t * d.z;
             if ((cx * cx + cz * cz) <= 1.0f + CLOSE_TO_ZERO) f(t);
         }
+    } else if (kind == RTC_TRIANGLE) {  // triangle.rs:45-68 (Moeller-Trumbore as written there)
+        const float4 t0 = load_uniform(tri, 3u * i), t1 = load_uniform(tri, 3u * i + 1u), t2 = load_uniform(tri, 3u * i + 2u);
+        const V3 p1 = v3(t0.x, t0.y, t0.z), e1 = v3(t1.x, t1.y, t1.z), e2 = v3(t2.x, t2.y, t2.z);
+        V3 dir_cross_e2 = cross3(d, e2);
+        float determinant = dot3(e1, dir_cross_e2);
+        if (!(fabsf(determinant) < 0.0000001f)) {
+            float fi = 1.0f / determinant;
+            V3 p1_to_origin = o - p1;
+            float u = fi * dot3(p1_to_origin, dir_cross_e2);
+            if (!(u < 0.0f || u > 1.0f)) {
+                V3 origin_cross_e1 = cross3(p1_to_origin, e1);
+                float v = fi * dot3(d, origin_cross_e1);
+                if (!(v < 0.0f || (u + v) > 1.0f)) f(fi * dot3(e2, origin_cross_e1));
+            }
+        }
     } else if (kind == RTC_CONE) {  // cone.rs:52-57: sides (:89-141), then -- always -- caps (:156-175)
         float two_a = 2.0f * (d.x * d.x - d.y * d.y + d.z * d.z);
         float b = 2.0f * (o.x * d.x - o.y * d.y + o.z * d.z);
@@ -585,13 +608,14 @@ DI void local_intersect_c(uint32_t bits, float min_y, float max_y, V3 o, V3 d, f
 }
 
 template <bool HITS_ONLY, class F>
-DI void local_intersect(uint32_t bits, float min_y, float max_y, V3 o, V3 d, F&& f) {
-    local_intersect_c<HITS_ONLY>(bits, min_y, max_y, o, d, quadratic_c(bits & SHAPE_KIND_MASK, o), f);
+DI void local_intersect(uint32_t bits, float min_y, float max_y, const float4* __restrict__ tri, uint32_t i, V3 o, V3 d, F&& f) {
+    local_intersect_c<HITS_ONLY>(bits, min_y, max_y, tri, i, o, d, quadratic_c(bits & SHAPE_KIND_MASK, o), f);
 }
 
 // local_norm_at (sphere.rs:71-73, plane.rs:57-59, cube.rs:66-80, cylinder.rs:62-72, cone.rs:60-73)
-DI V3 local_normal(uint32_t kind, float min_y, float max_y, V3 p) {
+DI V3 local_normal(uint32_t kind, float min_y, float max_y, const float4* __restrict__ tri, V3 p) {
     if (kind == RTC_SPHERE) return p;
+    if (kind == RTC_TRIANGLE) return v3(tri[0].w, tri[1].w, tri[2].w);  // triangle.rs:70-72: the stored normal
     if (kind == RTC_PLANE) return v3(0.0f, 1.0f, 0.0f);
     if (kind == RTC_CUBE) {
         float xa = fabsf(p.x), ya = fabsf(p.y), za = fabsf(p.z);
@@ -705,7 +729,7 @@ DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d) {
         if ((ob.bits & SHAPE_KIND_MASK) == SHAPE_NONE) return;  // padding record (wave-uniform)
         V3 po = obj_point(ob, o);
         V3 pd = obj_vector(ob, d);
-        local_intersect<true>(ob.bits, ob.min_y(), ob.max_y(), po, pd, [&](float t) {
+        local_intersect<true>(ob.bits, ob.min_y(), ob.max_y(), S.tri, i, po, pd, [&](float t) {
             if (t >= 0.0f && (best.obj < 0 || t < best.t)) {
                 best.t = t;
                 best.obj = (int)i;
@@ -833,7 +857,7 @@ DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* p
             mn = S.off0[i].w;
             mx = S.off1[i].w;
         }
-        local_intersect_c<true>(bits, mn, mx, pre[i].o, pd, pre[i].c, f);
+        local_intersect_c<true>(bits, mn, mx, S.tri, i, pre[i].o, pd, pre[i].c, f);
     };
     // pass 1: shadow casters
     bool found = false;
@@ -997,7 +1021,7 @@ DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int
         V3 pd = obj_vector(ob, d);
         int negatives = 0;
         float tmax = 0.0f;
-        local_intersect<false>(ob.bits, ob.min_y(), ob.max_y(), po, pd, [&](float t) {
+        local_intersect<false>(ob.bits, ob.min_y(), ob.max_y(), S.tri, i, po, pd, [&](float t) {
             if (t < 0.0f) {
                 if (negatives == 0 || t > tmax) tmax = t;
                 negatives++;
@@ -1098,7 +1122,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                 Obj rec = load_obj(S, ob);
                 V3 point = o + d * h.t;
                 V3 op = obj_point(rec, point);
-                n = obj_normal_to_world(rec, local_normal(rec.bits & SHAPE_KIND_MASK, rec.min_y(), rec.max_y(), op));
+                n = obj_normal_to_world(rec, local_normal(rec.bits & SHAPE_KIND_MASK, rec.min_y(), rec.max_y(), S.tri + 3 * ob, op));
                 inside = dot3(n, -d) < 0.0f;
                 if (inside) n = -n;
                 over_point = point + n * SELF_EPS;
@@ -1528,14 +1552,15 @@ __global__ void cosf_kernel(const float* __restrict__ x, uint32_t n, float* __re
 }
 
 // Shape::local_intersect for caller-supplied object-space rays: up to 4 distances per ray, in push order.
-__global__ void local_intersect_kernel(Obj ob, const float4* __restrict__ origins, const float4* __restrict__ directions,
-                                       uint32_t n, float4* __restrict__ out_t, int32_t* __restrict__ out_count) {
+__global__ void local_intersect_kernel(Obj ob, const float4* __restrict__ tri, const float4* __restrict__ origins,
+                                       const float4* __restrict__ directions, uint32_t n, float4* __restrict__ out_t,
+                                       int32_t* __restrict__ out_count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 o = origins[i], d = directions[i];
     float ts[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     int count = 0;
-    local_intersect<false>(ob.bits, ob.min_y(), ob.max_y(), v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), [&](float t) {
+    local_intersect<false>(ob.bits, ob.min_y(), ob.max_y(), tri, 0u, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), [&](float t) {
         if (count < 4) ts[count] = t;
         count++;
     });
@@ -1544,12 +1569,13 @@ __global__ void local_intersect_kernel(Obj ob, const float4* __restrict__ origin
 }
 
 // Shape::normal_at (shape.rs:72-154) for caller-supplied world points.
-__global__ void normal_at_kernel(Obj ob, const float4* __restrict__ points, uint32_t n, float4* __restrict__ out) {
+__global__ void normal_at_kernel(Obj ob, const float4* __restrict__ tri, const float4* __restrict__ points, uint32_t n,
+                                 float4* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 p = points[i];
     V3 op = obj_point(ob, v3(p.x, p.y, p.z));
-    V3 nn = obj_normal_to_world(ob, local_normal(ob.bits & SHAPE_KIND_MASK, ob.min_y(), ob.max_y(), op));
+    V3 nn = obj_normal_to_world(ob, local_normal(ob.bits & SHAPE_KIND_MASK, ob.min_y(), ob.max_y(), tri, op));
     out[i] = make_float4(nn.x, nn.y, nn.z, 0.0f);
 }
 

@@ -294,6 +294,71 @@ def groups_medley(width=256, height=192, jitter=("hashed", 3)):
     return world, camera, 5
 
 
+def bumpy_mesh_obj(nu=16, nv=10, with_normals=False):
+    """A closed, bumpy UV-sphere as Wavefront OBJ text (quads + two triangle fans), the kind of input the
+    reference's `here_be_dragons` demo reads from a file that is not in its repository."""
+    import math
+    lines = ["# procedural test mesh: %d x %d" % (nu, nv)]
+    verts = []
+    for j in range(1, nv):
+        th = math.pi * j / nv
+        for i in range(nu):
+            ph = 2.0 * math.pi * i / nu
+            r = 1.0 + 0.15 * math.sin(3 * ph) * math.sin(2 * th)
+            verts.append((r * math.sin(th) * math.cos(ph), r * math.cos(th), r * math.sin(th) * math.sin(ph)))
+    verts.append((0.0, 1.0, 0.0))
+    verts.append((0.0, -1.0, 0.0))
+    for v in verts:
+        lines.append("v %.5f %.5f %.5f" % v)
+    if with_normals:
+        for v in verts:
+            n = math.sqrt(sum(c * c for c in v))
+            lines.append("vn %.4f %.4f %.4f" % tuple(c / n for c in v))
+    top, bottom = len(verts) - 1, len(verts)
+
+    def ref(k):
+        return "%d//%d" % (k, k) if with_normals else "%d" % k
+    lines.append("g body")
+    for j in range(nv - 2):
+        for i in range(nu):
+            a = j * nu + i + 1
+            b = j * nu + (i + 1) % nu + 1
+            lines.append("f %s %s %s %s" % (ref(a), ref(b), ref(b + nu), ref(a + nu)))
+    lines.append("g caps")
+    for i in range(nu):
+        a, b = i + 1, (i + 1) % nu + 1
+        lines.append("f %s %s %s" % (ref(top), ref(b), ref(a)))
+        a2, b2 = (nv - 2) * nu + i + 1, (nv - 2) * nu + (i + 1) % nu + 1
+        lines.append("f %s %s %s" % (ref(bottom), ref(a2), ref(b2)))
+    return "\n".join(lines) + "\n"
+
+
+def mesh_objects(api, nu=16, nv=10, threshold=6):
+    """Two parsed OBJ meshes (one flat-shaded, one with vertex normals) as divided GroupShapes, a loose
+    top-level triangle and a floor."""
+    from .obj_parser import parse_obj
+    flat = parse_obj(bumpy_mesh_obj(nu, nv, False), api).take_all_as_group()
+    flat.set_material(api.Material(color=(0.9, 0.4, 0.2), diffuse=0.7, specular=0.4, shininess=60.0, reflective=0.1))
+    flat.set_transformation(api.chain(api.translation(-1.3, 1.0, 0.0), api.rotation_y(f32(0.5))))
+    flat.divide(threshold)
+    smooth = parse_obj(bumpy_mesh_obj(nu, nv, True), api).take_all_as_group()
+    smooth.set_material(api.Material(color=(0.1, 0.1, 0.15), transparency=0.85, refractive_index=1.52, reflective=0.5,
+                                     diffuse=0.3))
+    smooth.set_transformation(api.chain(api.translation(1.4, 0.8, 0.4), api.scaling(0.8, 0.8, 0.8)))
+    smooth.divide(threshold)
+    sail = api.Triangle(point(-0.5, 0.0, 2.5), point(1.0, 0.0, 2.2), point(0.2, 2.6, 2.4), None,
+                        api.Material(pattern=api.Stripes((0.2, 0.5, 0.9), (0.9, 0.9, 0.9), api.scaling(0.2, 0.2, 0.2))))
+    floor = api.Plane(api.identity_4x4(), api.Material(color=(0.8, 0.8, 0.75), specular=0.0, reflective=0.2))
+    return [floor, flat, smooth, sail]
+
+
+def mesh(width=512, height=384, nu=16, nv=10, threshold=6):
+    from . import api
+    world = World(mesh_objects(api, nu, nv, threshold), PointLight(point(-6, 8, -8), color(1, 1, 1)))
+    camera = Camera(width, height, PI / f32(3.0), view_transform(point(0.2, 2.2, -5.5), point(0, 0.8, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
 def shapes_medley(width=256, height=192, jitter=("hashed", 7)):
     """All four shape kinds, nested transparent objects, a non-casting object and an area light:
     a parity stress scene (not a reference demo).  The cylinders are the reflect_refract.rs one

@@ -16,8 +16,14 @@ def oracle_shape(s):
     pat = None if m.pattern is None else O.Pattern(m.pattern.kind, m.pattern.a, m.pattern.b, m.pattern.transform)
     om = O.Material(m.color, m.ambient, m.diffuse, m.specular, m.shininess, m.reflective, m.transparency,
                     m.refractive_index, pat)
-    return O.Shape(s.kind, s.transform, om, casts_shadow=s.casts_shadow, minimum_y=s.minimum_y,
-                   maximum_y=s.maximum_y, closed=s.closed)
+    out = O.Shape(s.kind, s.transform, om, casts_shadow=s.casts_shadow, minimum_y=s.minimum_y,
+                  maximum_y=s.maximum_y, closed=s.closed)
+    if getattr(s, "points", None) is not None:
+        out.points = [np.asarray(p, dtype=f32) for p in s.points]
+        if getattr(s, "normals", None) is not None:  # the oracle's SmoothTriangle (kind 6) renders flat on its own
+            out.kind = O.SMOOTH_TRIANGLE
+            out.normals = [np.asarray(n, dtype=f32) for n in s.normals]
+    return out
 
 
 def oracle_world(world):

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(L.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert P.lib().rtc_abi_version() == 3
+    assert P.lib().rtc_abi_version() == 4
 
 
 @pytest.mark.parametrize("name", ["soft_shadows", "first_scene", "first_plane", "glass_and_mirror", "shapes_medley",
@@ -108,7 +108,7 @@ def test_pattern_and_cone_boundary_errors_without_gpu():
     ident = np.eye(4, dtype=f32).reshape(-1)
     assert L.lib().rtc_object_init(C.byref(obj), L.RTC_CONE, ident.ctypes.data_as(L.FP), None) == L.RTC_OK
     assert obj.min_y == -np.inf and obj.max_y == np.inf and obj.closed == 0                      # cone.rs:33-42
-    assert L.lib().rtc_object_init(C.byref(obj), 5, ident.ctypes.data_as(L.FP), None) == L.RTC_ERR_UNSUPPORTED
+    assert L.lib().rtc_object_init(C.byref(obj), 6, ident.ctypes.data_as(L.FP), None) == L.RTC_ERR_UNSUPPORTED
 
 
 def _libm_powf():

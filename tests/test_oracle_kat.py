@@ -611,3 +611,38 @@ def test_group_divide(kat):  # shape/group.rs:458-639
     sub = ch[1].get_children()
     K.assert_exact(sub[0].transformation(), O.translation(*c["s2"]))
     K.assert_exact(sub[1].transformation(), O.translation(*c["s3"]))
+
+
+def _default_triangle(kat, api=O):
+    c = kat["triangle"]["default"]
+    return api.Triangle(K.point(c["p1"]), K.point(c["p2"]), K.point(c["p3"]))
+
+
+def test_triangle(kat):  # shape/triangle.rs:101-176
+    T = kat["triangle"]
+    t = _default_triangle(kat)
+    e1, e2, normal = t.triangle_fields()
+    K.assert_exact(e1, K.vector(T["construction"]["e1"]))
+    K.assert_exact(e2, K.vector(T["construction"]["e2"]))
+    K.assert_exact(normal, K.vector(T["construction"]["normal"]))
+    for p in T["normal_points"]["points"]:
+        K.assert_exact(t.local_norm_at(K.point(p)), normal)
+    for o, d in T["misses"]["rays"]:
+        assert t.local_intersect(K.point(o), K.vector(d)) == []
+    ts = t.local_intersect(K.point(T["strikes"]["ray"][0]), K.vector(T["strikes"]["ray"][1]))
+    assert ts == [f32(T["strikes"]["distance_exact"])]
+    c = T["bounding_box"]
+    b = O.Triangle(*[K.point(p) for p in c["points"]]).bounding_box()
+    K.assert_exact(b.min, K.point(c["min"]))
+    K.assert_exact(b.max, K.point(c["max"]))
+
+
+def test_smooth_triangle(kat):  # shape/smooth_triangle.rs:71-107
+    T = kat["triangle"]
+    c, d = T["smooth"], T["default"]
+    t = O.SmoothTriangle(K.point(d["p1"]), K.point(d["p2"]), K.point(d["p3"]), K.vector(c["n1"]), K.vector(c["n2"]), K.vector(c["n3"]))
+    (hit,) = t.local_intersect_uv(K.point(c["uv_ray"][0]), K.vector(c["uv_ray"][1]))
+    assert hit[1] == f32(c["u_exact"]) and hit[2] == f32(c["v_exact"])
+    K.assert_eps(t.normal_at_uv(O.point(0, 0, 0), c["u_exact"], c["v_exact"]), c["interpolated_normal_eps"])
+    # what a render sees: the hit object is the inner flat Triangle (smooth_triangle.rs:37-39)
+    K.assert_exact(t.normal_at(O.point(0, 0.5, 0)), K.vector(T["construction"]["normal"]))
