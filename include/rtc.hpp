@@ -181,6 +181,7 @@ struct Shape {
     float minimum_y = -std::numeric_limits<float>::infinity();  // cylinder.rs:39-41
     float maximum_y = std::numeric_limits<float>::infinity();
     bool closed = false;
+    Tuple p1{0, 0, 0, 1}, p2{0, 0, 0, 1}, p3{0, 0, 0, 1};  // Triangle (triangle.rs:11-13)
     // GroupShape state (shape/group.rs:12-16)
     std::vector<Shape> children;
     Matrix group_t_inverse = identity_4x4();   // BaseShape.t_inverse of the group itself (default: not an inversion)
@@ -210,6 +211,10 @@ struct Shape {
     void set_casts_shadow(bool v) { casts_shadow = v; }
     BoundingBox bounding_box() {  // group.rs:138-151 / the leaf kinds' bounding_box()
         BoundingBox b;
+        if (kind == RTC_TRIANGLE) {
+            rtc_triangle_bounds(p1.data(), p2.data(), p3.data(), nullptr, &b.min.x, &b.max.x);
+            return b;
+        }
         if (!is_group()) {
             check(rtc_shape_bounds(kind, minimum_y, maximum_y, nullptr, &b.min.x, &b.max.x));
             return b;
@@ -224,7 +229,8 @@ struct Shape {
     BoundingBox parent_space_bounding_box() {  // shape.rs:162-164 / group.rs:153-155
         if (is_group()) return bounding_box();
         BoundingBox b;
-        check(rtc_shape_bounds(kind, minimum_y, maximum_y, transform.m, &b.min.x, &b.max.x));
+        if (kind == RTC_TRIANGLE) rtc_triangle_bounds(p1.data(), p2.data(), p3.data(), transform.m, &b.min.x, &b.max.x);
+        else check(rtc_shape_bounds(kind, minimum_y, maximum_y, transform.m, &b.min.x, &b.max.x));
         return b;
     }
     void divide(size_t threshold) {  // group.rs:157-172; a no-op for leaves (shape.rs:167)
@@ -261,6 +267,7 @@ struct Shape {
         o.closed = closed;
         o.min_y = minimum_y;
         o.max_y = maximum_y;
+        for (int k = 0; k < 3; k++) o.p1[k] = p1.data()[k], o.p2[k] = p2.data()[k], o.p3[k] = p3.data()[k];
         return o;
     }
 };
@@ -283,6 +290,13 @@ struct Cylinder : Shape {
 struct Cone : Shape {  // cone.rs:12-42: minimum_y / maximum_y / closed are pub fields, as on Cylinder
     Cone() : Shape(RTC_CONE) {}
     static Cone build(Matrix t, Material m) { Cone s; s.transform = t; s.material = m; return s; }
+};
+struct Triangle : Shape {  // triangle.rs:19-33; e1, e2 and the normal are derived inside the library
+    Triangle(Tuple a, Tuple b, Tuple c) : Shape(RTC_TRIANGLE) { p1 = a, p2 = b, p3 = c; }
+};
+struct SmoothTriangle : Triangle {  // smooth_triangle.rs: renders through its inner flat Triangle (:37-39)
+    Tuple n1, n2, n3;
+    SmoothTriangle(Tuple a, Tuple b, Tuple c, Tuple na, Tuple nb, Tuple nc) : Triangle(a, b, c), n1(na), n2(nb), n3(nc) {}
 };
 struct GroupShape : Shape {  // shape/group.rs
     GroupShape() : Shape(GROUP) {}
