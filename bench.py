@@ -145,18 +145,19 @@ def main():
 
     st = renderer.stats()  # counters of the last launch + mean kernel time over the K timed launches
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    counts = torch.tensor([st["rays"], st["shaded_hits"], st["pixels"]], dtype=torch.float64, device=device)
+    counts = torch.tensor([st["rays"], st["shaded_hits"], st["pixels"], st["culled_shadow_rays"]], dtype=torch.float64,
+                          device=device)
     kern = torch.tensor([st["kernel_ms"]], dtype=torch.float64, device=device)
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(kern, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    rays, shaded, pixels = (int(v) for v in counts.tolist())
+    rays, shaded, pixels, culled = (int(v) for v in counts.tolist())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        n_obj = len(world.objects)
+        n_obj = len(world._c().leaves)  # leaf shapes (GroupShapes flattened)
         # roofline of the dominant kernel (render_kernel) on THIS rank: per-launch algorithmic bytes / mean duration
         algo_bytes = st["rays"] * n_obj * 64 + st["shaded_hits"] * 48 + st["pixels"] * 12
         achieved = algo_bytes / (st["kernel_ms"] * 1e-3) / 1e9 if st["kernel_ms"] > 0 else 0.0
@@ -180,6 +181,9 @@ def main():
                                    "jitter seed 0x5EED5EED" % (args.size, args.size) if args.scene == "soft_shadows"
                        else "%s %dx%d" % (args.scene, args.size, args.size),
                        "rays_per_frame": rays, "shaded_hits_per_frame": shaded, "pixels_per_frame": pixels,
+                       # of rays_per_frame: area-light shadow rays whose answer followed from the conservative
+                       # light-cone cull (no object test needed); they are counted because the reference casts them
+                       "shadow_rays_resolved_by_light_cone_cull": culled,
                        "partition": "64-row bands round-robin over %d rank(s)%s" % (
                            world_size, ", RCCL gather of f32 rows to rank 0" if world_size > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

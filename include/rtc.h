@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTC_ABI_VERSION 4
+#define RTC_ABI_VERSION 5
 /* maximum reflection_recursion_depth accepted (reference default: 5, constants.rs:4) */
 #define RTC_MAX_DEPTH 8
 
@@ -165,6 +165,8 @@ typedef struct rtc_stats {
     float kernel_ms;      /* mean HIP-event time of the render kernel over `launches`                          */
     uint32_t launches;    /* render launches since the previous rtc_ctx_stats call                             */
     uint32_t rows;        /* rows written to the output buffer                                                 */
+    uint64_t culled_shadow_rays; /* of `rays`: area-light shadow rays whose answer ("lit") followed from the
+                                    conservative light-cone cull, i.e. that tested no object       */
 } rtc_stats;
 
 typedef struct rtc_ctx rtc_ctx;

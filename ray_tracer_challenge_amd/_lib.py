@@ -69,7 +69,8 @@ class rtc_partition(C.Structure):
 
 class rtc_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("shaded_hits", C.c_uint64), ("pixels", C.c_uint64),
-                ("kernel_ms", C.c_float), ("launches", C.c_uint32), ("rows", C.c_uint32)]
+                ("kernel_ms", C.c_float), ("launches", C.c_uint32), ("rows", C.c_uint32),
+                ("culled_shadow_rays", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/rtc.h

@@ -761,7 +761,8 @@ class Camera:
         L.check(L.lib().rtc_render(C.byref(cs.scene), C.byref(self._cam), int(reflection_recursion_depth), device,
                                    _p(img), C.byref(stats)))
         self.last_stats = {"rays": int(stats.rays), "shaded_hits": int(stats.shaded_hits),
-                           "pixels": int(stats.pixels), "kernel_ms": float(stats.kernel_ms)}
+                           "pixels": int(stats.pixels), "kernel_ms": float(stats.kernel_ms),
+                           "culled_shadow_rays": int(stats.culled_shadow_rays)}
         return Canvas(self.width, self.height, img)
 
 

@@ -126,7 +126,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     const uint32_t n = scene->n_objects;
     hdr->n_objects = n;
     const uint32_t np = padded_count(n);  // stride of each SoA array
-    soa->assign((size_t)15 * np, make_float4(0, 0, 0, 0));
+    soa->assign((size_t)18 * np, make_float4(0, 0, 0, 0));
     {
         uint32_t none = SHAPE_NONE;
         float none_f;
@@ -233,6 +233,31 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         hdr->jitter_mode = l.jitter_mode;
         hdr->jitter_const = l.jitter_const;
         hdr->jitter_seed = l.jitter_seed;
+        // light-cone culling inputs: the parallelogram's corners in every object's space, and its y range
+        const float su = (float)l.u_steps, sv = (float)l.v_steps;
+        float cw[4][3];
+        float y_lo = INFINITY, y_hi = -INFINITY, y_abs = 0.0f;
+        for (int k = 0; k < 4; k++) {
+            const float fu = (k == 1 || k == 2) ? su : 0.0f, fv = (k >= 2) ? sv : 0.0f;
+            for (int a = 0; a < 3; a++) cw[k][a] = l.corner[a] + l.u_vec[a] * fu + l.v_vec[a] * fv;
+            y_lo = fminf(y_lo, cw[k][1]);
+            y_hi = fmaxf(y_hi, cw[k][1]);
+            y_abs += fabsf(cw[k][1]);
+        }
+        const float ym = 1e-5f * y_abs + 1e-30f;  // far above the sample points' rounding error
+        hdr->light_y_lo = y_lo - ym;
+        hdr->light_y_hi = y_hi + ym;
+        for (uint32_t i = 0; i < n; i++) {
+            const float* m = scene->objects[i].inv;
+            float c[4][3];
+            for (int k = 0; k < 4; k++)
+                for (int r = 0; r < 3; r++)
+                    c[k][r] = m[4 * r] * cw[k][0] + m[4 * r + 1] * cw[k][1] + m[4 * r + 2] * cw[k][2] + m[4 * r + 3];
+            float4* rec = &(*soa)[15 * (size_t)np + 3 * (size_t)i];
+            rec[0] = make_float4(c[0][0], c[0][1], c[0][2], c[1][0]);
+            rec[1] = make_float4(c[1][1], c[1][2], c[2][0], c[2][1]);
+            rec[2] = make_float4(c[2][2], c[3][0], c[3][1], c[3][2]);
+        }
     } else if (l.kind != RTC_LIGHT_POINT) {
         return fail(RTC_ERR_UNSUPPORTED, "light kind %d", l.kind);
     }
@@ -272,9 +297,9 @@ struct rtc_ctx {
     size_t ppm_rows_cap = 0, ppm_bits_cap = 0;
     hipFunction_t spec_fn = nullptr;  // scene-specialised kernel (hiprtc), or null: ahead-of-time kernels
     std::string kernel_name;          // what rtc_ctx_render launches, for rtc_ctx_kernel_name()
-    uint2* d_block_counts = nullptr;
+    uint4* d_block_counts = nullptr;
     size_t block_cap = 0;
-    unsigned long long* d_total = nullptr;  // {rays, shaded hits} of the last launch
+    unsigned long long* d_total = nullptr;  // {rays, shaded hits, culled shadow rays} of the last launch
     // HIP-event pairs around the render kernel, one per launch since the last rtc_ctx_stats
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -423,7 +448,8 @@ static SceneSoA soa_view(const float4* base, uint32_t n) {
     s.mat_c = base + 6 * (size_t)m;
     s.pat = base + 7 * (size_t)m;
     s.tri = base + 12 * (size_t)m;
-    s.trav = base + 15 * (size_t)m;
+    s.lcorn = base + 15 * (size_t)m;
+    s.trav = base + 18 * (size_t)m;
     return s;
 }
 
@@ -439,8 +465,8 @@ rtc_status rtc_ctx_create(int32_t device, rtc_ctx** out) {
     HIP_TRY(hipSetDevice(device));
     rtc_ctx* c = new rtc_ctx();
     c->device = device;
-    HIP_TRY(hipMalloc(&c->d_total, 2 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->d_total, 0, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&c->d_total, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_total, 0, 3 * sizeof(unsigned long long)));
     *out = c;
     return RTC_OK;
 }
@@ -538,7 +564,7 @@ rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, 
     if (n_blocks > c->block_cap) {  // grow-only workspace (first call / larger image only)
         if (c->d_block_counts) HIP_TRY(hipFree(c->d_block_counts));
         c->d_block_counts = nullptr;
-        HIP_TRY(hipMalloc(&c->d_block_counts, n_blocks * sizeof(uint2)));
+        HIP_TRY(hipMalloc(&c->d_block_counts, n_blocks * sizeof(uint4)));
         c->block_cap = n_blocks;
     }
     // traced pixels among this partition's rows: x < w-1, y < h-1
@@ -605,7 +631,7 @@ rtc_status rtc_ctx_stats(rtc_ctx* c, rtc_stats* out) {
     out->pixels = c->last_pixels;
     if (!c->rendered) return RTC_OK;
     HIP_TRY(hipSetDevice(c->device));
-    unsigned long long total[2] = {0, 0};
+    unsigned long long total[3] = {0, 0, 0};
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(total, c->d_total, sizeof(total), hipMemcpyDeviceToHost));
     double sum_ms = 0.0;
@@ -616,6 +642,7 @@ rtc_status rtc_ctx_stats(rtc_ctx* c, rtc_stats* out) {
     }
     out->rays = total[0];
     out->shaded_hits = total[1];
+    out->culled_shadow_rays = total[2];
     out->launches = (uint32_t)c->events_used;
     out->kernel_ms = c->events_used ? (float)(sum_ms / (double)c->events_used) : 0.0f;
     c->events_used = 0;

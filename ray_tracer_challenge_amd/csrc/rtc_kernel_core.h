@@ -336,6 +336,7 @@ struct SceneHdr {
     float cam_origin[3];  // transform_inverse * point(0,0,0), camera.rs:70
     uint32_t has_patterns;  // some material carries a pattern (wave-uniform switch around the pattern code)
     uint32_t n_trav;        // entries in SceneSoA::trav; 0: the world is a flat object list
+    float light_y_lo, light_y_hi;  // world-space y range of the area light's sample points, widened (light-cone culling)
 };
 
 // Structure-of-arrays scene records in HBM: 4 float4 of geometry (64 B) and
@@ -366,6 +367,9 @@ struct SceneSoA {
     // Triangles (shape/triangle.rs:9-17), 3 records per object, read only for RTC_TRIANGLE objects:
     //   { p1.xyz, normal.x }, { e1.xyz, normal.y }, { e2.xyz, normal.z }
     const float4* __restrict__ tri;
+    // Light-cone culling: the area light's four corners (around the parallelogram) in each object's own space,
+    // 3 records per object: { c0.xyz, c1.x }, { c1.yz, c2.xy }, { c2.z, c3.xyz }.  Approximate values (margins apply).
+    const float4* __restrict__ lcorn;
 };
 enum : uint32_t { TRAV_GROUP = 0u, TRAV_LEAF = 1u };
 enum : uint32_t {
@@ -645,8 +649,10 @@ struct Hit {
 // per-lane work counters (reduced per workgroup at kernel end)
 struct Counters {
     uint32_t rays;    // World::intersect evaluations
-    uint32_t shaded;  // shade_hit evaluations
+    uint32_t shaded;  // bits 0..11: shade_hit evaluations (<= 2^depth per pixel); bits 12..31: of `rays`, the shadow
+                      // rays answered by the light-cone cull without testing any object (<= 2^depth * cells)
 };
+constexpr uint32_t CNT_SHADED_MASK = 0xfffu, CNT_CULLED_SHIFT = 12u;
 
 // cube.rs:90-129 aabb_intersection(..).is_some() for a world-space box: `inv` are the reciprocals Ray::new keeps
 // (ray.rs:16).  fminf / fmaxf return the non-NaN operand, as Rust's f32::min / max do.
@@ -835,8 +841,16 @@ DI void shadow_prepare(const SceneHdr& H, const SceneSoA& S, V3 p, ShadowPre* pr
 // SIMPLE: every object is scale+translate-only, none is a cylinder or cone and no material has a pattern
 // (decided on the host), so the
 // loop-invariant uniform working set is 4 SGPRs per object and stays resident across the sample loop.
+constexpr uint32_t LIGHT_CULL_ALL_CASTERS = 0x80000000u;
+// `skip`: wave-uniform mask from light_cull_mask() -- objects that provably have no intersection at t >= 0 with
+// any ray from this shade point to the light; they cannot change either pass.
 template <int NOBJ, bool SIMPLE>
-DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* pre, V3 lp, V3 p, Counters& cnt) {
+DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* pre, V3 lp, V3 p, Counters& cnt,
+                        uint32_t skip) {
+    if (skip & LIGHT_CULL_ALL_CASTERS) {  // wave-uniform: nothing that casts a shadow is reachable
+        cnt.rays++;
+        return false;
+    }
     V3 v = lp - p;
     float distance;
     V3 dir;
@@ -867,6 +881,7 @@ DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* p
         const float4 g = S.geo[i];
         const uint32_t bits = spec_bits(i, __float_as_uint(g.w));
         if ((bits & SHAPE_KIND_MASK) == SHAPE_NONE || !(bits & SHAPE_CASTS)) return;  // wave-uniform
+        if (skip & (1u << i)) return;                                                 // wave-uniform
         object_ts(i, g, bits, [&](float t) {
             if (t >= 0.0f && (!found || t < t_c)) {
                 t_c = t;
@@ -882,12 +897,89 @@ DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* p
             const float4 g = S.geo[i];
             const uint32_t bits = spec_bits(i, __float_as_uint(g.w));
             if ((bits & SHAPE_KIND_MASK) == SHAPE_NONE || (bits & SHAPE_CASTS)) return;
+            if (skip & (1u << i)) return;
             object_ts(i, g, bits, [&](float t) {
                 if (t >= 0.0f && (t < t_c || (t == t_c && i < i_c))) shadowed = false;
             });
         });
     }
     return shadowed;
+}
+
+// ---- light-cone culling -----------------------------------------------------------------------------
+// All shadow rays of one shade point run from p into the light's parallelogram.  Per object, once per shade
+// point, decide CONSERVATIVELY whether any such ray can reach the object at t >= 0; if none can -- for every
+// active lane of the wave -- the object is left out of all (100) is_shadowed evaluations of this shade point.
+// This is to the shadow rays what a bounding-volume hierarchy is to primary rays: it removes tests whose outcome
+// is known, and therefore cannot change the image -- PROVIDED a culled object really yields no hit in the exact
+// f32 evaluation.  That is ensured by margins far above the evaluation's rounding error (DESIGN.md "Light-cone
+// culling"): the test works in the object's own space (where the exact quadratic is evaluated) with the unit
+// sphere / cube blown up by 10 % in radius, the cone of directions widened by 1e-3 in cosine, and it is only
+// trusted when the shade point is within 100 radii (beyond that the quadratic's cancellation error grows and
+// the object is simply kept).  Everything here is approximate arithmetic; NaNs fail every comparison and so
+// keep the object.  Scale+translate-only spheres, cubes and planes are handled, the rest is kept.
+template <int NOBJ>
+DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p) {
+    uint32_t mask = 0;
+    bool casters_left = false;  // wave-uniform
+    // the samples stay inside the parallelogram only for jitter in [0, 1] (the hashed source draws from (0, 1])
+    const bool hashed = spec_jitter_mode(H.jitter_mode) == RTC_JITTER_HASHED;
+    if (!hashed && !(H.jitter_const >= 0.0f && H.jitter_const <= 1.0f)) return 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)NOBJ; i++) {
+        const float4 g = S.geo[i];
+        const uint32_t bits = spec_bits(i, __float_as_uint(g.w));
+        const uint32_t kind = bits & SHAPE_KIND_MASK;
+        if (kind == SHAPE_NONE) continue;
+        if (!(bits & SHAPE_DIAG) || (kind != RTC_SPHERE && kind != RTC_CUBE && kind != RTC_PLANE)) {  // uniform
+            if (bits & SHAPE_CASTS) casters_left = true;
+            continue;
+        }
+        // the object-space shade point, as shadow_prepare computes it (same operations, same value)
+        const V3 tr = v3(S.off0[i].z, S.off1[i].z, S.off2[i].z);
+        const V3 o = v3(g.x * p.x + tr.x, g.y * p.y + tr.y, g.z * p.z + tr.z);
+        bool cull;
+        if (kind == RTC_PLANE) {
+            // plane.rs:45-56 gives no t >= 0 unless the object-space origin height o.y and the direction's d.y have
+            // strictly opposite signs.  d.y = g.y * (lp.y - p.y) / |lp - p| up to sign-preserving roundings, so if
+            // g.y * (lp.y - p.y) has o.y's sign (or is zero) for the whole y range of the light -- widened by far more
+            // than the sample points' rounding error --, every sample either runs parallel (rejected) or leaves the
+            // plane behind.  o.y is the very value the exact test uses.
+            const float a = g.y * (H.light_y_lo - p.y), b = g.y * (H.light_y_hi - p.y);
+            cull = (o.y > 0.0f && fminf(a, b) >= 0.0f) || (o.y < 0.0f && fmaxf(a, b) <= 0.0f);
+        } else {
+            // The rays fill the pyramid with apex o over the (object-space) parallelogram: the intersection of the four
+            // half-spaces through o bounded by its faces.  The inflated bounding sphere (centre = origin) lies outside
+            // as soon as ONE face plane separates it: signed distance of the origin beyond that face > radius.
+            // Unnormalised throughout: n.(-o) > R |n|  <=>  n.(-o) > 0 and (n.o)^2 > R^2 |n|^2.
+            const float r2 = kind == RTC_SPHERE ? 1.21f : 3.63f;  // (1.1 r)^2 of the unit sphere / the cube's circumsphere
+            const float oo = o.x * o.x + o.y * o.y + o.z * o.z;
+            const float4 l0 = S.lcorn[3 * i], l1 = S.lcorn[3 * i + 1], l2 = S.lcorn[3 * i + 2];  // wave-uniform
+            auto edge = [&](int k) {  // object-space vector from the shade point to corner k
+                const V3 c = k == 0 ? v3(l0.x, l0.y, l0.z) : k == 1 ? v3(l0.w, l1.x, l1.y) : k == 2 ? v3(l1.z, l1.w, l2.x) : v3(l2.y, l2.z, l2.w);
+                return c - o;
+            };
+            const V3 m = edge(0) + edge(2);  // towards the parallelogram's centre: inside the pyramid
+            bool narrow = true, outside = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const V3 e0 = edge(k), e1 = edge((k + 1) & 3);
+                const float me = dot3(m, e0);  // every corner within ~66 degrees of the axis: a proper convex cone
+                narrow = narrow && me > 0.0f && me * me > 0.16f * dot3(m, m) * dot3(e0, e0);
+                V3 n = cross3(e0, e1);
+                if (dot3(n, m) > 0.0f) n = -n;  // outward
+                const float h = -dot3(n, o);    // (distance of the origin outside face k) * |n|
+                outside = outside || (h > 0.0f && h * h > 1.01f * r2 * dot3(n, n));
+            }
+            cull = oo > r2 && oo < 1e4f * r2 && narrow && outside;
+        }
+        if (__all(cull)) mask |= 1u << i;
+        else if (bits & SHAPE_CASTS) casters_left = true;
+    }
+    // no shadow caster can be reached from this shade point: every sample is lit whatever else is in the way
+    // (world.rs:104-119 asks for the nearest hit to BE a caster), see is_shadowed_pre
+    if (!casters_left) mask |= LIGHT_CULL_ALL_CASTERS;
+    return mask;
 }
 
 // Pinned jitter (DESIGN.md "Jitter"): counter-based hash keyed by
@@ -921,7 +1013,12 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
     // every shadow ray of this shade point starts at p: do the origin-only work once per object
     constexpr bool PRE = NOBJ > 0;
     ShadowPre pre[PRE ? NOBJ : 1];
-    if constexpr (PRE) shadow_prepare<NOBJ>(H, S, p, pre);
+    uint32_t skip = 0u;
+    if constexpr (PRE) {
+        skip = light_cull_mask<NOBJ>(H, S, p);  // before pre[] becomes live: the cull needs registers of its own
+        shadow_prepare<NOBJ>(H, S, p, pre);
+        if (skip & LIGHT_CULL_ALL_CASTERS) cnt.shaded += (uint32_t)(H.u_steps * H.v_steps) << CNT_CULLED_SHIFT;  // statistics
+    }
     float total = 0.0f;
     for (int v = 0; v < H.v_steps; v++) {
         for (int u = 0; u < H.u_steps; u++) {
@@ -935,7 +1032,7 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
             // corner + u_vec * (u + jitter1) + v_vec * (v + jitter2)
             V3 lp = corner + uvec * ((float)u + j1) + vvec * ((float)v + j2);
             bool blocked;
-            if constexpr (PRE) blocked = is_shadowed_pre<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt);
+            if constexpr (PRE) blocked = is_shadowed_pre<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt, skip);
             else blocked = is_shadowed<NOBJ>(H, S, lp, p, cnt);
             if (!blocked) total += 1.0f;
         }
@@ -1259,7 +1356,7 @@ struct RenderArgs {
     SceneHdr hdr;
     SceneSoA soa;
     float* out;            // compact rows of this partition: [rows][width][3]
-    uint2* block_counts;   // one partial {rays, shaded hits} per workgroup
+    uint4* block_counts;   // one partial {rays, shaded hits, culled shadow rays, 0} per workgroup
     uint32_t rows;         // rows in `out`
     uint32_t band_rows, n_parts, part;
     int32_t depth;
@@ -1305,18 +1402,20 @@ DI void render_body(const RenderArgs& A) {
         dst[2] = col.z;
     }
     // work statistics: wave reduce, then one partial per workgroup
-    uint32_t rays = cnt.rays, shaded = cnt.shaded;
+    uint32_t rays = cnt.rays, shaded = cnt.shaded & CNT_SHADED_MASK, culled = cnt.shaded >> CNT_CULLED_SHIFT;
     for (int off = 32; off > 0; off >>= 1) {
         rays += __shfl_down(rays, off, 64);
         shaded += __shfl_down(shaded, off, 64);
+        culled += __shfl_down(culled, off, 64);
     }
-    __shared__ uint2 wave_counts[4];
-    if (lane == 0) wave_counts[wave] = make_uint2(rays, shaded);
+    __shared__ uint4 wave_counts[4];
+    if (lane == 0) wave_counts[wave] = make_uint4(rays, shaded, culled, 0u);
     __syncthreads();
     if (threadIdx.x == 0)
         A.block_counts[blockIdx.y * gridDim.x + blockIdx.x] =
-            make_uint2(wave_counts[0].x + wave_counts[1].x + wave_counts[2].x + wave_counts[3].x,
-                       wave_counts[0].y + wave_counts[1].y + wave_counts[2].y + wave_counts[3].y);
+            make_uint4(wave_counts[0].x + wave_counts[1].x + wave_counts[2].x + wave_counts[3].x,
+                       wave_counts[0].y + wave_counts[1].y + wave_counts[2].y + wave_counts[3].y,
+                       wave_counts[0].z + wave_counts[1].z + wave_counts[2].z + wave_counts[3].z, 0u);
 }
 
 #ifdef RTC_SPEC_LIST
@@ -1333,38 +1432,44 @@ __global__ __launch_bounds__(256, RTC_WAVES_PER_SIMD) void render_kernel(RenderA
 }
 
 
-__global__ __launch_bounds__(1024) void sum_counts_kernel(const uint2* __restrict__ block_counts, uint32_t n,
+__global__ __launch_bounds__(1024) void sum_counts_kernel(const uint4* __restrict__ block_counts, uint32_t n,
                                                           unsigned long long* __restrict__ total) {
-    unsigned long long rays = 0, shaded = 0;
+    unsigned long long rays = 0, shaded = 0, culled = 0;
     uint32_t i = threadIdx.x;
     for (; i + 3 * 1024 < n; i += 4 * 1024) {  // four independent loads in flight per lane
-        uint2 a = block_counts[i], b = block_counts[i + 1024], c = block_counts[i + 2048], d = block_counts[i + 3072];
+        uint4 a = block_counts[i], b = block_counts[i + 1024], c = block_counts[i + 2048], d = block_counts[i + 3072];
         rays += (unsigned long long)a.x + b.x + c.x + d.x;
         shaded += (unsigned long long)a.y + b.y + c.y + d.y;
+        culled += (unsigned long long)a.z + b.z + c.z + d.z;
     }
     for (; i < n; i += 1024) {
-        uint2 c = block_counts[i];
+        uint4 c = block_counts[i];
         rays += c.x;
         shaded += c.y;
+        culled += c.z;
     }
     for (int off = 32; off > 0; off >>= 1) {
         rays += __shfl_down(rays, off, 64);
         shaded += __shfl_down(shaded, off, 64);
+        culled += __shfl_down(culled, off, 64);
     }
-    __shared__ unsigned long long part[16][2];
+    __shared__ unsigned long long part[16][3];
     if ((threadIdx.x & 63) == 0) {
         part[threadIdx.x >> 6][0] = rays;
         part[threadIdx.x >> 6][1] = shaded;
+        part[threadIdx.x >> 6][2] = culled;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long r = 0, sh = 0;
+        unsigned long long r = 0, sh = 0, cu = 0;
         for (int w = 0; w < 16; w++) {
             r += part[w][0];
             sh += part[w][1];
+            cu += part[w][2];
         }
         total[0] = r;
         total[1] = sh;
+        total[2] = cu;
     }
 }
 

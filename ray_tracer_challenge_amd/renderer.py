@@ -70,7 +70,8 @@ class Renderer:
         st = L.rtc_stats()
         L.check(L.lib().rtc_ctx_stats(self._ctx, C.byref(st)))
         return {"rays": int(st.rays), "shaded_hits": int(st.shaded_hits), "pixels": int(st.pixels),
-                "kernel_ms": float(st.kernel_ms), "launches": int(st.launches), "rows": int(st.rows)}
+                "kernel_ms": float(st.kernel_ms), "launches": int(st.launches), "rows": int(st.rows),
+                "culled_shadow_rays": int(st.culled_shadow_rays)}
 
     def to_ppm(self, rgb, stream=None):
         """Canvas::to_ppm (canvas.rs:58-96) formatted on the device from an (h, w, 3) f32 tensor -> bytes."""
