@@ -960,18 +960,24 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p) {
                 return c - o;
             };
             const V3 m = edge(0) + edge(2);  // towards the parallelogram's centre: inside the pyramid
-            bool narrow = true, outside = false;
+            bool narrow = true, outside = false, leaving = true;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const V3 e0 = edge(k), e1 = edge((k + 1) & 3);
                 const float me = dot3(m, e0);  // every corner within ~66 degrees of the axis: a proper convex cone
                 narrow = narrow && me > 0.0f && me * me > 0.16f * dot3(m, m) * dot3(e0, e0);
+                const float oe = dot3(o, e0);  // corner direction at least ~3 degrees above the sphere's tangent plane at o
+                leaving = leaving && oe > 0.0f && oe * oe > 0.0025f * oo * dot3(e0, e0);
                 V3 n = cross3(e0, e1);
                 if (dot3(n, m) > 0.0f) n = -n;  // outward
                 const float h = -dot3(n, o);    // (distance of the origin outside face k) * |n|
                 outside = outside || (h > 0.0f && h * h > 1.01f * r2 * dot3(n, n));
             }
             cull = oo > r2 && oo < 1e4f * r2 && narrow && outside;
+            // A shade point sitting just outside the unit sphere whose whole light pyramid points away from it: with
+            // c = |o|^2 - 1 > 0 and b = 2 pd.o > 0 both roots (-b -+ sqrt(b^2 - 4ac)) / 2a are negative, and by more
+            // than rounding can undo because 4ac / b^2 >= c / (1 + c) >= 8e-5 (c is the exact test's own value).
+            if (kind == RTC_SPHERE) cull = cull || (oo - 1.0f > 1e-4f && oo <= r2 && leaving);
         }
         if (__all(cull)) mask |= 1u << i;
         else if (bits & SHAPE_CASTS) casters_left = true;
