@@ -847,10 +847,6 @@ constexpr uint32_t LIGHT_CULL_ALL_CASTERS = 0x80000000u;
 template <int NOBJ, bool SIMPLE>
 DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* pre, V3 lp, V3 p, Counters& cnt,
                         uint32_t skip) {
-    if (skip & LIGHT_CULL_ALL_CASTERS) {  // wave-uniform: nothing that casts a shadow is reachable
-        cnt.rays++;
-        return false;
-    }
     V3 v = lp - p;
     float distance;
     V3 dir;
@@ -1023,7 +1019,14 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
     if constexpr (PRE) {
         skip = light_cull_mask<NOBJ>(H, S, p);  // before pre[] becomes live: the cull needs registers of its own
         shadow_prepare<NOBJ>(H, S, p, pre);
-        if (skip & LIGHT_CULL_ALL_CASTERS) cnt.shaded += (uint32_t)(H.u_steps * H.v_steps) << CNT_CULLED_SHIFT;  // statistics
+        if (skip & LIGHT_CULL_ALL_CASTERS) {
+            // wave-uniform: no shadow caster is reachable, so each of the u_steps * v_steps is_shadowed() calls answers
+            // "lit": total = 1.0 + ... + 1.0 = cells exactly (an integer below 2^24), and cells / cells = 1.0
+            const uint32_t cells = (uint32_t)(H.u_steps * H.v_steps);
+            cnt.rays += cells;
+            cnt.shaded += cells << CNT_CULLED_SHIFT;  // statistics: rays answered without an object test
+            return (float)cells / H.cells_f;
+        }
     }
     float total = 0.0f;
     for (int v = 0; v < H.v_steps; v++) {
