@@ -126,7 +126,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     const uint32_t n = scene->n_objects;
     hdr->n_objects = n;
     const uint32_t np = padded_count(n);  // stride of each SoA array
-    soa->assign((size_t)18 * np, make_float4(0, 0, 0, 0));
+    soa->assign((size_t)19 * np, make_float4(0, 0, 0, 0));
     {
         uint32_t none = SHAPE_NONE;
         float none_f;
@@ -145,6 +145,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         float4 g[4];
         pack_geometry(o, g);
         for (int k = 0; k < 4; k++) (*soa)[(size_t)k * np + i] = g[k];
+        (*soa)[18 * (size_t)np + i] = make_float4(o.inv[3], o.inv[7], o.inv[11], 0.0f);
         const rtc_material& m = o.material;
         (*soa)[4 * np + i] = make_float4(m.color[0], m.color[1], m.color[2], m.ambient);
         (*soa)[5 * np + i] = make_float4(m.diffuse, m.specular, m.shininess, m.reflective);
@@ -449,7 +450,8 @@ static SceneSoA soa_view(const float4* base, uint32_t n) {
     s.pat = base + 7 * (size_t)m;
     s.tri = base + 12 * (size_t)m;
     s.lcorn = base + 15 * (size_t)m;
-    s.trav = base + 18 * (size_t)m;
+    s.trn = base + 18 * (size_t)m;
+    s.trav = base + 19 * (size_t)m;
     return s;
 }
 
@@ -544,6 +546,33 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
             c->spec_fn = nullptr;         // auto: the ahead-of-time kernel computes the same image
         } else {
             c->kernel_name = "render_kernel_spec[" + list.substr(16) + (c->simple ? ";simple" : "") + (hdr.has_patterns ? ";patterns" : "") + "]";
+        }
+    } else if (n > 8 && (policy == 1 || (policy == 2 && pixels >= (1ull << 18)))) {
+        // many objects that all share one kind / flags word (C5: 64 scale+translate spheres): the any-count loop with
+        // that word as a compile-time constant -- no per-object kind switch, two 16-byte records per object
+        uint32_t first;
+        std::memcpy(&first, &soa[0].w, 4);
+        bool uniform = true;
+        for (uint32_t i = 1; i < n && uniform; i++) {
+            uint32_t bits;
+            std::memcpy(&bits, &soa[i].w, 4);
+            uniform = bits == first;
+        }
+        if (uniform) {
+            char b[16];
+            snprintf(b, sizeof(b), "0x%x", first);
+            std::vector<std::string> defs = {std::string("-DRTC_SPEC_LIST=") + b, std::string("-DRTC_SPEC_UNIFORM_BITS=") + b,
+                                             "-DRTC_SPEC_NOBJ=0", "-DRTC_SPEC_SIMPLE=0",
+                                             "-DRTC_SPEC_LIGHT_KIND=" + std::to_string(hdr.light_kind),
+                                             "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
+                                             std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
+            rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
+            if (jst != RTC_OK) {
+                if (policy == 1) return jst;
+                c->spec_fn = nullptr;
+            } else {
+                c->kernel_name = std::string("render_kernel_spec[all ") + b + (hdr.has_patterns ? ";patterns" : "") + "]";
+            }
         }
     }
     return RTC_OK;
@@ -888,6 +917,7 @@ static rtc_status object_arg(const rtc_object* object, const char* who, Obj* ob,
     ob->off0 = g[1];
     ob->off1 = g[2];
     ob->off2 = g[3];
+    ob->trn = make_float4(object->inv[3], object->inv[7], object->inv[11], 0.0f);
     std::memcpy(&ob->bits, &g[0].w, 4);
     float4 tri[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
     if (object->kind == RTC_TRIANGLE) pack_triangle(*object, tri);

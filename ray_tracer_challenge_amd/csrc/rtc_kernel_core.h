@@ -370,6 +370,9 @@ struct SceneSoA {
     // Light-cone culling: the area light's four corners (around the parallelogram) in each object's own space,
     // 3 records per object: { c0.xyz, c1.x }, { c1.yz, c2.xy }, { c2.z, c3.xyz }.  Approximate values (margins apply).
     const float4* __restrict__ lcorn;
+    // { m03, m13, m23, 0 }: the translation column again, so that scale+translate-only objects need two records
+    // (geo + trn = 32 B) instead of four
+    const float4* __restrict__ trn;
 };
 enum : uint32_t { TRAV_GROUP = 0u, TRAV_LEAF = 1u };
 enum : uint32_t {
@@ -387,10 +390,15 @@ enum : uint32_t {
 // `kind == ...` / `bits & flag` test below disappears at compile time.  Values (matrices, materials,
 // light geometry, camera) stay run-time data: one specialisation serves every scene of that shape.
 #ifdef RTC_SPEC_LIST
+#ifdef RTC_SPEC_UNIFORM_BITS
+// any number of objects, all with the same kind / flags word (C5: 64 scale+translate spheres)
+DI uint32_t spec_bits(uint32_t, uint32_t) { return RTC_SPEC_UNIFORM_BITS; }
+#else
 DI uint32_t spec_bits(uint32_t i, uint32_t) {
     constexpr uint32_t table[8] = {RTC_SPEC_LIST};
     return table[i & 7u];
 }
+#endif
 DI int32_t spec_light_kind(int32_t) { return RTC_SPEC_LIGHT_KIND; }
 DI int32_t spec_jitter_mode(int32_t) { return RTC_SPEC_JITTER; }
 DI bool spec_has_patterns(uint32_t) { return RTC_SPEC_PATTERNS != 0; }
@@ -406,7 +414,7 @@ constexpr float SELF_EPS = 1.1920929e-7f * 10000.0f;   // world.rs:210
 constexpr float CLOSE_TO_ZERO = 0.000001f;             // cylinder.rs:82
 
 struct Obj {
-    float4 geo, off0, off1, off2;
+    float4 geo, off0, off1, off2, trn;
     uint32_t bits;
     DI float min_y() const { return off0.w; }
     DI float max_y() const { return off1.w; }
@@ -417,6 +425,7 @@ DI Obj load_obj(const SceneSoA& S, uint32_t i) {
     o.off0 = S.off0[i];
     o.off1 = S.off1[i];
     o.off2 = S.off2[i];
+    o.trn = S.trn[i];
     o.bits = __float_as_uint(o.geo.w);
     return o;
 }
@@ -441,9 +450,22 @@ DI Obj load_obj_static(const SceneSoA& S, uint32_t i) {
     Obj o;
     if constexpr (RUNTIME_INDEX) {
         o.geo = load_uniform(S.geo, i);
+        o.bits = spec_bits(i, __float_as_uint(o.geo.w));
+#ifdef RTC_SPEC_UNIFORM_BITS
+        // the kind / flags word is a compile-time constant: scale+translate-only objects that keep no bounds
+        // need just two records (geo + trn = 32 B)
+        constexpr uint32_t kind = RTC_SPEC_UNIFORM_BITS & SHAPE_KIND_MASK;
+        if constexpr ((RTC_SPEC_UNIFORM_BITS & SHAPE_DIAG) && kind != RTC_CYLINDER && kind != RTC_CONE) {
+            o.trn = load_uniform(S.trn, i);
+            o.off0 = o.off1 = o.off2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            return o;
+        }
+#endif
         o.off0 = load_uniform(S.off0, i);
         o.off1 = load_uniform(S.off1, i);
         o.off2 = load_uniform(S.off2, i);
+        o.trn = make_float4(o.off0.z, o.off1.z, o.off2.z, 0.0f);
+        return o;
     } else {
         o = load_obj(S, i);
     }
@@ -455,7 +477,7 @@ DI Obj load_obj_static(const SceneSoA& S, uint32_t i) {
 // When the 3x3 part is diagonal the products with the (exactly zero) off-diagonal
 // entries are +-0 and adding them changes nothing, so they are skipped.
 DI V3 obj_point(const Obj& b, V3 p) {
-    if (b.bits & SHAPE_DIAG) return {b.geo.x * p.x + b.off0.z, b.geo.y * p.y + b.off1.z, b.geo.z * p.z + b.off2.z};
+    if (b.bits & SHAPE_DIAG) return {b.geo.x * p.x + b.trn.x, b.geo.y * p.y + b.trn.y, b.geo.z * p.z + b.trn.z};
     return {b.geo.x * p.x + b.off0.x * p.y + b.off0.y * p.z + b.off0.z,
             b.off1.x * p.x + b.geo.y * p.y + b.off1.y * p.z + b.off1.z,
             b.off2.x * p.x + b.off2.y * p.y + b.geo.z * p.z + b.off2.z};
@@ -712,6 +734,17 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, const WorldRay& wr
     } else {
         // any object count: the record arrays are padded to a multiple of 8 with SHAPE_NONE entries (skipped by
         // the bodies), so the loop advances four records at a time and their loads are issued together
+#ifdef RTC_SPEC_UNIFORM_BITS
+        // uniform specialisation: the bodies no longer look at the padding records' kind, so stop at n_objects
+        uint32_t i = 0;
+        for (; i + 3u < H.n_objects; i += 4) {
+            body(i);
+            body(i + 1);
+            body(i + 2);
+            body(i + 3);
+        }
+        for (; i < H.n_objects; i++) body(i);
+#else
         const uint32_t padded = (H.n_objects + 7u) & ~7u;
         for (uint32_t i = 0; i < padded; i += 4) {
             body(i);
@@ -719,6 +752,7 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, const WorldRay& wr
             body(i + 2);
             body(i + 3);
         }
+#endif
     }
 }
 
@@ -932,7 +966,8 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p) {
             continue;
         }
         // the object-space shade point, as shadow_prepare computes it (same operations, same value)
-        const V3 tr = v3(S.off0[i].z, S.off1[i].z, S.off2[i].z);
+        const float4 tq = S.trn[i];
+        const V3 tr = v3(tq.x, tq.y, tq.z);
         const V3 o = v3(g.x * p.x + tr.x, g.y * p.y + tr.y, g.z * p.z + tr.z);
         bool cull;
         if (kind == RTC_PLANE) {

@@ -295,6 +295,8 @@ def test_boundary_errors_on_device():
     ("first_patterns", (100, 50), {}),
     ("reflect_refract", (160, 80), {}),
     ("patterns_medley", (128, 96), {}),
+    ("sphere_grid", (128, 128), {}),          # 64 like objects: the any-count loop specialised on their shared flags word
+    ("sphere_grid", (96, 64), {"n": 5}),      # 25 objects: the remainder loop
 ])
 def test_specialised_kernel_matches_generic_and_oracle(name, size, kw, monkeypatch):
     """RTC_AMD_SPECIALIZE=1 compiles the kernel for this scene's shape with hiprtc; the image, the ray
@@ -324,7 +326,9 @@ def test_specialisation_policy_defaults(monkeypatch):
     world, camera, _ = scenes.soft_shadows(1024, 512)
     assert Renderer(world, camera, device=0).kernel_name.startswith("render_kernel_spec[")  # >= 2^18 pixels
     world, camera, _ = scenes.sphere_grid(1024, 512)
-    assert Renderer(world, camera, device=0).kernel_name == "render_kernel<0,general>"     # 64 objects: generic
+    assert Renderer(world, camera, device=0).kernel_name == "render_kernel_spec[all 0x500]"  # 64 like objects
+    world.objects[3].casts_shadow = False                                                  # ... no longer alike
+    assert Renderer(world, camera, device=0).kernel_name == "render_kernel<0,general>"
 
 
 # ------------------------------------------------- shapes and patterns on the device
