@@ -20,7 +20,10 @@ _LIB_PATH = os.path.join(_HERE, "librtc_oracle.so")
 SPHERE, PLANE, CUBE, CYLINDER, CONE, TRIANGLE, SMOOTH_TRIANGLE = 0, 1, 2, 3, 4, 5, 6
 TEST_SHAPE = 100
 PATTERN_NONE, PATTERN_STRIPES, PATTERN_GRADIENT, PATTERN_RINGS, PATTERN_CHECKERS, PATTERN_SINE2D = 0, 1, 2, 3, 4, 5
+PATTERN_TEXTURE_MAP, PATTERN_CUBE_MAP = 6, 7
 PATTERN_TEST = 100
+UV_CHECKERS, UV_ALIGN_CHECK, UV_IMAGE = 1, 2, 3
+MAP_SPHERICAL, MAP_PLANAR, MAP_CYLINDRICAL = 1, 2, 3
 LIGHT_POINT, LIGHT_RECT = 0, 1
 JITTER_CONSTANT, JITTER_CYCLE, JITTER_HASHED = 0, 1, 2
 
@@ -39,8 +42,14 @@ def build(force=False):
     return _LIB_PATH
 
 
+class _UVPattern(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("width", C.c_float), ("height", C.c_float), ("colors", (C.c_float * 3) * 5),
+                ("image_width", C.c_uint32), ("image_height", C.c_uint32), ("image_rgb", _FP)]
+
+
 class _Pattern(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("a", C.c_float * 3), ("b", C.c_float * 3), ("transform", C.c_float * 16)]
+    _fields_ = [("kind", C.c_int32), ("a", C.c_float * 3), ("b", C.c_float * 3), ("transform", C.c_float * 16),
+                ("uv_mapping", C.c_int32), ("n_uv", C.c_int32), ("uv", C.POINTER(_UVPattern))]
 
 
 class _Material(C.Structure):
@@ -115,6 +124,9 @@ def lib():
         L.rtco_phong.argtypes = [C.c_void_p, C.POINTER(_Material), _FP, _FP, _FP, C.c_float, _FP]
         L.rtco_phong_on.argtypes = [C.c_void_p, C.POINTER(_Shape), _FP, _FP, _FP, C.c_float, _FP]
         L.rtco_scale_color.argtypes = [C.c_float]
+        L.rtco_uv_color_at.argtypes = [C.POINTER(_UVPattern), C.c_float, C.c_float, _FP]
+        L.rtco_canvas_from_ppm.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                           C.POINTER(C.c_void_p)]
         L.rtco_normal_at_uv.argtypes = [C.POINTER(_Shape), _FP, C.c_float, C.c_float, _FP]
         L.rtco_jitter_value.argtypes = [C.c_uint32]
         _lib = L
@@ -341,10 +353,11 @@ def jitter_value(h):
 class Pattern:
     """pattern/*.rs: two colours and a pattern->object transform (set_transformation inverts it)."""
 
-    def __init__(self, kind, a=(1, 1, 1), b=(0, 0, 0), transform=None):
+    def __init__(self, kind, a=(1, 1, 1), b=(0, 0, 0), transform=None, uv_mapping=0, uv=()):
         self.kind = kind
         self.a, self.b = tuple(float(c) for c in a), tuple(float(c) for c in b)
         self.transform = identity_4x4() if transform is None else np.asarray(transform, dtype=f32)
+        self.uv_mapping, self.uv = uv_mapping, list(uv)
 
     def set_transformation(self, t):
         self.transform = np.asarray(t, dtype=f32)
@@ -355,6 +368,10 @@ class Pattern:
         p.a[:] = [f32(c) for c in self.a]
         p.b[:] = [f32(c) for c in self.b]
         p.transform[:] = [f32(v) for v in self.transform.reshape(-1)]
+        if self.uv:
+            arr = (_UVPattern * len(self.uv))(*[u._c() for u in self.uv])
+            p.uv_mapping, p.n_uv, p.uv = self.uv_mapping, len(self.uv), arr
+            p._keep = (arr, self.uv)  # the ctypes array and the image buffers must outlive the call
         return p
 
     def color_at_world(self, point):
@@ -388,6 +405,118 @@ def Checkers(a=(1, 1, 1), b=(0, 0, 0), transform=None):
 
 def Sine2D(a=(1, 1, 1), b=(0, 0, 0), transform=None):
     return Pattern(PATTERN_SINE2D, a, b, transform)
+
+
+# ---- pattern/uv.rs ----
+class UVPatternBase:
+    def color_at(self, u, v):
+        c = self._c()
+        out = np.zeros(3, dtype=f32)
+        lib().rtco_uv_color_at(C.byref(c), f32(u), f32(v), _p(out))
+        return out
+
+
+class UVCheckers(UVPatternBase):
+    def __init__(self, width=1.0, height=1.0, a=(1, 1, 1), b=(0, 0, 0)):
+        self.width, self.height, self.a, self.b = width, height, tuple(a), tuple(b)
+
+    def _c(self):
+        u = _UVPattern()
+        u.kind, u.width, u.height = UV_CHECKERS, f32(self.width), f32(self.height)
+        u.colors[0][:] = [f32(c) for c in self.a]
+        u.colors[1][:] = [f32(c) for c in self.b]
+        return u
+
+
+class AlignCheck(UVPatternBase):
+    def __init__(self, main=(1, 1, 1), ul=(1, 0, 0), ur=(1, 1, 0), bl=(0, 1, 0), br=(0, 1, 1)):
+        self.colors = [tuple(c) for c in (main, ul, ur, bl, br)]
+
+    def _c(self):
+        u = _UVPattern()
+        u.kind = UV_ALIGN_CHECK
+        for k, col in enumerate(self.colors):
+            u.colors[k][:] = [f32(c) for c in col]
+        return u
+
+
+class UVImage(UVPatternBase):
+    def __init__(self, canvas):
+        """canvas: (h, w, 3) f32 array, e.g. from canvas_from_ppm()"""
+        self.canvas = np.ascontiguousarray(canvas, dtype=f32)
+
+    def _c(self):
+        u = _UVPattern()
+        u.kind = UV_IMAGE
+        u.image_height, u.image_width = self.canvas.shape[0], self.canvas.shape[1]
+        u.image_rgb = _p(self.canvas)
+        return u
+
+
+class SphericalMap:
+    kind = MAP_SPHERICAL
+
+
+class PlanarMap:
+    kind = MAP_PLANAR
+
+
+class CylindricalMap:
+    kind = MAP_CYLINDRICAL
+
+
+def point_to_uv(mapping, p):
+    a, out = _a(p, 4), np.zeros(2, dtype=f32)
+    lib().rtco_point_to_uv(int(mapping.kind), _p(a), _p(out))
+    return out[0], out[1]
+
+
+FACES = ("front", "back", "left", "right", "up", "down")
+
+
+def face_from_point(p):
+    a = _a(p, 4)
+    return FACES[lib().rtco_face_from_point(_p(a))]
+
+
+def cube_uv(face, p):
+    a, out = _a(p, 4), np.zeros(2, dtype=f32)
+    lib().rtco_cube_uv(FACES.index(face), _p(a), _p(out))
+    return out[0], out[1]
+
+
+def TextureMap(uv_pattern, uv_mapping, transform=None):
+    """TextureMap::new(uv_pattern, uv_mapping) -- pattern/uv.rs:68-76"""
+    return Pattern(PATTERN_TEXTURE_MAP, transform=transform, uv_mapping=uv_mapping.kind, uv=[uv_pattern])
+
+
+def CubicMap(front, back, left, right, up, down, transform=None):
+    """CubicMap::new -- pattern/uv.rs:207-231"""
+    return Pattern(PATTERN_CUBE_MAP, transform=transform, uv=[front, back, left, right, up, down])
+
+
+class PpmParseError(ValueError):
+    VARIANTS = ("IoError", "IncorrectFormat", "ParseIntError", "MalformedDimensionHeader")
+
+    def __init__(self, code):
+        super().__init__(self.VARIANTS[code - 1])
+        self.kind = self.VARIANTS[code - 1]
+
+
+def canvas_from_ppm(text):
+    """canvas.rs:120-197 -> (h, w, 3) f32"""
+    if isinstance(text, str):
+        text = text.encode()
+    w, h, rgb = C.c_uint32(), C.c_uint32(), C.c_void_p()
+    rc = lib().rtco_canvas_from_ppm(text, len(text), C.byref(w), C.byref(h), C.byref(rgb))
+    if rc:
+        raise PpmParseError(rc)
+    try:
+        n = w.value * h.value * 3
+        arr = np.ctypeslib.as_array(C.cast(rgb, _FP), shape=(max(n, 1),))[:n].copy()
+    finally:
+        lib().rtco_free(rgb)
+    return arr.reshape(h.value, w.value, 3)
 
 
 def TestPattern(transform=None):

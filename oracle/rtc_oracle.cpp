@@ -226,11 +226,21 @@ int hit_index(const std::vector<Intersection>& xs) {
 
 // --------------------------------------------------------------- material.rs
 // ------------------------------------------------------------- pattern/*.rs
+// ---- pattern/uv.rs ----
+struct UVPattern {
+    int kind = 0;
+    float width = 1, height = 1;
+    Color colors[5];
+    uint32_t iw = 0, ih = 0;
+    std::vector<float> image;  // Canvas.data[y][x] as RGB f32
+};
 struct Pattern {
     int kind = RTCO_PATTERN_NONE;
     Color a{0, 0, 0}, b{0, 0, 0};
     Color distance{0, 0, 0};  // gradient.rs:17, sine_2d.rs:17: b - a, computed once in new()
     Matrix t_inverse;         // pattern.rs:52-54
+    int uv_mapping = 0;
+    std::vector<UVPattern> uv;
 };
 // Rust `f as i32` saturates (and maps NaN to 0); a bare C cast is undefined outside the i32 range.
 inline int32_t rust_f32_as_i32(float f) {
@@ -239,8 +249,106 @@ inline int32_t rust_f32_as_i32(float f) {
     if (f <= -2147483648.0f) return INT32_MIN;
     return (int32_t)f;
 }
+// Rust `f as usize`: saturating at 0 and usize::MAX, NaN -> 0
+inline size_t rust_f32_as_usize(float f) {
+    if (!(f > 0.0f)) return 0;
+    if (f >= 18446744073709551616.0f) return SIZE_MAX;
+    return (size_t)f;
+}
+// f32::rem_euclid (core): r = self % rhs; if r < 0.0 { r + rhs.abs() } else { r }
+inline float rem_euclid(float a, float rhs) {
+    float r = fmodf(a, rhs);
+    return r < 0.0f ? r + std::fabs(rhs) : r;
+}
+Color uv_color_at(const UVPattern& p, float u, float v) {
+    switch (p.kind) {
+        case RTCO_UV_CHECKERS: {  // uv.rs:45-55; i32 addition wraps in release, panics in debug: not reachable for u, v in [0, 1]
+            int32_t u2 = rust_f32_as_i32(std::floor(u * p.width));
+            int32_t v2 = rust_f32_as_i32(std::floor(v * p.height));
+            return ((int32_t)((uint32_t)u2 + (uint32_t)v2)) % 2 == 0 ? p.colors[0] : p.colors[1];
+        }
+        case RTCO_UV_ALIGN_CHECK:  // uv.rs:145-165
+            if (v > 0.8f) {
+                if (u < 0.2f) return p.colors[1];
+                if (u > 0.8f) return p.colors[2];
+            } else if (v < 0.2f) {
+                if (u < 0.2f) return p.colors[3];
+                if (u > 0.8f) return p.colors[4];
+            }
+            return p.colors[0];
+        case RTCO_UV_IMAGE: {  // uv.rs:366-376
+            float vv = 1.0f - v;
+            float x = u * (float)(p.iw - 1);
+            float y = vv * (float)(p.ih - 1);
+            size_t xi = rust_f32_as_usize(roundf(x)), yi = rust_f32_as_usize(roundf(y));
+            if (xi >= p.iw || yi >= p.ih) return {0, 0, 0};  // the reference panics (index out of bounds)
+            const float* px = &p.image[(yi * p.iw + xi) * 3];
+            return {px[0], px[1], px[2]};
+        }
+    }
+    return {0, 0, 0};
+}
+const float FRAC_1_PI = 0.318309886183790671537767526745028724f;  // std::f32::consts::FRAC_1_PI
+const float PI_F = 3.14159265358979323846264338327950288f;
+const float FRAC_1_2PI = 1.0f / (2.0f * PI_F);  // uv.rs:12
+float calculate_u_from_azimuth(Tuple p) {  // uv.rs:107-113
+    float theta = atan2f(p.x, p.z);
+    float raw_u = theta * FRAC_1_2PI;
+    return 1.0f - (raw_u + 0.5f);
+}
+void point_to_uv(int mapping, Tuple p, float* u, float* v) {
+    switch (mapping) {
+        case RTCO_MAP_SPHERICAL: {  // uv.rs:93-105
+            *u = calculate_u_from_azimuth(p);
+            float radius = magnitude(vector(p.x, p.y, p.z));
+            float phi = acosf(p.y / radius);
+            *v = 1.0f - phi * FRAC_1_PI;
+            return;
+        }
+        case RTCO_MAP_PLANAR:  // uv.rs:182-186
+            *u = rem_euclid(p.x, 1.0f);
+            *v = rem_euclid(p.z, 1.0f);
+            return;
+        case RTCO_MAP_CYLINDRICAL:  // uv.rs:190-197
+            *u = calculate_u_from_azimuth(p);
+            *v = rem_euclid(p.y, 2.0f * PI_F) * FRAC_1_2PI;
+            return;
+    }
+    *u = *v = 0.0f;
+}
+int face_from_point(Tuple p) {  // uv.rs:264-283: Front 0, Back 1, Left 2, Right 3, Up 4, Down 5
+    float coord = fmaxf(fmaxf(std::fabs(p.x), std::fabs(p.y)), std::fabs(p.z));
+    if (coord == p.x) return 3;
+    if (coord == -p.x) return 2;
+    if (coord == p.y) return 4;
+    if (coord == -p.y) return 5;
+    if (coord == p.z) return 0;
+    return 1;
+}
+void cube_uv(int face, Tuple p, float* u, float* v) {  // uv.rs:285-319 (`%` on f32 is fmodf)
+    switch (face) {
+        case 0: *u = fmodf(p.x + 1.0f, 2.0f) / 2.0f; *v = fmodf(p.y + 1.0f, 2.0f) / 2.0f; return;  // front
+        case 1: *u = fmodf(1.0f - p.x, 2.0f) / 2.0f; *v = fmodf(p.y + 1.0f, 2.0f) / 2.0f; return;  // back
+        case 2: *u = fmodf(p.z + 1.0f, 2.0f) / 2.0f; *v = fmodf(p.y + 1.0f, 2.0f) / 2.0f; return;  // left
+        case 3: *u = fmodf(1.0f - p.z, 2.0f) / 2.0f; *v = fmodf(p.y + 1.0f, 2.0f) / 2.0f; return;  // right
+        case 4: *u = fmodf(p.x + 1.0f, 2.0f) / 2.0f; *v = fmodf(1.0f - p.z, 2.0f) / 2.0f; return;  // up
+        default: *u = fmodf(p.x + 1.0f, 2.0f) / 2.0f; *v = fmodf(p.z + 1.0f, 2.0f) / 2.0f; return; // down
+    }
+}
+
 Color pattern_color_at_world(const Pattern& p, Tuple pt) {
     switch (p.kind) {
+        case RTCO_PATTERN_TEXTURE_MAP: {  // uv.rs:84-88
+            float u, v;
+            point_to_uv(p.uv_mapping, pt, &u, &v);
+            return uv_color_at(p.uv[0], u, v);
+        }
+        case RTCO_PATTERN_CUBE_MAP: {  // uv.rs:248-261
+            int face = face_from_point(pt);
+            float u, v;
+            cube_uv(face, pt, &u, &v);
+            return uv_color_at(p.uv[face], u, v);
+        }
         case RTCO_PATTERN_STRIPES:  // stripes.rs:39-45; Rust % keeps the dividend's sign, as C's does
             return rust_f32_as_i32(std::floor(pt.x)) % 2 == 0 ? p.a : p.b;
         case RTCO_PATTERN_GRADIENT: {  // gradient.rs:33-36
@@ -269,6 +377,21 @@ Pattern pattern_from(const rtco_pattern& c) {
     p.b = {c.b[0], c.b[1], c.b[2]};
     p.distance = p.b - p.a;
     p.t_inverse = inverse(mat_from(c.transform, 4));
+    p.uv_mapping = c.uv_mapping;
+    if (c.kind == RTCO_PATTERN_TEXTURE_MAP || c.kind == RTCO_PATTERN_CUBE_MAP) {
+        for (int k = 0; k < c.n_uv; k++) {
+            const rtco_uv_pattern& src = c.uv[k];
+            UVPattern u;
+            u.kind = src.kind;
+            u.width = src.width;
+            u.height = src.height;
+            for (int j = 0; j < 5; j++) u.colors[j] = {src.colors[j][0], src.colors[j][1], src.colors[j][2]};
+            u.iw = src.image_width;
+            u.ih = src.image_height;
+            if (src.kind == RTCO_UV_IMAGE) u.image.assign(src.image_rgb, src.image_rgb + (size_t)u.iw * u.ih * 3);
+            p.uv.push_back(std::move(u));
+        }
+    }
     return p;
 }
 
@@ -1446,6 +1569,110 @@ void rtco_phong_on(rtco_world* w, const rtco_shape* object, const float p[4], co
 }
 void rtco_pattern_color_at_world(const rtco_pattern* pat, const float p[4], float out[3]) {
     putc(pattern_color_at_world(pattern_from(*pat), T(p)), out);
+}
+void rtco_uv_color_at(const rtco_uv_pattern* uv, float u, float v, float out[3]) {
+    rtco_pattern holder{};
+    holder.kind = RTCO_PATTERN_TEXTURE_MAP;
+    for (int i = 0; i < 4; i++) holder.transform[i * 5] = 1.0f;
+    holder.n_uv = 1;
+    holder.uv = uv;
+    Pattern p = pattern_from(holder);
+    putc(uv_color_at(p.uv[0], u, v), out);
+}
+void rtco_point_to_uv(int32_t mapping, const float p[4], float uv[2]) { point_to_uv(mapping, T(p), &uv[0], &uv[1]); }
+int rtco_face_from_point(const float p[4]) { return face_from_point(T(p)); }
+void rtco_cube_uv(int face, const float p[4], float uv[2]) { cube_uv(face, T(p), &uv[0], &uv[1]); }
+// canvas.rs:120-197, line by line: '#' comments and blank lines dropped, magic, "w h", scale, then triplets
+// that may span lines; a pixel is written for every complete triplet (write_pixel ignores out-of-canvas writes
+// only loosely, canvas.rs:27 -- here extra triplets are dropped).
+int rtco_canvas_from_ppm(const char* text, uint64_t len, uint32_t* w, uint32_t* h, float** rgb) {
+    std::vector<std::string> lines;
+    {
+        std::string cur;
+        for (uint64_t i = 0; i < len; i++) {
+            if (text[i] == '\n') {
+                lines.push_back(cur);
+                cur.clear();
+            } else {
+                cur.push_back(text[i]);
+            }
+        }
+        if (!cur.empty()) lines.push_back(cur);
+    }
+    auto trim = [](const std::string& s) {
+        size_t a = 0, b = s.size();
+        while (a < b && isspace((unsigned char)s[a])) a++;
+        while (b > a && isspace((unsigned char)s[b - 1])) b--;
+        return s.substr(a, b - a);
+    };
+    std::vector<std::string> clean;  // clean_line, canvas.rs:183-197
+    for (const std::string& l : lines) {
+        std::string t = trim(l);
+        if (t.empty() || t[0] == '#') continue;
+        clean.push_back(t);
+    }
+    auto parse_uint = [](const std::string& tok, uint64_t* out) {  // str::parse::<u32/usize>: digits, optional '+'
+        size_t i = 0;
+        if (!tok.empty() && tok[0] == '+') i = 1;
+        if (i >= tok.size()) return false;
+        uint64_t v = 0;
+        for (; i < tok.size(); i++) {
+            if (tok[i] < '0' || tok[i] > '9') return false;
+            v = v * 10 + (uint64_t)(tok[i] - '0');
+            if (v > 0xffffffffull) return false;
+        }
+        *out = v;
+        return true;
+    };
+    auto split = [](const std::string& s) {
+        std::vector<std::string> out;
+        std::string cur;
+        for (char ch : s) {
+            if (isspace((unsigned char)ch)) {
+                if (!cur.empty()) out.push_back(cur), cur.clear();
+            } else {
+                cur.push_back(ch);
+            }
+        }
+        if (!cur.empty()) out.push_back(cur);
+        return out;
+    };
+    if (clean.size() < 3) return 1;  // the reference unwraps and panics
+    if (clean[0] != "P3") return 2;
+    std::vector<std::string> dims = split(clean[1]);
+    if (dims.size() != 2) return 4;
+    uint64_t width, height, scale_u;
+    if (!parse_uint(dims[0], &width) || !parse_uint(dims[1], &height)) return 3;
+    if (!parse_uint(clean[2], &scale_u)) return 3;
+    const float scale = (float)(uint32_t)scale_u;
+    std::vector<float> img((size_t)width * height * 3, 0.0f);
+    std::vector<uint32_t> raw;
+    size_t x = 0, y = 0, head = 0;
+    for (size_t li = 3; li < clean.size(); li++) {
+        for (const std::string& tok : split(clean[li])) {
+            uint64_t v;
+            if (!parse_uint(tok, &v)) return 3;
+            raw.push_back((uint32_t)v);
+        }
+        while (raw.size() - head >= 3) {
+            float r = (float)raw[head] / scale, g = (float)raw[head + 1] / scale, b = (float)raw[head + 2] / scale;
+            head += 3;
+            if (x < width && y < height) {
+                float* px = &img[(y * width + x) * 3];
+                px[0] = r, px[1] = g, px[2] = b;
+            }
+            x += 1;
+            if (x >= width) {
+                x = 0;
+                y += 1;
+            }
+        }
+    }
+    *w = (uint32_t)width;
+    *h = (uint32_t)height;
+    *rgb = (float*)malloc(img.size() * sizeof(float) + 1);
+    memcpy(*rgb, img.data(), img.size() * sizeof(float));
+    return 0;
 }
 void rtco_pattern_color_at_object(const rtco_pattern* pat, const rtco_shape* object, const float world_point[4],
                                   float out[3]) {

@@ -35,13 +35,29 @@ enum { RTCO_JITTER_CONSTANT = 0, RTCO_JITTER_CYCLE = 1, RTCO_JITTER_HASHED = 2 }
 /* pattern/{stripes,gradient,rings,checkers,sine_2d}.rs; RTCO_PATTERN_TEST is pattern/pattern.rs:66-89
  * (test double: the pattern-space point as the colour) */
 enum { RTCO_PATTERN_NONE = 0, RTCO_PATTERN_STRIPES = 1, RTCO_PATTERN_GRADIENT = 2, RTCO_PATTERN_RINGS = 3,
-       RTCO_PATTERN_CHECKERS = 4, RTCO_PATTERN_SINE2D = 5, RTCO_PATTERN_TEST = 100 };
+       RTCO_PATTERN_CHECKERS = 4, RTCO_PATTERN_SINE2D = 5,
+       RTCO_PATTERN_TEXTURE_MAP = 6, /* pattern/uv.rs:62-89: one UV pattern through a UV mapping */
+       RTCO_PATTERN_CUBE_MAP = 7,    /* pattern/uv.rs:211-262: six UV patterns (front, back, left, right, up, down) */
+       RTCO_PATTERN_TEST = 100 };
+/* pattern/uv.rs: UVCheckers :20-55, AlignCheck :125-167, UVImage :347-377; mappings :91-113, :180-198 */
+enum { RTCO_UV_CHECKERS = 1, RTCO_UV_ALIGN_CHECK = 2, RTCO_UV_IMAGE = 3 };
+enum { RTCO_MAP_SPHERICAL = 1, RTCO_MAP_PLANAR = 2, RTCO_MAP_CYLINDRICAL = 3 };
+typedef struct rtco_uv_pattern {
+    int32_t kind;
+    float width, height;     /* UVCheckers */
+    float colors[5][3];      /* UVCheckers: a, b; AlignCheck: main, ul, ur, bl, br */
+    uint32_t image_width, image_height;
+    const float* image_rgb;  /* UVImage: Canvas.data, image_height rows of image_width RGB f32 (copied) */
+} rtco_uv_pattern;
 
 /* `transform` is the FORWARD pattern->object matrix; the oracle inverts it (pattern.rs:52-54). */
 typedef struct rtco_pattern {
     int32_t kind;
     float a[3], b[3];
     float transform[16];
+    int32_t uv_mapping;         /* TEXTURE_MAP */
+    int32_t n_uv;               /* 1 (TEXTURE_MAP) or 6 (CUBE_MAP) */
+    const rtco_uv_pattern* uv;
 } rtco_pattern;
 
 /* material.rs:18-51 */
@@ -206,6 +222,14 @@ void rtco_phong_on(rtco_world* w, const rtco_shape* object, const float p[4], co
                    const float n[4], float light_intensity, float out[3]);
 /* pattern.rs:12 color_at_world / :15-19 color_at_object */
 void rtco_pattern_color_at_world(const rtco_pattern* pat, const float p[4], float out[3]);
+/* pattern/uv.rs pieces, as the reference's tests call them */
+void rtco_uv_color_at(const rtco_uv_pattern* uv, float u, float v, float out[3]);
+void rtco_point_to_uv(int32_t mapping, const float p[4], float uv[2]);
+int rtco_face_from_point(const float p[4]); /* 0 front, 1 back, 2 left, 3 right, 4 up, 5 down (uv.rs:169-177) */
+void rtco_cube_uv(int face, const float p[4], float uv[2]);
+/* canvas.rs:120-197 canvas_from_ppm: returns 0 and a malloc'd w*h*3 f32 image (free with rtco_free), or the
+ * index of the ParseError variant + 1 (1 IoError, 2 IncorrectFormat, 3 ParseIntError, 4 MalformedDimensionHeader) */
+int rtco_canvas_from_ppm(const char* text, uint64_t len, uint32_t* w, uint32_t* h, float** rgb);
 void rtco_pattern_color_at_object(const rtco_pattern* pat, const rtco_shape* object, const float world_point[4],
                                   float out[3]);
 

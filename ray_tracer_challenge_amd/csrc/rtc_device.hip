@@ -1009,6 +1009,14 @@ void rtc_cosf_host(const float* x, uint32_t n, float* out) {
     for (uint32_t i = 0; i < n; i++) out[i] = cosf_glibc(x[i], h_sincosf_tab, h_inv_pio4);
 }
 
+// Same for atan2f / acosf (pattern/uv.rs:108,115).
+void rtc_atan2f_host(const float* y, const float* x, uint32_t n, float* out) {
+    for (uint32_t i = 0; i < n; i++) out[i] = atan2f_glibc(y[i], x[i]);
+}
+void rtc_acosf_host(const float* x, uint32_t n, float* out) {
+    for (uint32_t i = 0; i < n; i++) out[i] = acosf_glibc(x[i]);
+}
+
 // Diagnostic (not in rtc.h): runs fastmath_selftest_kernel on n host vectors (n*3 f32);
 // counts[0] = vectors inside the core range, counts[1] = mismatches against sqrtf and '/'.
 rtc_status rtc_selftest_fastmath(const float* vectors, uint32_t n, int32_t device, uint32_t counts[2]) {

@@ -291,6 +291,146 @@ HDI float cosf_glibc(float y, const SinCosTab* __restrict__ T, const uint32_t* _
 DI float rtc_cosf_dev(float x) { return cosf_glibc(x, d_sincosf_tab, d_inv_pio4); }
 
 // ============================================================================
+//  atanf / atan2f / acosf: glibc 2.35 sysdeps/ieee754/flt-32/{s_atanf,e_atan2f,e_acosf}.c -- the fdlibm
+//  single-precision routines, which an x86-64 glibc builds as plain scalar SSE (no FMA variants exist for
+//  them): every operation below is one IEEE f32 operation in the order the library performs it.  What
+//  f32::atan2 / f32::acos (pattern/uv.rs:108,115) resolve to on a Linux host.  Constants are given by their
+//  bit patterns, as read from this image's libm.so.6.
+// ============================================================================
+HDI float atanf_glibc(float x) {
+    const uint32_t hx = f2u(x), ix = hx & 0x7fffffffu;
+    const float atanhi[4] = {u2f(0x3eed6338u), u2f(0x3f490fdau), u2f(0x3f7b985eu), u2f(0x3fc90fdau)};
+    const float atanlo[4] = {u2f(0x31ac3769u), u2f(0x33222168u), u2f(0x33140fb4u), u2f(0x33a22168u)};
+    if (ix >= 0x4c000000u) {  // |x| >= 2^25
+        if (ix > 0x7f800000u) return x + x;
+        if ((int32_t)hx > 0) return atanhi[3] + atanlo[3];
+        return -atanhi[3] - atanlo[3];
+    }
+    int id;
+    if (ix < 0x3ee00000u) {             // |x| < 0.4375
+        if (ix < 0x31000000u) return x;  // |x| < 2^-29
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000u) {      // |x| < 1.1875
+            if (ix < 0x3f300000u) {  // 7/16 <= |x| < 11/16
+                id = 0;
+                x = (2.0f * x - 1.0f) / (2.0f + x);
+            } else {  // 11/16 <= |x| < 19/16
+                id = 1;
+                x = (x - 1.0f) / (x + 1.0f);
+            }
+        } else {
+            if (ix < 0x401c0000u) {  // |x| < 2.4375
+                id = 2;
+                x = (x - 1.5f) / (1.0f + 1.5f * x);
+            } else {  // 2.4375 <= |x| < 2^25
+                id = 3;
+                x = -1.0f / x;
+            }
+        }
+    }
+    const float z = x * x;
+    const float w = z * z;
+    // even and odd terms of the polynomial, Horner in w, exactly as compiled
+    float s1 = u2f(0x3c8569d7u) * w + u2f(0x3d4bda59u);
+    s1 = s1 * w + u2f(0x3d886b35u);
+    s1 = s1 * w + u2f(0x3dba2e6eu);
+    s1 = s1 * w + u2f(0x3e124925u);
+    s1 = s1 * w + u2f(0x3eaaaaabu);
+    s1 = s1 * z;
+    float s2 = u2f(0xbd15a221u) * w - u2f(0x3d6ef16bu);
+    s2 = s2 * w - u2f(0x3d9d8795u);
+    s2 = s2 * w - u2f(0x3de38e38u);
+    s2 = s2 * w - u2f(0x3e4ccccdu);
+    s2 = s2 * w;
+    const float t = (s1 + s2) * x;
+    if (id < 0) return x - t;
+    const float r = atanhi[id] - ((t - atanlo[id]) - x);
+    return ((int32_t)hx < 0) ? -r : r;
+}
+HDI float atan2f_glibc(float y, float x) {
+    const uint32_t hx = f2u(x), hy = f2u(y), ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+    const float tiny = u2f(0x0da24260u), pi_o_4 = u2f(0x3f490fdbu), pi_o_2 = u2f(0x3fc90fdbu), pi = u2f(0x40490fdbu);
+    const float pi_lo = u2f(0xb3bbbd2eu);
+    if (ix > 0x7f800000u || iy > 0x7f800000u) return x + y;  // NaN
+    if (hx == 0x3f800000u) return atanf_glibc(y);            // x = 1.0
+    const uint32_t m = ((hy >> 31) & 1u) | ((hx >> 30) & 2u);  // 2 * sign(x) + sign(y)
+    if (iy == 0u) {                                            // y = 0
+        if (m < 2u) return y;
+        return m == 2u ? pi + tiny : -pi - tiny;
+    }
+    if (ix == 0u) return ((int32_t)hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;  // x = 0
+    if (ix == 0x7f800000u) {                                                     // x = +-inf
+        if (iy == 0x7f800000u) {
+            if (m == 0u) return pi_o_4 + tiny;
+            if (m == 1u) return -pi_o_4 - tiny;
+            if (m == 2u) return 3.0f * pi_o_4 + tiny;
+            return -3.0f * pi_o_4 - tiny;
+        }
+        if (m == 0u) return 0.0f;
+        if (m == 1u) return -0.0f;
+        return m == 2u ? pi + tiny : -pi - tiny;
+    }
+    if (iy == 0x7f800000u) return ((int32_t)hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int32_t k = ((int32_t)iy - (int32_t)ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;                   // |y/x| > 2^60
+    else if ((int32_t)hx < 0 && k < -60) z = 0.0f;           // |y|/x < -2^60
+    else z = atanf_glibc(fabsf(y / x));
+    if (m == 0u) return z;
+    if (m == 1u) return u2f(f2u(z) ^ 0x80000000u);
+    if (m == 2u) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
+}
+HDI float acosf_glibc(float x) {
+    const uint32_t hx = f2u(x), ix = hx & 0x7fffffffu;
+    const float pi = u2f(0x40490fdau), pio2_hi = u2f(0x3fc90fdau), pio2_lo = u2f(0x33a22168u);
+    if (ix == 0x3f800000u) {  // |x| == 1
+        if ((int32_t)hx > 0) return 0.0f;
+        return pi + 2.0f * pio2_lo;
+    }
+    if (ix > 0x3f800000u) return (x - x) / (x - x);  // |x| > 1: NaN
+    auto p_of = [](float z) {
+        float p = u2f(0x3811ef08u) * z + u2f(0x3a4f7f04u);
+        p = p * z - u2f(0x3d241146u);
+        p = p * z + u2f(0x3e4e0aa8u);
+        p = p * z - u2f(0x3ea6b090u);
+        p = p * z + u2f(0x3e2aaaabu);
+        return p * z;
+    };
+    auto q_of = [](float z) {
+        float q = u2f(0x3d9dc62eu) * z - u2f(0x3f303361u);
+        q = q * z + u2f(0x4001572du);
+        q = q * z - u2f(0x4019d139u);
+        q = q * z;
+        return q + 1.0f;
+    };
+    if (ix < 0x3f000000u) {  // |x| < 0.5
+        if (ix <= 0x32800000u) return pio2_hi + pio2_lo;
+        const float z = x * x;
+        const float r = p_of(z) / q_of(z);
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if ((int32_t)hx < 0) {  // x < -0.5
+        const float z = (1.0f + x) * 0.5f;
+        const float s = sqrtf(z);
+        const float r = p_of(z) / q_of(z);
+        const float w = r * s - pio2_lo;
+        const float t = w + s;
+        return pi - (t + t);
+    }
+    const float z = (1.0f - x) * 0.5f;  // x > 0.5
+    const float s = sqrtf(z);
+    const float df = u2f(f2u(s) & 0xfffff000u);
+    const float r = p_of(z) / q_of(z);
+    const float c = (z - df * df) / (s + df);
+    const float w = r * s + c;
+    const float t = w + df;
+    return t + t;
+}
+
+// ============================================================================
 //  Scene as the kernel sees it
 // ============================================================================
 struct V3 {

@@ -4,6 +4,7 @@ Vectors: tests/golden/reference_kat.json (transcribed from the reference's
 inline #[test] functions; each block cites file:line).  No GPU needed.
 """
 import numpy as np
+import pytest
 
 from oracle import oracle as O
 from tests import kat as K
@@ -646,3 +647,65 @@ def test_smooth_triangle(kat):  # shape/smooth_triangle.rs:71-107
     K.assert_eps(t.normal_at_uv(O.point(0, 0, 0), c["u_exact"], c["v_exact"]), c["interpolated_normal_eps"])
     # what a render sees: the hit object is the inner flat Triangle (smooth_triangle.rs:37-39)
     K.assert_exact(t.normal_at(O.point(0, 0.5, 0)), K.vector(T["construction"]["normal"]))
+
+
+# ---------------------------------------------------------------- pattern/uv.rs + canvas_from_ppm
+def _ppm_text(lines):
+    return "\n".join("        " + ln if ln else ln for ln in lines)
+
+
+def _cube_map(kat, api):
+    c = kat["uv"]["cube_map"]
+    faces = {f: api.AlignCheck(*[c["names"][n] for n in names]) for f, names in c["faces"].items()}
+    return api.CubicMap(faces["front"], faces["back"], faces["left"], faces["right"], faces["up"], faces["down"])
+
+
+def test_uv_patterns_and_mappings(kat):  # pattern/uv.rs:387-640
+    U = kat["uv"]
+    c = U["checkers"]
+    p = O.UVCheckers(c["width"], c["height"], c["a"], c["b"])
+    for u, v, expect in c["cases_exact"]:
+        K.assert_exact(p.color_at(u, v), expect)
+    for pt, eu, ev in U["spherical"]["cases_eps"]:
+        u, v = O.point_to_uv(O.SphericalMap(), K.point(pt))
+        K.assert_eps([u, v], [eu, ev])
+    tm = O.TextureMap(O.UVCheckers(16.0, 8.0, (0, 0, 0), (1, 1, 1)), O.SphericalMap())
+    for pt, expect in U["texture_map_spherical"]["cases_exact"]:
+        K.assert_exact(tm.color_at_world(K.point(pt)), expect)
+    for pt, eu, ev in U["planar"]["cases_exact"]:
+        u, v = O.point_to_uv(O.PlanarMap(), K.point(pt))
+        assert (u, v) == (f32(eu), f32(ev)), pt
+    for pt, eu, ev in U["cylindrical"]["cases_eps"]:
+        u, v = O.point_to_uv(O.CylindricalMap(), K.point(pt))
+        K.assert_eps([u, v], [eu, ev])
+    c = U["align_check"]
+    ac = O.AlignCheck(*c["colors"])
+    for u, v, idx in c["cases_exact"]:
+        K.assert_exact(ac.color_at(u, v), c["colors"][idx])
+    for pt, face in U["faces"]["cases"]:
+        assert O.face_from_point(K.point(pt)) == face
+    for face, pt, eu, ev in U["cube_uv"]["cases_exact"]:
+        assert O.cube_uv(face, K.point(pt)) == (f32(eu), f32(ev)), (face, pt)
+    cm = _cube_map(kat, O)
+    for pt, name in U["cube_map"]["cases_exact"]:
+        K.assert_exact(cm.color_at_world(K.point(pt)), U["cube_map"]["names"][name])
+
+
+def test_ppm_reader_and_uv_image(kat):  # canvas.rs:281-398, pattern/uv.rs:642-669
+    R = kat["ppm_reader"]
+    with pytest.raises(O.PpmParseError) as e:
+        O.canvas_from_ppm(_ppm_text(R["wrong_magic"]["lines"]))
+    assert e.value.kind == R["wrong_magic"]["error"]
+    img = O.canvas_from_ppm(_ppm_text(R["size"]["lines"]))
+    assert img.shape == (R["size"]["height"], R["size"]["width"], 3)
+    img = O.canvas_from_ppm(_ppm_text(R["pixels"]["lines"]))
+    for x, y, expect in R["pixels"]["cases_eps"]:
+        K.assert_eps(img[y, x], expect)
+    for key in ("comments", "spanning", "empty_lines", "scale"):
+        img = O.canvas_from_ppm(_ppm_text(R[key]["lines"]))
+        for x, y, expect in R[key]["cases_exact"]:
+            K.assert_exact(img[y, x], expect)
+    c = kat["uv"]["image"]
+    pattern = O.UVImage(O.canvas_from_ppm(_ppm_text(c["ppm_lines"])))
+    for u, v, expect in c["cases_exact"]:
+        K.assert_exact(pattern.color_at(u, v), expect)
