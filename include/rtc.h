@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTC_ABI_VERSION 5
+#define RTC_ABI_VERSION 6
 /* maximum reflection_recursion_depth accepted (reference default: 5, constants.rs:4) */
 #define RTC_MAX_DEPTH 8
 
@@ -49,7 +49,13 @@ typedef enum rtc_status {
 enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3, RTC_CONE = 4, RTC_TRIANGLE = 5 };
 /* pattern/{stripes,gradient,rings,checkers,sine_2d}.rs; NONE = Material.pattern is None (material.rs:50) */
 enum { RTC_PATTERN_NONE = 0, RTC_PATTERN_STRIPES = 1, RTC_PATTERN_GRADIENT = 2, RTC_PATTERN_RINGS = 3,
-       RTC_PATTERN_CHECKERS = 4, RTC_PATTERN_SINE2D = 5 };
+       RTC_PATTERN_CHECKERS = 4, RTC_PATTERN_SINE2D = 5,
+       RTC_PATTERN_TEXTURE_MAP = 6, /* pattern/uv.rs:62-89 TextureMap: one UV pattern through a UV mapping   */
+       RTC_PATTERN_CUBE_MAP = 7     /* pattern/uv.rs:200-262 CubicMap: six UV patterns, one per cube face     */ };
+/* pattern/uv.rs: UVCheckers :20-55, AlignCheck :125-167, UVImage :347-377 */
+enum { RTC_UV_CHECKERS = 1, RTC_UV_ALIGN_CHECK = 2, RTC_UV_IMAGE = 3 };
+/* pattern/uv.rs: SphericalMap :91-105, PlanarMap :180-186, CylindricalMap :188-198 */
+enum { RTC_MAP_SPHERICAL = 1, RTC_MAP_PLANAR = 2, RTC_MAP_CYLINDRICAL = 3 };
 /* light/{point_light,rectangle_light}.rs */
 enum { RTC_LIGHT_POINT = 0, RTC_LIGHT_RECT = 1 };
 /* RectangleLight jitter source.  The reference takes an arbitrary closure
@@ -62,11 +68,24 @@ enum { RTC_JITTER_CONSTANT = 0, RTC_JITTER_HASHED = 2 };
  * BasePattern.t_inverse (pattern.rs:33,52-54).  Gradient and Sine2D keep `distance = b - a`
  * (gradient.rs:17, sine_2d.rs:17); the library forms it from a and b with the same single subtraction.
  * Build with rtc_pattern_init().  (uv.rs texture maps are not on this path.) */
+/* One boxed UVPattern (pattern/uv.rs:14-16). */
+typedef struct rtc_uv_pattern {
+    int32_t kind;           /* RTC_UV_* */
+    float width, height;    /* UVCheckers */
+    float colors[5][3];     /* UVCheckers: a, b.  AlignCheck: main, ul, ur, bl, br */
+    uint32_t image_width;   /* UVImage: its Canvas (canvas.rs:6-10) as image_height rows of image_width RGB f32,  */
+    uint32_t image_height;  /* i.e. Canvas.data[y][x]; host memory, copied into HBM by rtc_ctx_set_scene          */
+    const float* image_rgb;
+} rtc_uv_pattern;
+
 typedef struct rtc_pattern {
     int32_t kind; /* RTC_PATTERN_* */
     float a[3];
     float b[3];
     float inv[16];
+    int32_t uv_mapping;       /* TEXTURE_MAP: RTC_MAP_*                                                         */
+    uint32_t n_uv;            /* TEXTURE_MAP: 1.  CUBE_MAP: 6, in CubicMap::new's order front, back, left, right, */
+    const rtc_uv_pattern* uv; /* up, down (uv.rs:207-231).  Read during rtc_ctx_set_scene / the batched calls.    */
 } rtc_pattern;
 
 /* material.rs:18-51 */
@@ -204,6 +223,14 @@ void rtc_material_default(rtc_material* out);
  * stores transform.inverse() (pattern.rs:52-54).  transform NULL = identity. */
 rtc_status rtc_pattern_init(rtc_pattern* out, int32_t kind, const float a[3], const float b[3],
                             const float transform[16]);
+/* TextureMap::new(uv_pattern, uv_mapping) (uv.rs:68-76; uv_mapping = RTC_MAP_*, n_uv = 1) or CubicMap::new(front,
+ * back, left, right, up, down) (uv.rs:207-231; uv_mapping = 0, n_uv = 6), then set_transformation(transform).
+ * `uv` is borrowed, not copied. */
+rtc_status rtc_texture_map_init(rtc_pattern* out, int32_t uv_mapping, const rtc_uv_pattern* uv, uint32_t n_uv,
+                                const float transform[16]);
+/* canvas_from_ppm (canvas.rs:120-197): parses P3 text into a malloc'd width*height*3 f32 image (free with
+ * rtc_free).  Errors: RTC_ERR_INVALID_ARG with the ParseError variant's name in rtc_last_error(). */
+rtc_status rtc_canvas_from_ppm(const char* text, uint64_t len, uint32_t* width, uint32_t* height, float** out_rgb);
 /* Shape::build(transform, material): stores transform.inverse() (base_shape.rs:56-60).
  * Cylinder / Cone bounds default to -inf/+inf, open (cylinder.rs:34-43, cone.rs:33-42). */
 rtc_status rtc_object_init(rtc_object* out, int32_t kind, const float transform[16], const rtc_material* m);
@@ -306,6 +333,9 @@ rtc_status rtc_pattern_color_at(const rtc_pattern* pattern, const rtc_object* ob
  * pattern/sine_2d.rs:40), evaluated on the device; host buffers of n f32. */
 rtc_status rtc_powf(const float* x, const float* y, uint32_t n, int32_t device, float* out);
 rtc_status rtc_cosf(const float* x, uint32_t n, int32_t device, float* out);
+/* f32::atan2 / f32::acos (pattern/uv.rs:108,101) likewise */
+rtc_status rtc_atan2f(const float* y, const float* x, uint32_t n, int32_t device, float* out);
+rtc_status rtc_acosf(const float* x, uint32_t n, int32_t device, float* out);
 
 /* Canvas::to_ppm (canvas.rs:58-96) on an f32 image already on the host:
  * returns a malloc'd buffer (free with rtc_free) holding the P3 text. */

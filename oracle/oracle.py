@@ -371,7 +371,7 @@ class Pattern:
         if self.uv:
             arr = (_UVPattern * len(self.uv))(*[u._c() for u in self.uv])
             p.uv_mapping, p.n_uv, p.uv = self.uv_mapping, len(self.uv), arr
-            p._keep = (arr, self.uv)  # the ctypes array and the image buffers must outlive the call
+            self._keep = (arr, self.uv)  # borrowed by the C struct and its copies: lives as long as this Pattern
         return p
 
     def color_at_world(self, point):

@@ -9,6 +9,8 @@ top of that ABI.  The shared library must be built first
 """
 from ._lib import RtcError, lib  # noqa: F401
 from .api import *  # noqa: F401,F403
+from .api import (AlignCheck, CubicMap, CylindricalMap, PlanarMap, SphericalMap, TextureMap, UVCheckers, UVImage,  # noqa: F401
+                  acosf, acosf_host, atan2f, atan2f_host, canvas_from_ppm)
 from .api import (BoundingBox, Camera, Canvas, Checkers, Cone, Cube, Cylinder, Gradient, GroupShape, Material,  # noqa: F401
                   Pattern, Plane, PointLight, RectangleLight, Rings, Shape, Sine2D, SmoothTriangle, Sphere, Stripes, Triangle, World, cosf, cosf_host,
                   default_world, device_count, glass, metal, powf, powf_host)

@@ -16,7 +16,9 @@ RTC_OK = 0
 RTC_ERR_INVALID_ARG, RTC_ERR_UNSUPPORTED, RTC_ERR_NO_LIGHT, RTC_ERR_DEVICE, RTC_ERR_NO_DEVICE = -1, -2, -3, -4, -5
 RTC_SPHERE, RTC_PLANE, RTC_CUBE, RTC_CYLINDER, RTC_CONE, RTC_TRIANGLE = 0, 1, 2, 3, 4, 5
 (RTC_PATTERN_NONE, RTC_PATTERN_STRIPES, RTC_PATTERN_GRADIENT, RTC_PATTERN_RINGS, RTC_PATTERN_CHECKERS,
- RTC_PATTERN_SINE2D) = 0, 1, 2, 3, 4, 5
+ RTC_PATTERN_SINE2D, RTC_PATTERN_TEXTURE_MAP, RTC_PATTERN_CUBE_MAP) = 0, 1, 2, 3, 4, 5, 6, 7
+RTC_UV_CHECKERS, RTC_UV_ALIGN_CHECK, RTC_UV_IMAGE = 1, 2, 3
+RTC_MAP_SPHERICAL, RTC_MAP_PLANAR, RTC_MAP_CYLINDRICAL = 1, 2, 3
 RTC_LIGHT_POINT, RTC_LIGHT_RECT = 0, 1
 RTC_JITTER_CONSTANT, RTC_JITTER_HASHED = 0, 2
 RTC_MAX_DEPTH = 8
@@ -24,8 +26,14 @@ RTC_MAX_DEPTH = 8
 FP = C.POINTER(C.c_float)
 
 
+class rtc_uv_pattern(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("width", C.c_float), ("height", C.c_float), ("colors", (C.c_float * 3) * 5),
+                ("image_width", C.c_uint32), ("image_height", C.c_uint32), ("image_rgb", C.POINTER(C.c_float))]
+
+
 class rtc_pattern(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("a", C.c_float * 3), ("b", C.c_float * 3), ("inv", C.c_float * 16)]
+    _fields_ = [("kind", C.c_int32), ("a", C.c_float * 3), ("b", C.c_float * 3), ("inv", C.c_float * 16),
+                ("uv_mapping", C.c_int32), ("n_uv", C.c_uint32), ("uv", C.POINTER(rtc_uv_pattern))]
 
 
 class rtc_material(C.Structure):
@@ -97,6 +105,9 @@ SIGNATURES = {
     "rtc_reflect": (None, [FP, FP, FP]),
     "rtc_material_default": (None, [C.POINTER(rtc_material)]),
     "rtc_pattern_init": (C.c_int, [C.POINTER(rtc_pattern), C.c_int32, FP, FP, FP]),
+    "rtc_texture_map_init": (C.c_int, [C.POINTER(rtc_pattern), C.c_int32, C.POINTER(rtc_uv_pattern), C.c_uint32, FP]),
+    "rtc_canvas_from_ppm": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_void_p)]),
     "rtc_object_init": (C.c_int, [C.POINTER(rtc_object), C.c_int32, FP, C.POINTER(rtc_material)]),
     "rtc_bounds_empty": (None, [FP, FP]),
     "rtc_bounds_add": (None, [FP, FP, FP, FP]),
@@ -132,6 +143,8 @@ SIGNATURES = {
     "rtc_pattern_color_at": (C.c_int, [C.POINTER(rtc_pattern), C.POINTER(rtc_object), FP, C.c_uint32, C.c_int32, FP]),
     "rtc_powf": (C.c_int, [FP, FP, C.c_uint32, C.c_int32, FP]),
     "rtc_cosf": (C.c_int, [FP, C.c_uint32, C.c_int32, FP]),
+    "rtc_atan2f": (C.c_int, [FP, FP, C.c_uint32, C.c_int32, FP]),
+    "rtc_acosf": (C.c_int, [FP, C.c_uint32, C.c_int32, FP]),
     "rtc_to_ppm": (C.c_int, [FP, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "rtc_free": (None, [C.c_void_p]),
     "rtc_last_error": (C.c_char_p, []),
@@ -141,6 +154,8 @@ SIGNATURES = {
 # diagnostic export, not in rtc.h: host compile of the device powf restatement
 EXTRA = {"rtc_powf_host": (None, [FP, FP, C.c_uint32, FP]),
          "rtc_cosf_host": (None, [FP, C.c_uint32, FP]),
+         "rtc_atan2f_host": (None, [FP, FP, C.c_uint32, FP]),
+         "rtc_acosf_host": (None, [FP, C.c_uint32, FP]),
          # device self-test of the range-checked exact sqrt/divide cores against sqrtf and '/'
          "rtc_selftest_fastmath": (C.c_int, [FP, C.c_uint32, C.c_int32, C.POINTER(C.c_uint32)])}
 

@@ -180,10 +180,11 @@ class Pattern:
     """A procedural pattern: two colours and a pattern->object transform (pattern/pattern.rs:8-26).
     color_at_world / color_at_object evaluate on the device."""
 
-    def __init__(self, kind, a=(1.0, 1.0, 1.0), b=(0.0, 0.0, 0.0), transform=None):
+    def __init__(self, kind, a=(1.0, 1.0, 1.0), b=(0.0, 0.0, 0.0), transform=None, uv_mapping=0, uv=()):
         self.kind = kind
         self.a, self.b = tuple(float(c) for c in a), tuple(float(c) for c in b)
         self.transform = identity_4x4() if transform is None else np.asarray(transform, dtype=f32).reshape(4, 4)
+        self.uv_mapping, self.uv = uv_mapping, list(uv)  # TextureMap / CubicMap
 
     def set_transformation(self, t):
         """pattern.rs:20-22; the inverse is taken when the pattern is flattened."""
@@ -195,6 +196,11 @@ class Pattern:
     def _c(self):
         p = L.rtc_pattern()
         a, b, t = _a(self.a, 3), _a(self.b, 3), _a(self.transform, 16)
+        if self.uv:
+            arr = (L.rtc_uv_pattern * len(self.uv))(*[u._c() for u in self.uv])
+            L.check(L.lib().rtc_texture_map_init(C.byref(p), int(self.uv_mapping), arr, len(self.uv), _p(t)))
+            self._keep = (arr, self.uv)  # borrowed by the C struct (and by every copy of it): lives as long as this Pattern
+            return p
         L.check(L.lib().rtc_pattern_init(C.byref(p), self.kind, _p(a), _p(b), _p(t)))
         return p
 
@@ -210,7 +216,7 @@ class Pattern:
 
     def color_at_world(self, points, device=0):
         """Pattern::color_at_world: the pattern-space lookup itself (identity object and pattern transforms)."""
-        return Pattern(self.kind, self.a, self.b).color_at_object(points, None, device)
+        return Pattern(self.kind, self.a, self.b, None, self.uv_mapping, self.uv).color_at_object(points, None, device)
 
 
 def Stripes(a=(1.0, 1.0, 1.0), b=(0.0, 0.0, 0.0), transform=None):
@@ -236,6 +242,86 @@ def Checkers(a=(1.0, 1.0, 1.0), b=(0.0, 0.0, 0.0), transform=None):
 def Sine2D(a=(1.0, 1.0, 1.0), b=(0.0, 0.0, 0.0), transform=None):
     """Sine2D::new -- pattern/sine_2d.rs:16-23"""
     return Pattern(L.RTC_PATTERN_SINE2D, a, b, transform)
+
+
+# ------------------------------------------------------------------- pattern/uv.rs
+class UVCheckers:
+    """UVCheckers::new(width, height, a, b) -- pattern/uv.rs:28-36 (default 1, 1, white, black)"""
+
+    def __init__(self, width=1.0, height=1.0, a=(1.0, 1.0, 1.0), b=(0.0, 0.0, 0.0)):
+        self.width, self.height, self.a, self.b = width, height, tuple(a), tuple(b)
+
+    def _c(self):
+        u = L.rtc_uv_pattern()
+        u.kind, u.width, u.height = L.RTC_UV_CHECKERS, float(f32(self.width)), float(f32(self.height))
+        u.colors[0][:] = [float(f32(c)) for c in self.a]
+        u.colors[1][:] = [float(f32(c)) for c in self.b]
+        return u
+
+
+class AlignCheck:
+    """AlignCheck::new(main, ul, ur, bl, br) -- pattern/uv.rs:135-143 (default white, red, yellow, green, cyan)"""
+
+    def __init__(self, main=(1, 1, 1), ul=(1, 0, 0), ur=(1, 1, 0), bl=(0, 1, 0), br=(0, 1, 1)):
+        self.colors = [tuple(c) for c in (main, ul, ur, bl, br)]
+
+    def _c(self):
+        u = L.rtc_uv_pattern()
+        u.kind = L.RTC_UV_ALIGN_CHECK
+        for k, col in enumerate(self.colors):
+            u.colors[k][:] = [float(f32(c)) for c in col]
+        return u
+
+
+class UVImage:
+    """UVImage::new(canvas) -- pattern/uv.rs:351-355; canvas: a Canvas or an (h, w, 3) f32 array"""
+
+    def __init__(self, canvas):
+        data = canvas.data if hasattr(canvas, "data") and not isinstance(canvas, np.ndarray) else canvas
+        self.canvas = np.ascontiguousarray(data, dtype=f32)
+
+    def _c(self):
+        u = L.rtc_uv_pattern()
+        u.kind = L.RTC_UV_IMAGE
+        u.image_height, u.image_width = self.canvas.shape[0], self.canvas.shape[1]
+        u.image_rgb = _p(self.canvas)
+        return u
+
+
+class SphericalMap:  # pattern/uv.rs:91-105
+    kind = L.RTC_MAP_SPHERICAL
+
+
+class PlanarMap:  # pattern/uv.rs:180-186
+    kind = L.RTC_MAP_PLANAR
+
+
+class CylindricalMap:  # pattern/uv.rs:188-198
+    kind = L.RTC_MAP_CYLINDRICAL
+
+
+def TextureMap(uv_pattern, uv_mapping, transform=None):
+    """TextureMap::new(uv_pattern, uv_mapping) -- pattern/uv.rs:68-76"""
+    return Pattern(L.RTC_PATTERN_TEXTURE_MAP, transform=transform, uv_mapping=uv_mapping.kind, uv=[uv_pattern])
+
+
+def CubicMap(front, back, left, right, up, down, transform=None):
+    """CubicMap::new(front, back, left, right, up, down) -- pattern/uv.rs:207-231"""
+    return Pattern(L.RTC_PATTERN_CUBE_MAP, transform=transform, uv=[front, back, left, right, up, down])
+
+
+def canvas_from_ppm(text):
+    """canvas_from_ppm (canvas.rs:120-197): P3 text -> Canvas"""
+    if isinstance(text, str):
+        text = text.encode()
+    w, h, rgb = C.c_uint32(), C.c_uint32(), C.c_void_p()
+    L.check(L.lib().rtc_canvas_from_ppm(text, len(text), C.byref(w), C.byref(h), C.byref(rgb)))
+    try:
+        n = w.value * h.value * 3
+        data = np.ctypeslib.as_array(C.cast(rgb, L.FP), shape=(max(n, 1),))[:n].copy()
+    finally:
+        L.lib().rtc_free(rgb)
+    return Canvas(w.value, h.value, data.reshape(h.value, w.value, 3))
 
 
 # ------------------------------------------------------------------ material.rs
@@ -779,6 +865,36 @@ def cosf(x, device=0):
     a = _a(x)
     out = np.zeros(a.size, dtype=f32)
     L.check(L.lib().rtc_cosf(_p(a), a.size, device, _p(out)))
+    return out
+
+
+def atan2f(y, x, device=0):
+    """f32::atan2 on the device (pattern/uv.rs:108)."""
+    a, b = _a(y), _a(x)
+    out = np.zeros(a.size, dtype=f32)
+    L.check(L.lib().rtc_atan2f(_p(a), _p(b), a.size, device, _p(out)))
+    return out
+
+
+def acosf(x, device=0):
+    """f32::acos on the device (pattern/uv.rs:101)."""
+    a = _a(x)
+    out = np.zeros(a.size, dtype=f32)
+    L.check(L.lib().rtc_acosf(_p(a), a.size, device, _p(out)))
+    return out
+
+
+def atan2f_host(y, x):
+    a, b = _a(y), _a(x)
+    out = np.zeros(a.size, dtype=f32)
+    L.lib().rtc_atan2f_host(_p(a), _p(b), a.size, _p(out))
+    return out
+
+
+def acosf_host(x):
+    a = _a(x)
+    out = np.zeros(a.size, dtype=f32)
+    L.lib().rtc_acosf_host(_p(a), a.size, _p(out))
     return out
 
 

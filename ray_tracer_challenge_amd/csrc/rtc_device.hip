@@ -102,6 +102,26 @@ static void pack_triangle(const rtc_object& o, float4 rec[3]) {
     rec[1] = make_float4(e1[0], e1[1], e1[2], nrm[1]);
     rec[2] = make_float4(e2[0], e2[1], e2[2], nrm[2]);
 }
+static rtc_status pack_uv_pattern(const rtc_uv_pattern& u, std::vector<float4>* uvrec, std::vector<float>* texels,
+                                  std::vector<std::pair<const float*, size_t>>* seen);
+// TextureMap / CubicMap: the pattern's second record points at its UV patterns, which are appended to `uvrec`.
+static rtc_status pack_texture_map(const rtc_pattern& pt, float4 rec[5], std::vector<float4>* uvrec, std::vector<float>* texels,
+                                   std::vector<std::pair<const float*, size_t>>* seen) {
+    const uint32_t want = pt.kind == RTC_PATTERN_CUBE_MAP ? 6u : 1u;
+    if (pt.n_uv != want || !pt.uv) return fail(RTC_ERR_INVALID_ARG, "pattern kind %d needs %u UV pattern(s), got %u", pt.kind, want, pt.n_uv);
+    if (pt.kind == RTC_PATTERN_TEXTURE_MAP && (pt.uv_mapping < RTC_MAP_SPHERICAL || pt.uv_mapping > RTC_MAP_CYLINDRICAL))
+        return fail(RTC_ERR_UNSUPPORTED, "UV mapping %d is not on the device path", pt.uv_mapping);
+    uint32_t mapping = (uint32_t)pt.uv_mapping, first = (uint32_t)(uvrec->size() / 6);
+    float mf, ff;
+    std::memcpy(&mf, &mapping, 4);
+    std::memcpy(&ff, &first, 4);
+    rec[1] = make_float4(mf, ff, 0.0f, 0.0f);
+    for (uint32_t k = 0; k < want; k++) {
+        rtc_status st = pack_uv_pattern(pt.uv[k], uvrec, texels, seen);
+        if (st != RTC_OK) return st;
+    }
+    return RTC_OK;
+}
 // The five pattern records of one material (see SceneSoA::pat).
 static void pack_pattern(const rtc_pattern& pt, float4 rec[5]) {
     uint32_t kind = (uint32_t)pt.kind;
@@ -118,7 +138,48 @@ static void pack_pattern(const rtc_pattern& pt, float4 rec[5]) {
 
 // Validates and flattens rtc_scene + rtc_camera into the kernel's header and
 // SoA records (host staging buffer: 7 float4 arrays of np entries each, then 5 pattern records per object).
-static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHdr* hdr, std::vector<float4>* soa) {
+// Appends the six `uvrec` records of one UV pattern; UVImage canvases go to `texels` (each distinct host image once).
+static rtc_status pack_uv_pattern(const rtc_uv_pattern& u, std::vector<float4>* uvrec, std::vector<float>* texels,
+                                  std::vector<std::pair<const float*, size_t>>* seen) {
+    auto as_f = [](uint32_t v) {
+        float f;
+        std::memcpy(&f, &v, 4);
+        return f;
+    };
+    if (u.kind < RTC_UV_CHECKERS || u.kind > RTC_UV_IMAGE) return fail(RTC_ERR_UNSUPPORTED, "UV pattern kind %d is not on the device path", u.kind);
+    size_t first_texel = 0;
+    uint32_t iw = 0, ih = 0;
+    if (u.kind == RTC_UV_IMAGE) {
+        if (!u.image_rgb || u.image_width == 0 || u.image_height == 0) return fail(RTC_ERR_INVALID_ARG, "UVImage without a canvas");
+        iw = u.image_width;
+        ih = u.image_height;
+        bool found = false;
+        for (auto& e : *seen)
+            if (e.first == u.image_rgb) {
+                first_texel = e.second;
+                found = true;
+            }
+        if (!found) {
+            first_texel = texels->size() / 3;
+            texels->insert(texels->end(), u.image_rgb, u.image_rgb + (size_t)iw * ih * 3);
+            seen->push_back({u.image_rgb, first_texel});
+        }
+        if (first_texel + (size_t)iw * ih > 0xffffffffull) return fail(RTC_ERR_UNSUPPORTED, "more than 2^32 texels");
+    }
+    const float (*c)[3] = u.colors;
+    uvrec->push_back(make_float4(as_f((uint32_t)u.kind), u.width, u.height, as_f((uint32_t)first_texel)));
+    uvrec->push_back(make_float4(as_f(iw), as_f(ih), 0.0f, 0.0f));
+    uvrec->push_back(make_float4(c[0][0], c[0][1], c[0][2], c[1][0]));
+    uvrec->push_back(make_float4(c[1][1], c[1][2], c[2][0], c[2][1]));
+    uvrec->push_back(make_float4(c[2][2], c[3][0], c[3][1], c[3][2]));
+    uvrec->push_back(make_float4(c[4][0], c[4][1], c[4][2], 0.0f));
+    return RTC_OK;
+}
+
+static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHdr* hdr, std::vector<float4>* soa,
+                          std::vector<float>* texels) {
+    std::vector<float4> uvrec;
+    std::vector<std::pair<const float*, size_t>> seen_images;
     if (!scene) return fail(RTC_ERR_INVALID_ARG, "scene is NULL");
     if (!scene->light) return fail(RTC_ERR_NO_LIGHT, "World light should be set");  // world.rs:66
     if (scene->n_objects && !scene->objects) return fail(RTC_ERR_INVALID_ARG, "scene.objects is NULL");
@@ -152,12 +213,17 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         (*soa)[6 * np + i] = make_float4(m.transparency, m.refractive_index, 0.0f, 0.0f);
         const rtc_pattern& pt = m.pattern;
         if (pt.kind != RTC_PATTERN_NONE) {
-            if (pt.kind < RTC_PATTERN_STRIPES || pt.kind > RTC_PATTERN_SINE2D)
+            if (pt.kind < RTC_PATTERN_STRIPES || pt.kind > RTC_PATTERN_CUBE_MAP)
                 return fail(RTC_ERR_UNSUPPORTED, "object %u: pattern kind %d is not on the device path", i, pt.kind);
             if (!is_affine(pt.inv))
                 return fail(RTC_ERR_UNSUPPORTED, "object %u: pattern inverse transform is not affine", i);
             hdr->has_patterns = 1;
-            pack_pattern(pt, &(*soa)[7 * (size_t)np + 5 * (size_t)i]);
+            float4* rec = &(*soa)[7 * (size_t)np + 5 * (size_t)i];
+            pack_pattern(pt, rec);
+            if (pt.kind >= RTC_PATTERN_TEXTURE_MAP) {
+                rtc_status ust = pack_texture_map(pt, rec, &uvrec, texels, &seen_images);
+                if (ust != RTC_OK) return ust;
+            }
         }
     }
     // GroupShapes: write the depth-first traversal out as an entry list (see SceneSoA::trav)
@@ -262,6 +328,8 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     } else if (l.kind != RTC_LIGHT_POINT) {
         return fail(RTC_ERR_UNSUPPORTED, "light kind %d", l.kind);
     }
+    hdr->uvrec_off = (uint32_t)soa->size();
+    soa->insert(soa->end(), uvrec.begin(), uvrec.end());
     if (cam) {
         if (cam->width == 0 || cam->height == 0) return fail(RTC_ERR_INVALID_ARG, "empty canvas");
         if (!is_affine(cam->inv)) return fail(RTC_ERR_UNSUPPORTED, "camera inverse transform is not affine");
@@ -290,6 +358,8 @@ struct rtc_ctx {
     bool has_scene = false;
     float4* d_soa = nullptr;
     size_t soa_cap = 0;  // float4 entries
+    float* d_texels = nullptr;  // UVImage canvases (RGB f32), grow-only
+    size_t texel_cap = 0;       // floats
     uint32_t n_objects = 0;
     bool simple = false;  // every object scale+translate-only, no cylinder / cone, no patterns
     // workspace of rtc_ctx_to_ppm (grow-only)
@@ -437,9 +507,11 @@ rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunct
 
 }  // namespace
 
-static SceneSoA soa_view(const float4* base, uint32_t n) {
-    uint32_t m = rtc::padded_count(n);
+static SceneSoA soa_view(const float4* base, const SceneHdr& hdr, const float* d_texels) {
+    uint32_t m = rtc::padded_count(hdr.n_objects);
     SceneSoA s;
+    s.uvrec = base + hdr.uvrec_off;
+    s.texels = d_texels;
     s.geo = base + 0 * (size_t)m;
     s.off0 = base + 1 * (size_t)m;
     s.off1 = base + 2 * (size_t)m;
@@ -477,6 +549,7 @@ void rtc_ctx_destroy(rtc_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->d_soa) (void)hipFree(c->d_soa);
+    if (c->d_texels) (void)hipFree(c->d_texels);
     if (c->d_block_counts) (void)hipFree(c->d_block_counts);
     if (c->d_total) (void)hipFree(c->d_total);
     if (c->d_ppm_rows) (void)hipFree(c->d_ppm_rows);
@@ -492,9 +565,17 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     if (!c) return fail(RTC_ERR_INVALID_ARG, "ctx is NULL");
     SceneHdr hdr;
     std::vector<float4> soa;
-    rtc_status st = flatten(scene, camera, &hdr, &soa);
+    std::vector<float> texels;
+    rtc_status st = flatten(scene, camera, &hdr, &soa, &texels);
     if (st != RTC_OK) return st;
     HIP_TRY(hipSetDevice(c->device));
+    if (texels.size() > c->texel_cap) {
+        if (c->d_texels) HIP_TRY(hipFree(c->d_texels));
+        c->d_texels = nullptr;
+        HIP_TRY(hipMalloc(&c->d_texels, texels.size() * sizeof(float)));
+        c->texel_cap = texels.size();
+    }
+    if (!texels.empty()) HIP_TRY(hipMemcpy(c->d_texels, texels.data(), texels.size() * sizeof(float), hipMemcpyHostToDevice));
     if (soa.size() > c->soa_cap) {
         if (c->d_soa) HIP_TRY(hipFree(c->d_soa));
         c->d_soa = nullptr;
@@ -615,7 +696,7 @@ rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, 
     }
     RenderArgs a;
     a.hdr = c->hdr;
-    a.soa = soa_view(c->d_soa, c->n_objects);
+    a.soa = soa_view(c->d_soa, c->hdr, c->d_texels);
     a.out = (float*)d_out_rgb;
     a.block_counts = c->d_block_counts;
     a.rows = rows;
@@ -779,16 +860,19 @@ struct DevBuf {
     }
     hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
 };
-rtc_status begin_batch(const rtc_scene* scene, int32_t device, SceneHdr* hdr, DevBuf* soa_buf) {
+rtc_status begin_batch(const rtc_scene* scene, int32_t device, SceneHdr* hdr, DevBuf* soa_buf, DevBuf* tex_buf) {
     int n = usable_devices();
     if (n <= 0) return fail(RTC_ERR_NO_DEVICE, "no HIP device visible; librtc_amd has no CPU fallback");
     if (device < 0 || device >= n) return fail(RTC_ERR_INVALID_ARG, "device %d out of range (have %d)", device, n);
     std::vector<float4> soa;
-    rtc_status st = flatten(scene, nullptr, hdr, &soa);
+    std::vector<float> texels;
+    rtc_status st = flatten(scene, nullptr, hdr, &soa, &texels);
     if (st != RTC_OK) return st;
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(soa_buf->alloc(soa.size() * sizeof(float4)));
     HIP_TRY(hipMemcpy(soa_buf->p, soa.data(), soa.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(tex_buf->alloc(texels.size() * sizeof(float)));
+    if (!texels.empty()) HIP_TRY(hipMemcpy(tex_buf->p, texels.data(), texels.size() * sizeof(float), hipMemcpyHostToDevice));
     return RTC_OK;
 }
 }  // namespace
@@ -803,8 +887,8 @@ rtc_status rtc_color_at(const rtc_scene* scene, const float* origins, const floa
             return fail(RTC_ERR_INVALID_ARG, "ray %u: origin.w must be 1 and direction.w 0", i);
     }
     SceneHdr hdr;
-    DevBuf soa, d_o, d_d, d_out;
-    rtc_status st = begin_batch(scene, device, &hdr, &soa);
+    DevBuf soa, tex, d_o, d_d, d_out;
+    rtc_status st = begin_batch(scene, device, &hdr, &soa, &tex);
     if (st != RTC_OK) return st;
     HIP_TRY(d_o.alloc((size_t)n * 16));
     HIP_TRY(d_d.alloc((size_t)n * 16));
@@ -812,7 +896,7 @@ rtc_status rtc_color_at(const rtc_scene* scene, const float* origins, const floa
     HIP_TRY(hipMemcpy(d_o.p, origins, (size_t)n * 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_d.p, directions, (size_t)n * 16, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(color_at_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, hdr,
-                       soa_view((const float4*)soa.p, hdr.n_objects), (const float4*)d_o.p, (const float4*)d_d.p, n,
+                       soa_view((const float4*)soa.p, hdr, (const float*)tex.p), (const float4*)d_o.p, (const float4*)d_d.p, n,
                        depth, (float*)d_out.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out_rgb, d_out.p, (size_t)n * 12, hipMemcpyDeviceToHost));
@@ -823,18 +907,18 @@ rtc_status rtc_intensity_at(const rtc_scene* scene, const float* points, uint32_
     if (!points || !out) return fail(RTC_ERR_INVALID_ARG, "rtc_intensity_at: null argument");
     if (n == 0) return RTC_OK;
     SceneHdr hdr;
-    DevBuf soa, d_p, d_out;
-    rtc_status st = begin_batch(scene, device, &hdr, &soa);
+    DevBuf soa, tex, d_p, d_out;
+    rtc_status st = begin_batch(scene, device, &hdr, &soa, &tex);
     if (st != RTC_OK) return st;
     HIP_TRY(d_p.alloc((size_t)n * 16));
     HIP_TRY(d_out.alloc((size_t)n * 4));
     HIP_TRY(hipMemcpy(d_p.p, points, (size_t)n * 16, hipMemcpyHostToDevice));
     if (hdr.n_objects <= 4 && !hdr.n_trav)
         hipLaunchKernelGGL(intensity_at_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, hdr,
-                           soa_view((const float4*)soa.p, hdr.n_objects), (const float4*)d_p.p, n, (float*)d_out.p);
+                           soa_view((const float4*)soa.p, hdr, (const float*)tex.p), (const float4*)d_p.p, n, (float*)d_out.p);
     else
         hipLaunchKernelGGL(intensity_at_kernel_generic, dim3((n + 63) / 64), dim3(64), 0, nullptr, hdr,
-                           soa_view((const float4*)soa.p, hdr.n_objects), (const float4*)d_p.p, n, (float*)d_out.p);
+                           soa_view((const float4*)soa.p, hdr, (const float*)tex.p), (const float4*)d_p.p, n, (float*)d_out.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RTC_OK;
@@ -845,8 +929,8 @@ rtc_status rtc_is_shadowed(const rtc_scene* scene, const float* light_positions,
     if (!light_positions || !points || !out) return fail(RTC_ERR_INVALID_ARG, "rtc_is_shadowed: null argument");
     if (n == 0) return RTC_OK;
     SceneHdr hdr;
-    DevBuf soa, d_l, d_p, d_out;
-    rtc_status st = begin_batch(scene, device, &hdr, &soa);
+    DevBuf soa, tex, d_l, d_p, d_out;
+    rtc_status st = begin_batch(scene, device, &hdr, &soa, &tex);
     if (st != RTC_OK) return st;
     HIP_TRY(d_l.alloc((size_t)n * 16));
     HIP_TRY(d_p.alloc((size_t)n * 16));
@@ -854,7 +938,7 @@ rtc_status rtc_is_shadowed(const rtc_scene* scene, const float* light_positions,
     HIP_TRY(hipMemcpy(d_l.p, light_positions, (size_t)n * 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_p.p, points, (size_t)n * 16, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(is_shadowed_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, hdr,
-                       soa_view((const float4*)soa.p, hdr.n_objects), (const float4*)d_l.p, (const float4*)d_p.p, n,
+                       soa_view((const float4*)soa.p, hdr, (const float*)tex.p), (const float4*)d_l.p, (const float4*)d_p.p, n,
                        (int32_t*)d_out.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -891,6 +975,38 @@ rtc_status rtc_cosf(const float* x, uint32_t n, int32_t device, float* out) {
     HIP_TRY(d_out.alloc((size_t)n * 4));
     HIP_TRY(hipMemcpy(d_x.p, x, (size_t)n * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(cosf_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, (const float*)d_x.p, n, (float*)d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
+rtc_status rtc_atan2f(const float* y, const float* x, uint32_t n, int32_t device, float* out) {
+    if (!x || !y || !out) return fail(RTC_ERR_INVALID_ARG, "rtc_atan2f: null argument");
+    if (n == 0) return RTC_OK;
+    rtc_status st = select_device(device);
+    if (st != RTC_OK) return st;
+    DevBuf d_x, d_y, d_out;
+    HIP_TRY(d_x.alloc((size_t)n * 4));
+    HIP_TRY(d_y.alloc((size_t)n * 4));
+    HIP_TRY(d_out.alloc((size_t)n * 4));
+    HIP_TRY(hipMemcpy(d_x.p, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_y.p, y, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(atan2f_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, (const float*)d_y.p, (const float*)d_x.p, n,
+                       (float*)d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+rtc_status rtc_acosf(const float* x, uint32_t n, int32_t device, float* out) {
+    if (!x || !out) return fail(RTC_ERR_INVALID_ARG, "rtc_acosf: null argument");
+    if (n == 0) return RTC_OK;
+    rtc_status st = select_device(device);
+    if (st != RTC_OK) return st;
+    DevBuf d_x, d_out;
+    HIP_TRY(d_x.alloc((size_t)n * 4));
+    HIP_TRY(d_out.alloc((size_t)n * 4));
+    HIP_TRY(hipMemcpy(d_x.p, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(acosf_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, (const float*)d_x.p, n, (float*)d_out.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RTC_OK;
@@ -973,7 +1089,7 @@ rtc_status rtc_normal_at(const rtc_object* object, const float* world_points, ui
 rtc_status rtc_pattern_color_at(const rtc_pattern* pattern, const rtc_object* object, const float* world_points,
                                 uint32_t n, int32_t device, float* out_rgb) {
     if (!pattern || !world_points || !out_rgb) return fail(RTC_ERR_INVALID_ARG, "rtc_pattern_color_at: null argument");
-    if (pattern->kind < RTC_PATTERN_STRIPES || pattern->kind > RTC_PATTERN_SINE2D)
+    if (pattern->kind < RTC_PATTERN_STRIPES || pattern->kind > RTC_PATTERN_CUBE_MAP)
         return fail(RTC_ERR_UNSUPPORTED, "rtc_pattern_color_at: pattern kind %d is not on the device path", pattern->kind);
     if (!is_affine(pattern->inv)) return fail(RTC_ERR_UNSUPPORTED, "rtc_pattern_color_at: pattern inverse transform is not affine");
     Obj ob;
@@ -984,14 +1100,22 @@ rtc_status rtc_pattern_color_at(const rtc_pattern* pattern, const rtc_object* ob
     if (n == 0) return RTC_OK;
     float4 rec[5];
     pack_pattern(*pattern, rec);
-    DevBuf d_pat, d_p, d_out;
+    std::vector<float4> uvrec;
+    std::vector<float> texels;
+    std::vector<std::pair<const float*, size_t>> seen;
+    if (pattern->kind >= RTC_PATTERN_TEXTURE_MAP && (st = pack_texture_map(*pattern, rec, &uvrec, &texels, &seen)) != RTC_OK) return st;
+    DevBuf d_pat, d_p, d_out, d_uv, d_tex;
+    HIP_TRY(d_uv.alloc(uvrec.size() * sizeof(float4)));
+    HIP_TRY(d_tex.alloc(texels.size() * sizeof(float)));
+    if (!uvrec.empty()) HIP_TRY(hipMemcpy(d_uv.p, uvrec.data(), uvrec.size() * sizeof(float4), hipMemcpyHostToDevice));
+    if (!texels.empty()) HIP_TRY(hipMemcpy(d_tex.p, texels.data(), texels.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(d_pat.alloc(sizeof(rec)));
     HIP_TRY(d_p.alloc((size_t)n * 16));
     HIP_TRY(d_out.alloc((size_t)n * 12));
     HIP_TRY(hipMemcpy(d_pat.p, rec, sizeof(rec), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_p.p, world_points, (size_t)n * 16, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(pattern_color_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, ob, (const float4*)d_pat.p,
-                       (const float4*)d_p.p, n, (float*)d_out.p);
+                       (const float4*)d_uv.p, (const float*)d_tex.p, (const float4*)d_p.p, n, (float*)d_out.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out_rgb, d_out.p, (size_t)n * 12, hipMemcpyDeviceToHost));
     return RTC_OK;

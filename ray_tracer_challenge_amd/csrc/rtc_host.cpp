@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "rtc_internal.h"
 
@@ -222,15 +223,126 @@ rtc_status rtc_pattern_init(rtc_pattern* out, int32_t kind, const float a[3], co
     if (!out || !a || !b) return fail(RTC_ERR_INVALID_ARG, "rtc_pattern_init: null argument");
     if (kind < RTC_PATTERN_STRIPES || kind > RTC_PATTERN_SINE2D)
         return fail(RTC_ERR_UNSUPPORTED, "rtc_pattern_init: unknown pattern kind %d", kind);
+    std::memset(out, 0, sizeof(*out));
     out->kind = kind;
     std::memcpy(out->a, a, sizeof(float) * 3);
     std::memcpy(out->b, b, sizeof(float) * 3);
     if (transform) {
         inverse4(transform, out->inv);  // pattern.rs:52-54
     } else {  // BasePattern::default(): the identity (pattern.rs:31-34)
-        std::memset(out->inv, 0, sizeof(out->inv));
         for (int i = 0; i < 4; i++) out->inv[i * 5] = 1.0f;
     }
+    return RTC_OK;
+}
+
+rtc_status rtc_texture_map_init(rtc_pattern* out, int32_t uv_mapping, const rtc_uv_pattern* uv, uint32_t n_uv,
+                                const float transform[16]) {
+    if (!out || !uv) return fail(RTC_ERR_INVALID_ARG, "rtc_texture_map_init: null argument");
+    const bool cube = n_uv == 6 && uv_mapping == 0;
+    if (!cube && !(n_uv == 1 && uv_mapping >= RTC_MAP_SPHERICAL && uv_mapping <= RTC_MAP_CYLINDRICAL))
+        return fail(RTC_ERR_UNSUPPORTED, "rtc_texture_map_init: want one UV pattern and a mapping (TextureMap) or six UV patterns "
+                                         "and mapping 0 (CubicMap); got %u pattern(s), mapping %d", n_uv, uv_mapping);
+    std::memset(out, 0, sizeof(*out));
+    out->kind = cube ? RTC_PATTERN_CUBE_MAP : RTC_PATTERN_TEXTURE_MAP;
+    out->uv_mapping = uv_mapping;
+    out->n_uv = n_uv;
+    out->uv = uv;
+    if (transform) {
+        inverse4(transform, out->inv);
+    } else {
+        for (int i = 0; i < 4; i++) out->inv[i * 5] = 1.0f;
+    }
+    return RTC_OK;
+}
+
+// canvas_from_ppm, canvas.rs:120-197 (clean_line :183-197): '#' lines and blank lines are dropped anywhere, then the
+// magic "P3", "width height", the scale, and colour samples that may be split across lines any way they like; each
+// complete triplet is one pixel (sample / scale as f32), filled row by row.
+rtc_status rtc_canvas_from_ppm(const char* text, uint64_t len, uint32_t* width, uint32_t* height, float** out_rgb) {
+    if (!text || !width || !height || !out_rgb) return fail(RTC_ERR_INVALID_ARG, "rtc_canvas_from_ppm: null argument");
+    struct Line {
+        const char* b;
+        const char* e;
+    };
+    auto is_space = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; };
+    std::vector<Line> lines;
+    for (uint64_t i = 0; i < len;) {
+        uint64_t j = i;
+        while (j < len && text[j] != '\n') j++;
+        const char* b = text + i;
+        const char* e = text + j;
+        while (b < e && is_space(*b)) b++;
+        while (e > b && is_space(e[-1])) e--;
+        if (b < e && *b != '#') lines.push_back({b, e});
+        i = j + 1;
+    }
+    // str::parse::<u32 / usize>: an optional '+', then decimal digits only
+    auto parse_uint = [](const char* b, const char* e, uint64_t* out) {
+        if (b < e && *b == '+') b++;
+        if (b >= e) return false;
+        uint64_t v = 0;
+        for (; b < e; b++) {
+            if (*b < '0' || *b > '9') return false;
+            v = v * 10 + (uint64_t)(*b - '0');
+            if (v > 0xffffffffull) return false;
+        }
+        *out = v;
+        return true;
+    };
+    auto tokens = [&](const Line& l) {
+        std::vector<Line> out;
+        const char* p = l.b;
+        while (p < l.e) {
+            while (p < l.e && is_space(*p)) p++;
+            const char* q = p;
+            while (q < l.e && !is_space(*q)) q++;
+            if (q > p) out.push_back({p, q});
+            p = q;
+        }
+        return out;
+    };
+    if (lines.size() < 3) return fail(RTC_ERR_INVALID_ARG, "IoError: fewer than three header lines");  // the reference unwraps
+    if (!(lines[0].e - lines[0].b == 2 && lines[0].b[0] == 'P' && lines[0].b[1] == '3'))
+        return fail(RTC_ERR_INVALID_ARG, "IncorrectFormat: Incorrect magic number at line 1: expected P3, found %.*s",
+                    (int)(lines[0].e - lines[0].b), lines[0].b);
+    std::vector<Line> dims = tokens(lines[1]);
+    if (dims.size() != 2)
+        return fail(RTC_ERR_INVALID_ARG, "MalformedDimensionHeader: Expected width and height at line 2; found %.*s",
+                    (int)(lines[1].e - lines[1].b), lines[1].b);
+    uint64_t w = 0, h = 0, scale_u = 0;
+    if (!parse_uint(dims[0].b, dims[0].e, &w) || !parse_uint(dims[1].b, dims[1].e, &h) || !parse_uint(lines[2].b, lines[2].e, &scale_u))
+        return fail(RTC_ERR_INVALID_ARG, "ParseIntError: invalid digit found in string");
+    const float scale = (float)(uint32_t)scale_u;
+    const size_t n = (size_t)w * (size_t)h * 3;
+    float* img = (float*)std::calloc(n ? n : 1, sizeof(float));
+    if (!img) return fail(RTC_ERR_INVALID_ARG, "out of memory");
+    uint32_t pending[3];
+    int have = 0;
+    size_t x = 0, y = 0;
+    for (size_t li = 3; li < lines.size(); li++) {
+        for (const Line& t : tokens(lines[li])) {
+            uint64_t v;
+            if (!parse_uint(t.b, t.e, &v)) {
+                std::free(img);
+                return fail(RTC_ERR_INVALID_ARG, "ParseIntError: invalid digit found in string");
+            }
+            pending[have++] = (uint32_t)v;
+            if (have == 3) {
+                have = 0;
+                if (x < w && y < h) {
+                    float* px = img + (y * w + x) * 3;
+                    for (int k = 0; k < 3; k++) px[k] = (float)pending[k] / scale;
+                }
+                if (++x >= w) {
+                    x = 0;
+                    y++;
+                }
+            }
+        }
+    }
+    *width = (uint32_t)w;
+    *height = (uint32_t)h;
+    *out_rgb = img;
     return RTC_OK;
 }
 

@@ -40,7 +40,9 @@ typedef unsigned long size_t;
 #define RTC_MAX_DEPTH 8
 enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3, RTC_CONE = 4, RTC_TRIANGLE = 5 };
 enum { RTC_PATTERN_NONE = 0, RTC_PATTERN_STRIPES = 1, RTC_PATTERN_GRADIENT = 2, RTC_PATTERN_RINGS = 3,
-       RTC_PATTERN_CHECKERS = 4, RTC_PATTERN_SINE2D = 5 };
+       RTC_PATTERN_CHECKERS = 4, RTC_PATTERN_SINE2D = 5, RTC_PATTERN_TEXTURE_MAP = 6, RTC_PATTERN_CUBE_MAP = 7 };
+enum { RTC_UV_CHECKERS = 1, RTC_UV_ALIGN_CHECK = 2, RTC_UV_IMAGE = 3 };
+enum { RTC_MAP_SPHERICAL = 1, RTC_MAP_PLANAR = 2, RTC_MAP_CYLINDRICAL = 3 };
 enum { RTC_LIGHT_POINT = 0, RTC_LIGHT_RECT = 1 };
 enum { RTC_JITTER_CONSTANT = 0, RTC_JITTER_HASHED = 2 };
 #else
@@ -52,7 +54,10 @@ enum { RTC_JITTER_CONSTANT = 0, RTC_JITTER_HASHED = 2 };
 #define RTC_HOSTDEV __host__ __device__
 static_assert(RTC_MAX_DEPTH == 8 && RTC_SPHERE == 0 && RTC_PLANE == 1 && RTC_CUBE == 2 && RTC_CYLINDER == 3 &&
                   RTC_CONE == 4 && RTC_TRIANGLE == 5 && RTC_PATTERN_NONE == 0 && RTC_PATTERN_STRIPES == 1 && RTC_PATTERN_GRADIENT == 2 &&
-                  RTC_PATTERN_RINGS == 3 && RTC_PATTERN_CHECKERS == 4 && RTC_PATTERN_SINE2D == 5 && RTC_LIGHT_POINT == 0 && RTC_LIGHT_RECT == 1 && RTC_JITTER_CONSTANT == 0 && RTC_JITTER_HASHED == 2,
+                  RTC_PATTERN_RINGS == 3 && RTC_PATTERN_CHECKERS == 4 && RTC_PATTERN_SINE2D == 5 &&
+                  RTC_PATTERN_TEXTURE_MAP == 6 && RTC_PATTERN_CUBE_MAP == 7 && RTC_UV_CHECKERS == 1 &&
+                  RTC_UV_ALIGN_CHECK == 2 && RTC_UV_IMAGE == 3 && RTC_MAP_SPHERICAL == 1 && RTC_MAP_PLANAR == 2 &&
+                  RTC_MAP_CYLINDRICAL == 3 && RTC_LIGHT_POINT == 0 && RTC_LIGHT_RECT == 1 && RTC_JITTER_CONSTANT == 0 && RTC_JITTER_HASHED == 2,
               "rtc_kernel_core.h restates these rtc.h constants for the hiprtc build");
 #endif
 
@@ -477,6 +482,7 @@ struct SceneHdr {
     uint32_t has_patterns;  // some material carries a pattern (wave-uniform switch around the pattern code)
     uint32_t n_trav;        // entries in SceneSoA::trav; 0: the world is a flat object list
     float light_y_lo, light_y_hi;  // world-space y range of the area light's sample points, widened (light-cone culling)
+    uint32_t uvrec_off;            // where SceneSoA::uvrec starts inside the scene buffer, in float4 units (host use)
 };
 
 // Structure-of-arrays scene records in HBM: 4 float4 of geometry (64 B) and
@@ -513,6 +519,12 @@ struct SceneSoA {
     // { m03, m13, m23, 0 }: the translation column again, so that scale+translate-only objects need two records
     // (geo + trn = 32 B) instead of four
     const float4* __restrict__ trn;
+    // Texture maps (pattern/uv.rs).  A TEXTURE_MAP / CUBE_MAP pattern's second record is { mapping, first UV pattern,
+    // 0, 0 }; each UV pattern is six records in `uvrec`:
+    //   { kind, width, height, first texel }, { image width, image height, 0, 0 }, then five RGB colours packed
+    //   ({ c0.rgb, c1.r }, { c1.gb, c2.rg }, { c2.b, c3.rgb }, { c4.rgb, 0 }); `texels`: every UVImage's Canvas, RGB f32.
+    const float4* __restrict__ uvrec;
+    const float* __restrict__ texels;
 };
 enum : uint32_t { TRAV_GROUP = 0u, TRAV_LEAF = 1u };
 enum : uint32_t {
@@ -1234,8 +1246,105 @@ DI int32_t rust_f32_as_i32(float f) {
 // Pattern::color_at_world for the five procedural patterns (stripes.rs:39-45, gradient.rs:33-36, rings.rs:38-50,
 // checkers.rs:38-46, sine_2d.rs:39-44).  pa = {a.rgb, kind}, pb = {b.rgb | distance.rgb, 0}.
 // `v % 2 == 0` on an i32 is `(v & 1) == 0` for either sign.
-DI V3 pattern_color_at_world(float4 pa, float4 pb, V3 pt) {
+// Rust `f as usize`: saturating, NaN -> 0 (32 bits are plenty: it indexes an image)
+DI uint32_t rust_f32_as_index(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+// f32::rem_euclid: r = a % rhs; if r < 0 { r + |rhs| } else { r }   (`%` on f32 is fmodf, which is exact)
+DI float rem_euclid_f32(float a, float rhs) {
+    float r = fmodf(a, rhs);
+    return r < 0.0f ? r + fabsf(rhs) : r;
+}
+// UVPattern::color_at (uv.rs:45-55 UVCheckers, :145-165 AlignCheck, :366-376 UVImage)
+DI V3 uv_color_at(const SceneSoA& S, uint32_t index, float u, float v) {
+    const float4* r = S.uvrec + 6u * index;
+    const float4 h0 = r[0];
+    const uint32_t kind = __float_as_uint(h0.x);
+    if (kind == RTC_UV_IMAGE) {
+        const float4 h1 = r[1];
+        const uint32_t iw = __float_as_uint(h1.x), ih = __float_as_uint(h1.y);
+        const float vv = 1.0f - v;
+        const float x = u * (float)(iw - 1u);
+        const float y = vv * (float)(ih - 1u);
+        const uint32_t xi = rust_f32_as_index(roundf(x)), yi = rust_f32_as_index(roundf(y));
+        if (xi >= iw || yi >= ih) return v3(0.0f, 0.0f, 0.0f);  // the reference panics on the out-of-range index
+        const float* px = S.texels + ((size_t)__float_as_uint(h0.w) + (size_t)yi * iw + xi) * 3u;
+        return v3(px[0], px[1], px[2]);
+    }
+    const float4 c0 = r[2], c1 = r[3], c2 = r[4], c3 = r[5];
+    const V3 col[5] = {v3(c0.x, c0.y, c0.z), v3(c0.w, c1.x, c1.y), v3(c1.z, c1.w, c2.x), v3(c2.y, c2.z, c2.w), v3(c3.x, c3.y, c3.z)};
+    if (kind == RTC_UV_CHECKERS) {
+        const int32_t u2 = rust_f32_as_i32(floorf(u * h0.y)), v2 = rust_f32_as_i32(floorf(v * h0.z));
+        return (((uint32_t)u2 + (uint32_t)v2) & 1u) == 0u ? col[0] : col[1];
+    }
+    // AlignCheck: main, ul, ur, bl, br
+    if (v > 0.8f) {
+        if (u < 0.2f) return col[1];
+        if (u > 0.8f) return col[2];
+    } else if (v < 0.2f) {
+        if (u < 0.2f) return col[3];
+        if (u > 0.8f) return col[4];
+    }
+    return col[0];
+}
+constexpr float UV_FRAC_1_PI = 0.318309886183790671537767526745028724f;  // std::f32::consts::FRAC_1_PI
+constexpr float UV_PI = 3.14159265358979323846264338327950288f;
+constexpr float UV_FRAC_1_2PI = 1.0f / (2.0f * UV_PI);                   // uv.rs:12 (folded in f32, as rustc does)
+DI float u_from_azimuth(V3 p) {  // uv.rs:107-113
+    const float theta = atan2f_glibc(p.x, p.z);
+    const float raw_u = theta * UV_FRAC_1_2PI;
+    return 1.0f - (raw_u + 0.5f);
+}
+// TextureMap / CubicMap::color_at_world (uv.rs:84-88, 248-261)
+DI V3 texture_color_at_world(const SceneSoA& S, uint32_t kind, uint32_t mapping, uint32_t first_uv, V3 p) {
+    float u, v;
+    uint32_t index = first_uv;
+    if (kind == RTC_PATTERN_CUBE_MAP) {
+        // face_from_point (uv.rs:264-283), then the face's own projection (:285-319); faces in CubicMap::new's order
+        const float coord = fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z));
+        if (coord == p.x) {  // right
+            index += 3u;
+            u = fmodf(1.0f - p.z, 2.0f) / 2.0f;
+            v = fmodf(p.y + 1.0f, 2.0f) / 2.0f;
+        } else if (coord == -p.x) {  // left
+            index += 2u;
+            u = fmodf(p.z + 1.0f, 2.0f) / 2.0f;
+            v = fmodf(p.y + 1.0f, 2.0f) / 2.0f;
+        } else if (coord == p.y) {  // up
+            index += 4u;
+            u = fmodf(p.x + 1.0f, 2.0f) / 2.0f;
+            v = fmodf(1.0f - p.z, 2.0f) / 2.0f;
+        } else if (coord == -p.y) {  // down
+            index += 5u;
+            u = fmodf(p.x + 1.0f, 2.0f) / 2.0f;
+            v = fmodf(p.z + 1.0f, 2.0f) / 2.0f;
+        } else if (coord == p.z) {  // front
+            u = fmodf(p.x + 1.0f, 2.0f) / 2.0f;
+            v = fmodf(p.y + 1.0f, 2.0f) / 2.0f;
+        } else {  // back
+            index += 1u;
+            u = fmodf(1.0f - p.x, 2.0f) / 2.0f;
+            v = fmodf(p.y + 1.0f, 2.0f) / 2.0f;
+        }
+    } else if (mapping == RTC_MAP_SPHERICAL) {  // uv.rs:93-105
+        u = u_from_azimuth(p);
+        const float radius = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+        const float phi = acosf_glibc(p.y / radius);
+        v = 1.0f - phi * UV_FRAC_1_PI;
+    } else if (mapping == RTC_MAP_PLANAR) {  // uv.rs:182-186
+        u = rem_euclid_f32(p.x, 1.0f);
+        v = rem_euclid_f32(p.z, 1.0f);
+    } else {  // cylindrical, uv.rs:190-197
+        u = u_from_azimuth(p);
+        v = rem_euclid_f32(p.y, 2.0f * UV_PI) * UV_FRAC_1_2PI;
+    }
+    return uv_color_at(S, index, u, v);
+}
+DI V3 pattern_color_at_world(const SceneSoA& S, float4 pa, float4 pb, V3 pt) {
     const uint32_t kind = __float_as_uint(pa.w);
+    if (kind >= RTC_PATTERN_TEXTURE_MAP) return texture_color_at_world(S, kind, __float_as_uint(pb.x), __float_as_uint(pb.y), pt);
     const V3 a = v3(pa.x, pa.y, pa.z), b = v3(pb.x, pb.y, pb.z);
     if (kind == RTC_PATTERN_GRADIENT) {
         float fraction = pt.x - floorf(pt.x);
@@ -1253,12 +1362,12 @@ DI V3 pattern_color_at_world(float4 pa, float4 pb, V3 pt) {
 }
 // Pattern::color_at_object (pattern.rs:15-19): world -> object -> pattern space.  Both matrices are affine
 // (checked on the host), so the w component stays exactly 1.
-DI V3 pattern_color_at_object(const float4* __restrict__ pat, const Obj& rec, V3 world_point) {
+DI V3 pattern_color_at_object(const SceneSoA& S, const float4* __restrict__ pat, const Obj& rec, V3 world_point) {
     const float4 pa = pat[0], pb = pat[1], r0 = pat[2], r1 = pat[3], r2 = pat[4];
     V3 op = obj_point(rec, world_point);
     V3 pp = v3(r0.x * op.x + r0.y * op.y + r0.z * op.z + r0.w, r1.x * op.x + r1.y * op.y + r1.z * op.z + r1.w,
                r2.x * op.x + r2.y * op.y + r2.z * op.z + r2.w);
-    return pattern_color_at_world(pa, pb, pp);
+    return pattern_color_at_world(S, pa, pb, pp);
 }
 
 // light/phong_lighting.rs:12-63; `material_color` is material.color or the pattern's colour (:24-27)
@@ -1448,7 +1557,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                 if (spec_has_patterns(H.has_patterns)) {
                     const float4* pat = S.pat + 5 * ob;
                     if (__float_as_uint(pat[0].w) != RTC_PATTERN_NONE)
-                        material_color = pattern_color_at_object(pat, load_obj(S, ob), over_point);
+                        material_color = pattern_color_at_object(S, pat, load_obj(S, ob), over_point);
                 }
             }
             V3 surface = phong(H, material_color, ma, mb, over_point, eye, n, li);
@@ -1835,6 +1944,14 @@ __global__ void powf_kernel(const float* __restrict__ x, const float* __restrict
     if (i < n) out[i] = rtc_powf_dev(x[i], y[i]);
 }
 
+__global__ void atan2f_kernel(const float* __restrict__ y, const float* __restrict__ x, uint32_t n, float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = atan2f_glibc(y[i], x[i]);
+}
+__global__ void acosf_kernel(const float* __restrict__ x, uint32_t n, float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = acosf_glibc(x[i]);
+}
 __global__ void cosf_kernel(const float* __restrict__ x, uint32_t n, float* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = rtc_cosf_dev(x[i]);
@@ -1869,12 +1986,16 @@ __global__ void normal_at_kernel(Obj ob, const float4* __restrict__ tri, const f
 }
 
 // Pattern::color_at_object (pattern.rs:15-19) for caller-supplied world points; pat: the 5 pattern records.
-__global__ void pattern_color_kernel(Obj ob, const float4* __restrict__ pat, const float4* __restrict__ points, uint32_t n,
+__global__ void pattern_color_kernel(Obj ob, const float4* __restrict__ pat, const float4* __restrict__ uvrec,
+                                     const float* __restrict__ texels, const float4* __restrict__ points, uint32_t n,
                                      float* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 p = points[i];
-    V3 c = pattern_color_at_object(pat, ob, v3(p.x, p.y, p.z));
+    SceneSoA S = {};
+    S.uvrec = uvrec;
+    S.texels = texels;
+    V3 c = pattern_color_at_object(S, pat, ob, v3(p.x, p.y, p.z));
     out[3 * i + 0] = c.x;
     out[3 * i + 1] = c.y;
     out[3 * i + 2] = c.z;

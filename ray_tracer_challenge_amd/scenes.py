@@ -359,6 +359,90 @@ def mesh(width=512, height=384, nu=16, nv=10, threshold=6):
     return world, camera, 5
 
 
+def synthetic_ppm(width, height, seed=1, scale=255):
+    """P3 text of a deterministic test image (smooth bands + blocks + speckle): stands in for the earth / skybox
+    photographs the reference's texture demos read from files that are not in its repository."""
+    lines = ["P3", "# synthetic test image %dx%d seed %d" % (width, height, seed), "%d %d" % (width, height), str(scale)]
+    s = (seed * 2654435761) & 0xFFFFFFFF
+    for y in range(height):
+        row = []
+        for x in range(width):
+            s = _xorshift32(s or 1)
+            r = (x * scale) // max(width - 1, 1)
+            g = (y * scale) // max(height - 1, 1)
+            b = ((x // 8 + y // 8) % 2) * (scale // 2) + (s >> 24) * (scale // 2) // 255
+            row.append("%d %d %d" % (r, g, b))
+        for k in range(0, len(row), 5):
+            lines.append("  ".join(row[k:k + 5]))
+    return "\n".join(lines) + "\n"
+
+
+def first_textures_objects(api, earth_ppm=None):
+    """World.objects of demos/src/bin/first_textures.rs:37-118; `earth_ppm`: P3 text of the image the demo takes on its
+    command line (default: a synthetic 128x64 image)."""
+    black, white = (0, 0, 0), (1, 1, 1)
+    floor = api.Plane(api.scaling(10.0, 0.01, 10.0),
+                      api.Material(specular=0.0, pattern=api.TextureMap(api.UVCheckers(16.0, 8.0, black, white), api.PlanarMap())))
+    sphere = api.Sphere(api.translation(-2.5, 1.3, 3.0),
+                        api.Material(pattern=api.TextureMap(api.UVCheckers(16.0, 8.0, black, white), api.SphericalMap()),
+                                     diffuse=0.7, specular=0.3))
+    canvas = api.canvas_from_ppm(earth_ppm if earth_ppm is not None else synthetic_ppm(128, 64))
+    earth = api.Sphere(api.chain(api.translation(0.0, 1.0, 0.0), api.rotation_x(f32(-0.5)), api.rotation_y(f32(-1.5))),
+                       api.Material(pattern=api.TextureMap(api.UVImage(canvas), api.SphericalMap()), diffuse=0.9, specular=0.1,
+                                    shininess=10.0, ambient=0.1))
+    pedestal = api.Cylinder(None, api.Material(color=(0.2, 0.2, 0.2), ambient=0.0, diffuse=0.8, specular=0.0, reflective=0.2),
+                            minimum_y=-0.15, maximum_y=0.0, closed=True)
+    earth_display = api.GroupShape.with_children([earth, pedestal])
+    earth_display.set_transformation(api.translation(-0.2, 0.15, 0.5))
+    cylinder = api.Cylinder(api.translation(2.0, 2.0, 2.0),
+                            api.Material(ambient=0.1, specular=0.6, shininess=15.0, diffuse=0.8,
+                                         pattern=api.TextureMap(api.UVCheckers(16.0, 16.0, (0, 0.5, 0), white), api.CylindricalMap())),
+                            minimum_y=-3.0, maximum_y=3.0)
+    cube = api.Cube(api.chain(api.translation(5.0, 2.0, 2.0), api.rotation_x(-PI / f32(4.0))),
+                    api.Material(pattern=align_check_cubic_map(api)))
+    return [floor, sphere, cylinder, cube, earth_display]
+
+
+def align_check_cubic_map(api):
+    """get_align_check_cubic_map_pattern, pattern/uv.rs:321-338"""
+    white, red, yellow, green, cyan, blue, purple, brown = ((1, 1, 1), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 1, 1), (0, 0, 1),
+                                                             (1, 0, 1), (1, 0.5, 0))
+    left = api.AlignCheck(yellow, cyan, red, blue, brown)
+    front = api.AlignCheck(cyan, red, yellow, brown, green)
+    right = api.AlignCheck(red, yellow, purple, green, white)
+    back = api.AlignCheck(green, purple, cyan, white, blue)
+    up = api.AlignCheck(brown, cyan, purple, red, yellow)
+    down = api.AlignCheck(purple, brown, green, blue, white)
+    return api.CubicMap(front, back, left, right, up, down)
+
+
+def first_textures(width=1000, height=500, jitter=("hashed", DEFAULT_SEED), earth_ppm=None):
+    """demos/src/bin/first_textures.rs:34-141 (area light :160-170, which the demo draws with thread_rng)."""
+    from . import api
+    light = RectangleLight(color(1.5, 1.5, 1.5), point(-10, 10, -10), vector(2, 0, 0), 10, vector(0, 2, 0), 10, jitter)
+    world = World(first_textures_objects(api, earth_ppm), light)
+    camera = Camera(width, height, PI / f32(3.0), view_transform(point(0, 1.5, -10), point(2, 2.8, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
+def skybox_objects(api, face_size=64):
+    """World.objects of demos/src/bin/skybox.rs:40-117 with six synthetic face images."""
+    sphere = api.Sphere(api.chain(api.scaling(0.75, 0.75, 0.75), api.translation(0.0, 0.0, 5.0)),
+                        api.Material(diffuse=0.4, specular=0.6, shininess=20.0, reflective=0.6, ambient=0.0))
+    faces = [api.UVImage(api.canvas_from_ppm(synthetic_ppm(face_size, face_size, seed=k + 2))) for k in range(6)]
+    sky = api.Cube(api.scaling(1000.0, 1000.0, 1000.0),
+                   api.Material(diffuse=0.0, specular=0.0, ambient=1.0, pattern=api.CubicMap(*faces)))
+    return [sphere, sky]
+
+
+def skybox(width=800, height=400, face_size=64):
+    """demos/src/bin/skybox.rs:40-129 (its default canvas is 800x400)."""
+    from . import api
+    world = World(skybox_objects(api, face_size), PointLight(point(0, 100, 0), color(1, 1, 1)))
+    camera = Camera(width, height, 1.2, view_transform(point(0, 0, 0), point(0, 0, 5), vector(0, 1, 0)))
+    return world, camera, 5
+
+
 def shapes_medley(width=256, height=192, jitter=("hashed", 7)):
     """All four shape kinds, nested transparent objects, a non-casting object and an area light:
     a parity stress scene (not a reference demo).  The cylinders are the reflect_refract.rs one

@@ -7,13 +7,28 @@ from oracle import oracle as O
 f32 = np.float32
 
 
+def oracle_uv(u):
+    name = type(u).__name__
+    if name == "UVCheckers":
+        return O.UVCheckers(u.width, u.height, u.a, u.b)
+    if name == "AlignCheck":
+        return O.AlignCheck(*u.colors)
+    return O.UVImage(u.canvas)
+
+
+def oracle_pattern(p):
+    if p is None:
+        return None
+    return O.Pattern(p.kind, p.a, p.b, p.transform, p.uv_mapping, [oracle_uv(u) for u in p.uv])
+
+
 def oracle_shape(s):
     """Product-API shape -> oracle shape.  A GroupShape is handed over as the reference's
     GroupShape::with_children of its (already baked) children: the oracle derives the bounding boxes itself."""
     if hasattr(s, "children"):
         return O.GroupShape.with_children([oracle_shape(c) for c in s.children])
     m = s.material
-    pat = None if m.pattern is None else O.Pattern(m.pattern.kind, m.pattern.a, m.pattern.b, m.pattern.transform)
+    pat = oracle_pattern(m.pattern)
     om = O.Material(m.color, m.ambient, m.diffuse, m.specular, m.shininess, m.reflective, m.transparency,
                     m.refractive_index, pat)
     out = O.Shape(s.kind, s.transform, om, casts_shadow=s.casts_shadow, minimum_y=s.minimum_y,
