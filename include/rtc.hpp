@@ -89,16 +89,63 @@ RTC_HPP_MAT(view_transform, (Tuple from, Tuple to, Tuple up), rtc_view_transform
 // ---- pattern/*.rs -----------------------------------------------------------------------------------
 // A boxed Pattern: kind, the two colours (pub fields a / b as in stripes.rs:11-12) and the transform given to
 // set_transformation (pattern.rs:20-22); the inverse is taken when the material is flattened.
+// A boxed UVPattern (pattern/uv.rs:14-16): UVCheckers, AlignCheck or UVImage; an image's pixels are shared, not copied.
+struct UVPattern {
+    rtc_uv_pattern u{};
+    std::shared_ptr<std::vector<float>> image;
+};
+inline UVPattern UVCheckers(float width, float height, Color a, Color b) {  // uv.rs:28-36
+    UVPattern p;
+    p.u.kind = RTC_UV_CHECKERS;
+    p.u.width = width, p.u.height = height;
+    for (int k = 0; k < 3; k++) p.u.colors[0][k] = a.data()[k], p.u.colors[1][k] = b.data()[k];
+    return p;
+}
+inline UVPattern AlignCheck(Color main, Color ul, Color ur, Color bl, Color br) {  // uv.rs:135-143
+    UVPattern p;
+    p.u.kind = RTC_UV_ALIGN_CHECK;
+    const Color cs[5] = {main, ul, ur, bl, br};
+    for (int j = 0; j < 5; j++)
+        for (int k = 0; k < 3; k++) p.u.colors[j][k] = cs[j].data()[k];
+    return p;
+}
+enum class UVMapping : int32_t { Spherical = RTC_MAP_SPHERICAL, Planar = RTC_MAP_PLANAR, Cylindrical = RTC_MAP_CYLINDRICAL };
+
 struct Pattern {
     int32_t kind;
     Color a, b;
     Matrix transform = identity_4x4();
+    int32_t uv_mapping = 0;              // TextureMap
+    std::vector<UVPattern> uv;           // TextureMap: 1; CubicMap: front, back, left, right, up, down
+    mutable std::shared_ptr<std::vector<rtc_uv_pattern>> uv_c;  // what rtc_pattern::uv borrows
     Pattern(int32_t k, Color a_, Color b_) : kind(k), a(a_), b(b_) {}
     void set_transformation(Matrix t) { transform = t; }
     rtc_pattern c() const {
         rtc_pattern p;
+        if (!uv.empty()) {
+            uv_c = std::make_shared<std::vector<rtc_uv_pattern>>();
+            for (const UVPattern& q : uv) {
+                rtc_uv_pattern r = q.u;
+                if (q.image) r.image_rgb = q.image->data();
+                uv_c->push_back(r);
+            }
+            check(rtc_texture_map_init(&p, uv_mapping, uv_c->data(), (uint32_t)uv_c->size(), transform.m));
+            return p;
+        }
         check(rtc_pattern_init(&p, kind, a.data(), b.data(), transform.m));
         return p;
+    }
+};
+struct TextureMap : Pattern {  // uv.rs:68-76
+    TextureMap(UVPattern uv_pattern, UVMapping mapping) : Pattern(RTC_PATTERN_TEXTURE_MAP, black(), black()) {
+        uv_mapping = (int32_t)mapping;
+        uv.push_back(std::move(uv_pattern));
+    }
+};
+struct CubicMap : Pattern {  // uv.rs:207-231
+    CubicMap(UVPattern front, UVPattern back, UVPattern left, UVPattern right, UVPattern up, UVPattern down)
+        : Pattern(RTC_PATTERN_CUBE_MAP, black(), black()) {
+        uv = {std::move(front), std::move(back), std::move(left), std::move(right), std::move(up), std::move(down)};
     }
 };
 struct Stripes : Pattern {   // stripes.rs:17-31 (default: white, black)
@@ -360,6 +407,30 @@ struct Canvas {
         return s;
     }
 };
+inline Canvas canvas_from_ppm(const std::string& text) {  // canvas.rs:120-197
+    uint32_t w = 0, h = 0;
+    float* rgb = nullptr;
+    check(rtc_canvas_from_ppm(text.data(), text.size(), &w, &h, &rgb));
+    Canvas c(w, h);
+    std::memcpy(c.data.data(), rgb, c.data.size() * sizeof(float));
+    rtc_free(rgb);
+    return c;
+}
+inline UVPattern UVImage(const Canvas& canvas) {  // uv.rs:351-355
+    UVPattern p;
+    p.u.kind = RTC_UV_IMAGE;
+    p.u.image_width = (uint32_t)canvas.width, p.u.image_height = (uint32_t)canvas.height;
+    p.image = std::make_shared<std::vector<float>>(canvas.data);
+    return p;
+}
+inline Pattern align_check_cubic_map() {  // get_align_check_cubic_map_pattern, uv.rs:321-338
+    const Color white_{1, 1, 1}, red_{1, 0, 0}, yellow_{1, 1, 0}, green_{0, 1, 0}, cyan_{0, 1, 1}, blue_{0, 0, 1},
+        purple_{1, 0, 1}, brown_{1, 0.5f, 0};
+    UVPattern left = AlignCheck(yellow_, cyan_, red_, blue_, brown_), front = AlignCheck(cyan_, red_, yellow_, brown_, green_);
+    UVPattern right = AlignCheck(red_, yellow_, purple_, green_, white_), back = AlignCheck(green_, purple_, cyan_, white_, blue_);
+    UVPattern up = AlignCheck(brown_, cyan_, purple_, red_, yellow_), down = AlignCheck(purple_, brown_, green_, blue_, white_);
+    return CubicMap(front, back, left, right, up, down);
+}
 
 // ---- camera.rs ------------------------------------------------------------------------------------
 struct Camera {

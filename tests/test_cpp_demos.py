@@ -23,7 +23,7 @@ def built():
 
 
 def test_demos_build_and_refuse_to_run_without_gpu(built):
-    for name in ("soft_shadows", "first_scene", "first_plane", "first_patterns", "reflect_refract", "hexagons"):
+    for name in ("soft_shadows", "first_scene", "first_plane", "first_patterns", "reflect_refract", "hexagons", "first_textures"):
         assert os.access(os.path.join(built, name), os.X_OK)
     if P.device_count() == 0:
         p = subprocess.run([os.path.join(built, "first_plane"), "8x8"], capture_output=True, text=True)
@@ -40,3 +40,18 @@ def test_demo_stdout_is_the_oracles_ppm(built, name, size):
     world, camera, depth = getattr(scenes, name)(*size)
     img, _ = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=8)
     assert p.stdout == O.to_ppm(img) + b"\n"
+
+
+@pytest.mark.gpu
+def test_first_textures_demo_reads_its_image_from_a_ppm_file(built, tmp_path):
+    """first_textures.rs takes the earth map as a P3 file on its command line; so does the C++ counterpart."""
+    text = scenes.synthetic_ppm(96, 48, seed=5)
+    path = tmp_path / "earth.ppm"
+    path.write_text(text)
+    p = subprocess.run([os.path.join(built, "first_textures"), str(path), "120x60"], capture_output=True)
+    assert p.returncode == 0, p.stderr
+    world, camera, depth = scenes.first_textures(120, 60, earth_ppm=text)
+    img, _ = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=8)
+    assert p.stdout == O.to_ppm(img) + b"\n"
+    bad = subprocess.run([os.path.join(built, "first_textures"), str(tmp_path / "missing.ppm")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "cannot open" in bad.stderr
