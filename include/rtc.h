@@ -262,6 +262,11 @@ rtc_status rtc_camera_new(uint32_t width, uint32_t height, float field_of_view, 
                           rtc_camera* out);                                               /* camera.rs:23-56 */
 void rtc_ray_for_pixel(const rtc_camera* c, uint32_t x, uint32_t y, float origin[4], float direction[4]); /* camera.rs:60-74 */
 
+/* Runs the checks and the flattening rtc_ctx_set_scene performs (shape / pattern kinds, affine transforms, group
+ * nesting, light and camera sanity), without touching a device: RTC_OK, or the status rtc_ctx_set_scene would
+ * return with its message in rtc_last_error().  camera may be NULL. */
+rtc_status rtc_scene_validate(const rtc_scene* scene, const rtc_camera* camera);
+
 /* ------------------------------------------------------------------------
  * Device path.  Every function below needs a gfx950 GPU and fails with
  * RTC_ERR_NO_DEVICE otherwise.

@@ -124,6 +124,7 @@ SIGNATURES = {
     "rtc_ray_for_pixel": (None, [C.POINTER(rtc_camera), C.c_uint32, C.c_uint32, FP, FP]),
     "rtc_render": (C.c_int, [C.POINTER(rtc_scene), C.POINTER(rtc_camera), C.c_int32, C.c_int32, FP,
                              C.POINTER(rtc_stats)]),
+    "rtc_scene_validate": (C.c_int, [C.POINTER(rtc_scene), C.POINTER(rtc_camera)]),
     "rtc_ctx_create": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)]),
     "rtc_ctx_destroy": (None, [C.c_void_p]),
     "rtc_ctx_set_scene": (C.c_int, [C.c_void_p, C.POINTER(rtc_scene), C.POINTER(rtc_camera)]),

@@ -743,6 +743,11 @@ class World:
     def _c(self):
         return _CScene(self)
 
+    def validate(self, camera=None):
+        """rtc_scene_validate: the checks rtc_ctx_set_scene would make, without a GPU (raises RtcError)."""
+        cs = self._c()
+        L.check(L.lib().rtc_scene_validate(C.byref(cs.scene), C.byref(camera._cam) if camera is not None else None))
+
     def color_at(self, origins, directions, depth, device=0):
         """World::color_at for a batch of rays (world.rs:88-101); (n,4),(n,4) -> (n,3)."""
         o = np.ascontiguousarray(np.asarray(origins, dtype=f32).reshape(-1, 4))

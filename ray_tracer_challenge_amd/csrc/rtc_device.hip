@@ -531,6 +531,13 @@ extern "C" {
 
 int32_t rtc_device_count(void) { return usable_devices(); }
 
+rtc_status rtc_scene_validate(const rtc_scene* scene, const rtc_camera* camera) {
+    SceneHdr hdr;
+    std::vector<float4> soa;
+    std::vector<float> texels;
+    return flatten(scene, camera, &hdr, &soa, &texels);
+}
+
 rtc_status rtc_ctx_create(int32_t device, rtc_ctx** out) {
     if (!out) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_create: out is NULL");
     int n = usable_devices();

@@ -195,3 +195,40 @@ def test_no_gpu_means_error_not_fallback():
     with pytest.raises(P.RtcError) as e:
         camera.render(world, depth)
     assert e.value.status == L.RTC_ERR_NO_DEVICE
+
+
+def test_scene_validation_without_gpu():
+    """rtc_scene_validate runs the flattening and its checks on the host: every shipped scene passes, and the
+    things the device path refuses are refused here with the same status."""
+    import ray_tracer_challenge_amd as P
+    for name in ("soft_shadows", "first_scene", "shapes_medley", "patterns_medley", "reflect_refract", "hexagons", "groups_medley",
+                 "grouped_grid", "mesh", "first_textures", "skybox", "sphere_grid"):
+        world, camera, _ = getattr(scenes, name)(64, 48)
+        world.validate(camera)
+    world, camera, _ = scenes.hexagons(16, 8)
+    cs = world._c()
+
+    def status():
+        return L.lib().rtc_scene_validate(C.byref(cs.scene), C.byref(camera._cam))
+    assert status() == L.RTC_OK
+    cs.groups[1].n_objects = 13          # side 0 sticks out of the hexagon
+    assert status() == L.RTC_ERR_INVALID_ARG and b"nest" in L.lib().rtc_last_error()
+    cs.groups[1].n_objects = 2
+    cs.groups[0].first_object = 2        # not pre-order any more
+    assert status() == L.RTC_ERR_INVALID_ARG
+    cs.groups[0].first_object = 1
+    cs.groups[6].first_object = 40       # outside the object list
+    assert status() == L.RTC_ERR_INVALID_ARG
+    cs.groups[6].first_object = 11
+    assert status() == L.RTC_OK
+    proj = np.eye(4, dtype=f32)
+    proj[3, 2] = 0.5
+    light = P.PointLight(P.point(0, 0, -5), P.color(1, 1, 1))
+    for bad, code in ((P.World([P.Sphere(proj)], light), L.RTC_ERR_UNSUPPORTED),
+                      (P.World([P.Sphere(None, P.Material(pattern=P.Stripes(transform=proj)))], light), L.RTC_ERR_UNSUPPORTED),
+                      (P.World([P.Sphere()], None), L.RTC_ERR_NO_LIGHT),
+                      (P.World([P.Sphere(None, P.Material(pattern=P.Pattern(L.RTC_PATTERN_CUBE_MAP, uv=[P.UVCheckers()] * 5)))], light),
+                       L.RTC_ERR_UNSUPPORTED)):
+        with pytest.raises(P.RtcError) as e:
+            bad.validate()
+        assert e.value.status == code
