@@ -155,6 +155,44 @@ def main():
     elapsed = float(t.item())
     rays, shaded, pixels, culled = (int(v) for v in counts.tolist())
 
+    # N > 1, informational: the same K frames delivered to rank 0 as the bytes Canvas::to_ppm would print (device
+    # scale_color, canvas.rs:39-43) -- a quarter of the xGMI traffic of the f32 Canvas rows that `value` is measured
+    # with.  Never fatal: a failure is reported in the field instead.
+    wire = None
+    if world_size > 1 and args.steps > 0:
+        try:
+            gather8 = BandGather(camera.height, camera.width, 3, torch.uint8, device, rank, world_size)
+            scratch = [torch.empty((renderer.rows(part), camera.width, 3), dtype=torch.float32, device=device) for _ in range(2)]
+
+            def run8(n_steps):
+                img8 = None
+                for i in range(n_steps):
+                    slot = i % 2
+                    renderer.render(depth, out=scratch[slot], part=part)
+                    renderer.quantize(scratch[slot], out=gather8.local_view(slot))
+                    gather8.start(slot)
+                    if i > 0:
+                        img8 = gather8.finish((i - 1) % 2)
+                return gather8.finish((n_steps - 1) % 2) if n_steps > 0 else img8
+            run8(min(args.warmup, 2))
+            fence()
+            renderer.stats()
+            t1 = time.perf_counter()
+            img8 = run8(args.steps)
+            fence()
+            e8 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+            dist.all_reduce(e8, op=dist.ReduceOp.MAX)
+            renderer.stats()
+            ok8 = None
+            if rank == 0 and image is not None and img8 is not None:
+                ok8 = bool(torch.equal(img8, renderer.quantize(image.contiguous())))  # the gathered bytes == bytes of the gathered f32 frame
+            wire = {"encoding": "u8 (scale_color on the device)", "ms_per_step": round(float(e8.item()) / args.steps * 1e3, 4),
+                    "value": round(rays / (float(e8.item()) / args.steps) / 1e6, 2), "unit": "Mrays/s",
+                    "gathered_bytes_per_step": int(camera.height * camera.width * 3 * (world_size - 1) // world_size),
+                    "equals_quantised_f32_frame": ok8}
+        except Exception as exc:  # noqa: BLE001
+            wire = {"error": repr(exc)[:200]}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         n_obj = len(world._c().leaves)  # leaf shapes (GroupShapes flattened)
@@ -199,6 +237,13 @@ def main():
             "valu": valu_view(tmeta, st["kernel_ms"]),
             "parity_check": verify,
         }
+        if world_size > 1:
+            # `value` gathers the f32 Canvas rows (12 B / pixel) to rank 0 over xGMI: one link per peer, so the step is
+            # max(render, rows_of_one_peer / link rate).  Render and transport separately:
+            line["multi_gpu"] = {"gather": "f32 Canvas rows to rank 0, double-buffered (frame i's gather overlaps frame i+1's render)",
+                                 "render_kernel_ms_max_over_ranks": round(float(kern.item()), 4),
+                                 "gathered_bytes_per_step": int(camera.height * camera.width * 12 * (world_size - 1) // world_size),
+                                 "wire_format_gather": wire}
         if args.cpu_seconds > 0 and world_size == 1:
             line["cpu_baseline"] = cpu_baseline(world, camera, depth, args.cpu_seconds)
         elif world_size > 1:

@@ -85,9 +85,11 @@ class Renderer:
                                        C.byref(n), C.c_void_p(s.cuda_stream)))
         return text[: n.value].cpu().numpy().tobytes()
 
-    def quantize(self, rgb, stream=None):
+    def quantize(self, rgb, stream=None, out=None):
         """canvas.rs:39-43 scale_color on the device: f32 tensor -> u8 tensor of the same shape."""
-        out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
+        if out is None:
+            out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
+        assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() == rgb.numel()
         s = torch.cuda.current_stream(self.device) if stream is None else stream
         L.check(L.lib().rtc_ctx_quantize(self._ctx, C.c_void_p(rgb.data_ptr()), rgb.numel(),
                                          C.c_void_p(out.data_ptr()), C.c_void_p(s.cuda_stream)))
