@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Kernel time of every BASELINE configuration and demo scene (development / documentation tool)."""
+import sys, os, hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ray_tracer_challenge_amd import scenes
+from ray_tracer_challenge_amd.renderer import Renderer
+CASES = [("C1 soft_shadows 1000x400", "soft_shadows", (1000, 400)), ("C2 single_sphere 1024^2", "single_sphere", (1024, 1024)),
+         ("C3 soft_shadows 4096^2", "soft_shadows", (4096, 4096)), ("C4 glass_and_mirror 4096^2", "glass_and_mirror", (4096, 4096)),
+         ("C5 sphere_grid 8192^2", "sphere_grid", (8192, 8192)), ("first_scene 4096x2048", "first_scene", (4096, 2048)),
+         ("first_plane 4096x2048", "first_plane", (4096, 2048)), ("first_patterns 4096x2048", "first_patterns", (4096, 2048)),
+         ("reflect_refract 4096x2048", "reflect_refract", (4096, 2048)), ("hexagons 4096x2048", "hexagons", (4096, 2048)),
+         ("first_textures 4096x2048", "first_textures", (4096, 2048)), ("skybox 4096x2048", "skybox", (4096, 2048)),
+         ("grouped_grid 4096^2", "grouped_grid", (4096, 4096)), ("mesh 2048^2", "mesh", (2048, 2048))]
+for label, name, size in CASES:
+    world, camera, depth = getattr(scenes, name)(*size)
+    r = Renderer(world, camera, device=0); out = r.alloc()
+    for _ in range(2): r.render(depth, out=out)
+    r.stats()
+    for _ in range(5): r.render(depth, out=out)
+    st = r.stats()
+    print("| %s | %s | %.3f | %d | %.1f | %.2f |" % (label, r.kernel_name, st["kernel_ms"], st["rays"], st["rays"] / st["kernel_ms"] / 1e6,
+                                                  st["pixels"] / st["kernel_ms"] / 1e6), flush=True)
+    r.close()
