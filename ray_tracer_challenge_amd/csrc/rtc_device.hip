@@ -256,14 +256,19 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
                     return fail(RTC_ERR_INVALID_ARG, "group %u: objects [%u, %u) do not nest inside the enclosing group / the world",
                                 gi, g.first_object, (unsigned)end);
                 open.push_back({(uint32_t)end, trav.size() / 2});
+                float big = 0.0f;  // pruning slack: 1e-3 of the largest |coordinate| (NaN-propagating on purpose)
+                for (int a = 0; a < 3; a++) {
+                    const float lo = std::fabs(g.bounds_min[a]), hi = std::fabs(g.bounds_max[a]);
+                    big = (lo != lo || hi != hi) ? NAN : std::fmax(big, std::fmax(lo, hi));
+                }
                 trav.push_back(make_float4(g.bounds_min[0], g.bounds_min[1], g.bounds_min[2], 0.0f));
-                trav.push_back(make_float4(g.bounds_max[0], g.bounds_max[1], g.bounds_max[2], as_f(TRAV_GROUP)));
+                trav.push_back(make_float4(g.bounds_max[0], g.bounds_max[1], g.bounds_max[2], 1e-3f * big));
                 any = true;
                 gi++;
             }
             if (p < n) {
                 trav.push_back(make_float4(0.0f, 0.0f, 0.0f, as_f(p)));
-                trav.push_back(make_float4(0.0f, 0.0f, 0.0f, as_f(TRAV_LEAF)));
+                trav.push_back(make_float4(0.0f, 0.0f, 0.0f, TRAV_LEAF_TAG));
             }
         }
         if (gi != scene->n_groups)
@@ -328,6 +333,9 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     } else if (l.kind != RTC_LIGHT_POINT) {
         return fail(RTC_ERR_UNSUPPORTED, "light kind %d", l.kind);
     }
+    hdr->all_cast = 1;
+    for (uint32_t i = 0; i < n; i++)
+        if (!scene->objects[i].casts_shadow) hdr->all_cast = 0;
     hdr->uvrec_off = (uint32_t)soa->size();
     soa->insert(soa->end(), uvrec.begin(), uvrec.end());
     if (cam) {

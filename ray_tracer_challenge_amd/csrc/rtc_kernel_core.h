@@ -483,6 +483,7 @@ struct SceneHdr {
     uint32_t n_trav;        // entries in SceneSoA::trav; 0: the world is a flat object list
     float light_y_lo, light_y_hi;  // world-space y range of the area light's sample points, widened (light-cone culling)
     uint32_t uvrec_off;            // where SceneSoA::uvrec starts inside the scene buffer, in float4 units (host use)
+    uint32_t all_cast;             // every object casts shadows: a shadow ray may stop at its first hit before the light
 };
 
 // Structure-of-arrays scene records in HBM: 4 float4 of geometry (64 B) and
@@ -507,8 +508,9 @@ struct SceneSoA {
     const float4* __restrict__ pat;
     // Worlds with GroupShapes (shape/group.rs): the object records are the tree's leaves in depth-first order and
     // `trav` is that traversal written out, two float4 per entry:
-    //   group: { bounds.min.xyz, skip }, { bounds.max.xyz, TRAV_GROUP }   skip = entry index after the group's subtree
-    //   leaf : { 0, 0, 0, object index }, { 0, 0, 0, TRAV_LEAF }
+    //   group: { bounds.min.xyz, skip }, { bounds.max.xyz, slack }   skip = entry index after the group's subtree,
+    //          slack = 1e-3 * the box's largest |coordinate| (pruning margin, see for_each_object)
+    //   leaf : { 0, 0, 0, object index }, { 0, 0, 0, -1 }
     const float4* __restrict__ trav;
     // Triangles (shape/triangle.rs:9-17), 3 records per object, read only for RTC_TRIANGLE objects:
     //   { p1.xyz, normal.x }, { e1.xyz, normal.y }, { e2.xyz, normal.z }
@@ -526,7 +528,7 @@ struct SceneSoA {
     const float4* __restrict__ uvrec;
     const float* __restrict__ texels;
 };
-enum : uint32_t { TRAV_GROUP = 0u, TRAV_LEAF = 1u };
+constexpr float TRAV_LEAF_TAG = -1.0f;  // e1.w of a leaf entry; a group's e1.w is its pruning slack (>= 0)
 enum : uint32_t {
     SHAPE_KIND_MASK = 0xffu,
     SHAPE_NONE = 0xffu,      // padding record: never intersects (arrays are padded to a multiple of 8)
@@ -830,9 +832,10 @@ constexpr uint32_t CNT_SHADED_MASK = 0xfffu, CNT_CULLED_SHIFT = 12u;
 
 // cube.rs:90-129 aabb_intersection(..).is_some() for a world-space box: `inv` are the reciprocals Ray::new keeps
 // (ray.rs:16).  fminf / fmaxf return the non-NaN operand, as Rust's f32::min / max do.
-DI bool aabb_hit(V3 o, V3 inv, float4 mn, float4 mx) {
+DI bool aabb_hit(V3 o, V3 inv, float4 mn, float4 mx, float& tmin) {
     float x0 = (mn.x - o.x) * inv.x, x1 = (mx.x - o.x) * inv.x;
-    float tmin = fminf(x0, x1), tmax = fmaxf(x0, x1);
+    tmin = fminf(x0, x1);
+    float tmax = fmaxf(x0, x1);
     float y0 = (mn.y - o.y) * inv.y, y1 = (mx.y - o.y) * inv.y;
     tmin = fmaxf(tmin, fminf(y0, y1));
     tmax = fminf(tmax, fmaxf(y0, y1));
@@ -842,13 +845,17 @@ DI bool aabb_hit(V3 o, V3 inv, float4 mn, float4 mx) {
     return tmax >= fmaxf(0.0f, tmin);
 }
 // The world-space ray as GroupShape::local_intersect sees it (group.rs:115-133: groups do not transform the ray).
+// `limit` (tree walks only): the caller has no use for intersections beyond this ray parameter -- the nearest hit so
+// far, or the distance to the light for a shadow ray -- so a group whose box the ray ENTERS later than that need not
+// be opened (see for_each_object); -inf: this lane needs nothing more at all.  +inf switches the pruning off.
 struct WorldRay {
     V3 o, inv;
+    float limit;
 };
 template <int NOBJ>
 DI WorldRay world_ray(V3 o, V3 d) {
-    if constexpr (NOBJ < 0) return {o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z)};
-    else return {o, o};  // unused
+    if constexpr (NOBJ < 0) return {o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), RTC_INF};
+    else return {o, o, RTC_INF};  // unused
 }
 
 // Applies `body(i)` to every object the reference's World::intersect would reach.  NOBJ > 0: the scene has at
@@ -859,17 +866,25 @@ DI WorldRay world_ray(V3 o, V3 d) {
 // wave jumps over a subtree only when no lane is inside it.  Every lane therefore visits exactly the leaves, in
 // exactly the order, the reference's recursive child loop visits for its ray.
 template <int NOBJ, class F>
-DI void for_each_object(const SceneHdr& H, const SceneSoA& S, const WorldRay& wr, F&& body) {
+DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& body) {
     if constexpr (NOBJ < 0) {
+        // Pruning by wr.limit cannot change what the caller computes: everything a group contributes lies inside its
+        // box up to rounding (bounds are hulls of transformed corners; a hit satisfies the shape's equation under the
+        // rounded inverse transform: a relative ~1e-6 of the coordinates), the computed entry parameter tmin is within
+        // 3 ulp of the exact one, and the group is only left closed when tmin exceeds the limit by 1e-3 of the box's
+        // largest coordinate (its `slack`, stored with the entry; infinite or NaN bounds never prune) plus 1e-4 of
+        // the limit -- three orders of magnitude more than those errors.
         uint32_t resume = 0;  // this lane ignores entries below `resume`
         for (uint32_t k = 0; k < H.n_trav;) {
             const float4 e0 = load_uniform(S.trav, 2u * k), e1 = load_uniform(S.trav, 2u * k + 1u);
-            const bool active = k >= resume;
-            if (__float_as_uint(e1.w) == TRAV_GROUP) {
+            const bool active = k >= resume && wr.limit > -RTC_INF;
+            if (!(e1.w < 0.0f)) {  // a group: e1.w is its slack (>= 0, inf or NaN); leaves carry -1
                 const uint32_t skip = __float_as_uint(e0.w);
                 bool inside = false;
                 if (active) {
-                    inside = aabb_hit(wr.o, wr.inv, e0, e1);
+                    float tmin;
+                    inside = aabb_hit(wr.o, wr.inv, e0, e1, tmin);
+                    if (inside && tmin > wr.limit + (e1.w + 1e-4f * fabsf(wr.limit))) inside = false;  // nothing of interest in there
                     if (!inside) resume = skip;
                 }
                 k = __any(inside) ? k + 1u : skip;
@@ -912,10 +927,14 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, const WorldRay& wr
 // without materialising or sorting the list: the hit is the first entry, in
 // (object order, push order), of the minimum among distances >= 0 -- which is
 // what a stable sort followed by a first-minimum scan selects.
+// Tree walks only: `t_max` -- hits beyond it do not matter to the caller (a shadow ray's distance to the light);
+// `any_hit` -- the caller only asks whether there is a hit below t_max (a shadow ray in a world where every object
+// casts shadows: the nearest hit is then a caster whichever it is), so a lane stops at its first such hit.
 template <int NOBJ>
-DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d) {
+DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, float t_max = RTC_INF, bool any_hit = false) {
     Hit best = {0.0f, -1};
-    const WorldRay wr = world_ray<NOBJ>(o, d);
+    WorldRay wr = world_ray<NOBJ>(o, d);
+    wr.limit = t_max;
     for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) {
         Obj ob = load_obj_static<NOBJ <= 0>(S, i);
         if ((ob.bits & SHAPE_KIND_MASK) == SHAPE_NONE) return;  // padding record (wave-uniform)
@@ -925,6 +944,7 @@ DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d) {
             if (t >= 0.0f && (best.obj < 0 || t < best.t)) {
                 best.t = t;
                 best.obj = (int)i;
+                if constexpr (NOBJ < 0) wr.limit = (any_hit && t < t_max) ? -RTC_INF : fminf(wr.limit, t);
             }
         });
     });
@@ -938,7 +958,7 @@ DI bool is_shadowed(const SceneHdr& H, const SceneSoA& S, V3 light_position, V3 
     float distance = mag3(v);
     V3 direction = norm3(v);
     cnt.rays++;
-    Hit h = nearest_hit<NOBJ>(H, S, p, direction);
+    Hit h = nearest_hit<NOBJ>(H, S, p, direction, distance, H.all_cast != 0u);
     if (h.obj < 0) return false;
     bool casts = (__float_as_uint(S.geo[h.obj].w) & SHAPE_CASTS) != 0;
     return casts && h.t < distance;
@@ -1008,7 +1028,7 @@ struct ShadowPre {
 template <int NOBJ>
 DI void shadow_prepare(const SceneHdr& H, const SceneSoA& S, V3 p, ShadowPre* pre) {
     static_assert(NOBJ > 0, "flat unrolled scenes only");
-    const WorldRay wr = world_ray<NOBJ>(p, p);
+    WorldRay wr = world_ray<NOBJ>(p, p);
     for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) {
         Obj ob = load_obj_static<NOBJ <= 0>(S, i);
         pre[i].o = obj_point(ob, p);
@@ -1038,7 +1058,7 @@ DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* p
     V3 dir;
     normalize_exact(v, distance, dir);  // == mag3(v), norm3(v)
     cnt.rays++;
-    const WorldRay wr = world_ray<NOBJ>(p, dir);  // unused: NOBJ > 0 here
+    WorldRay wr = world_ray<NOBJ>(p, dir);  // unused: NOBJ > 0 here
     auto object_ts = [&](uint32_t i, const float4 g, uint32_t bits, auto&& f) {
         V3 pd;
         if (SIMPLE || (bits & SHAPE_DIAG)) {
@@ -1401,7 +1421,8 @@ DI V3 phong(const SceneHdr& H, V3 material_color, float4 ma, float4 mb, V3 p, V3
 // (t_max_negative, index); toggling the hit object then gives n2.
 template <int NOBJ>
 DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int hit_obj, float& n1, float& n2) {
-    const WorldRay wr = world_ray<NOBJ>(o, d);
+    WorldRay wr = world_ray<NOBJ>(o, d);
+    wr.limit = 0.0f;             // only intersections behind the origin (t < 0) matter here
     float t1 = 0.0f, t2 = 0.0f;  // best and runner-up container keys
     int c1 = -1, c2 = -1;
     bool hit_inside = false;
