@@ -51,7 +51,7 @@ def _random_world(rng, n_objects, jitter):
 JITTERS = [("constant", 0.0), ("constant", 1.0), ("constant", 0.5), ("hashed", 99), ("constant", 1.5), ("constant", -0.25)]
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(30))
 def test_intensity_at_matches_oracle_on_random_scenes(seed):
     """Light::intensity_at (the culled sample loop) for 1500 points per scene: on and near object surfaces, in the
     open, behind objects -- every value must be the oracle's, exactly."""
@@ -78,7 +78,7 @@ def test_intensity_at_matches_oracle_on_random_scenes(seed):
         assert got[i] == exp, (seed, jitter, i, pts[i], got[i], exp)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(20))
 def test_random_area_light_scenes_render_like_the_oracle(seed):
     rng = np.random.default_rng(5000 + seed)
     jitter = JITTERS[seed % 4]
@@ -107,3 +107,28 @@ def test_cull_statistics_are_reported():
     img, rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=8)
     H.assert_images_equal(canvas.data, img, "soft_shadows 256x128")
     assert st["rays"] == rays
+
+
+@pytest.mark.parametrize("jitter", [("hashed", 3), ("constant", 0.0), ("constant", 1.0)])
+def test_dense_sweep_across_shadow_edges(jitter):
+    """Shade points in fine steps along lines that run from open floor, through the penumbra, under the objects and
+    out again -- so every wave-sized run of points crosses from 'culled' to 'tested' somewhere near the objects'
+    silhouettes as seen from the light -- for a sphere, a squashed sphere, a cube and a second, non-casting sphere."""
+    floor = P.Plane(None, P.Material())
+    ball = P.Sphere(P.translation(0.0, 1.0, 0.0), P.Material())
+    disc = P.Sphere(P.chain(P.translation(2.5, 0.6, 0.3), P.scaling(1.2, 0.15, 0.8)), P.Material())
+    box = P.Cube(P.chain(P.translation(-2.6, 0.5, -0.2), P.scaling(0.5, 0.5, 0.7)), P.Material())
+    ghost = P.Sphere(P.chain(P.translation(0.8, 2.2, 0.1), P.scaling(0.4, 0.4, 0.4)), P.Material(), casts_shadow=False)
+    light = P.RectangleLight(P.color(1, 1, 1), P.point(-1.0, 5.0, -1.0), P.vector(2, 0, 0), 4, P.vector(0, 0.5, 2), 3, jitter)
+    for objs in ([floor, ball, disc, box], [floor, ball, ghost, box], [ball, disc], [floor, disc, ghost]):
+        world = P.World(objs, light)
+        ow = H.oracle_world(world)
+        xs = np.arange(-6.0, 6.0, 0.004, dtype=np.float64)
+        for z, y in ((0.0, 1.19e-3), (0.65, 1.19e-3), (-0.2, 0.3)):
+            pts = np.stack([xs, np.full_like(xs, y), np.full_like(xs, z), np.ones_like(xs)], axis=1).astype(f32)
+            got = world.intensity_at(pts)
+            for i in range(pts.shape[0]):
+                ow.set_pixel(i)
+                exp = ow.intensity_at(pts[i])
+                assert got[i] == exp, (jitter, len(objs), z, pts[i], got[i], exp)
+            assert 0.0 < got.mean() < 1.0 or len(objs) == 2
