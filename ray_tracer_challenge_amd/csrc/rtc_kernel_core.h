@@ -7,22 +7,27 @@
 //     kernels"): the per-object kind / flag words become compile-time constants, which removes the
 //     wave-uniform kind switches from the unrolled object loops (C3: 4.06 -> 3.13 ms, same bits).
 //
-// One wavefront lane per pixel, 8x8 pixel tiles per 64-lane wave.  The
-// flattened scene (structure-of-arrays float4 records, 64 B geometry + 48 B
-// material per object) lives in HBM; because every lane of a wave walks the
-// same object list, the records are fetched with wave-uniform addresses
-// (scalar loads -> SGPRs) and cost no vector registers or LDS bandwidth.
-// Recursion (reflected_color / refracted_color -> color_at) is an explicit
-// per-lane post-order stack, so that sums are formed in exactly the
-// reference's order.  No MFMA: the path is branchy scalar f32 arithmetic.
+// One wavefront lane per pixel, 8x8 pixel tiles per 64-lane wave.  The flattened scene (structure-of-arrays
+// float4 records, see SceneSoA) lives in HBM; because every lane of a wave walks the same object list -- or, for
+// worlds with GroupShapes, the same depth-first entry list, as a packet -- the records are fetched with
+// wave-uniform addresses (scalar loads -> SGPRs) and cost no vector registers or LDS bandwidth.  Recursion
+// (reflected_color / refracted_color -> color_at) is an explicit per-lane post-order stack, so that sums are
+// formed in exactly the reference's order.  No MFMA: the path is branchy scalar f32 arithmetic.
+//
+// Contents, in order: the libm restatements (powf, cosf, atanf / atan2f, acosf); the scene layout; shape
+// intersectors and normals (sphere, plane, cube, cylinder, cone, triangle); object loops and the group-tree
+// packet walk; is_shadowed and its area-light fast path (origin hoisting, caster-first passes, exact sqrt /
+// divide cores, light-cone culling); patterns and texture maps; phong, n1/n2, schlick; color_at; the render
+// kernel; then the ahead-of-time-only utility kernels (counter sum, quantiser, PPM formatter, batched entry points).
 //
 // Bit-exactness rules (see DESIGN.md "Arithmetic contract"):
-//   * whole file is compiled with -ffp-contract=off and the pragma below: the
-//     Rust reference never fuses a*b+c;
+//   * whole file is compiled with -ffp-contract=off and the pragma below: the Rust reference never fuses a*b+c;
 //   * every sum keeps the reference's association order;
 //   * '/' and sqrtf are the correctly rounded IEEE forms (hipcc default);
-//   * powf is a restatement of glibc 2.35's FMA powf (the routine a Linux
-//     build of the reference calls), in f64, not ocml's powf.
+//   * libm calls (powf, cos, atan2, acos) are restatements of glibc 2.35's routines -- the ones a Linux build of
+//     the reference calls -- not ocml's;
+//   * anything that skips work (shadow-ray culling, tree pruning, the plane shortcut) does so only where the
+//     skipped evaluation's outcome is known, with margins documented at the site.
 //
 #ifndef RTC_KERNEL_CORE_H
 #define RTC_KERNEL_CORE_H
