@@ -936,11 +936,13 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
 // `any_hit` -- the caller only asks whether there is a hit below t_max (a shadow ray in a world where every object
 // casts shadows: the nearest hit is then a caster whichever it is), so a lane stops at its first such hit.
 template <int NOBJ>
-DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, float t_max = RTC_INF, bool any_hit = false) {
+DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, float t_max = RTC_INF, bool any_hit = false,
+                   uint32_t skip = 0u) {
     Hit best = {0.0f, -1};
     WorldRay wr = world_ray<NOBJ>(o, d);
     wr.limit = t_max;
     for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) {
+        if (i < 32u && ((skip >> i) & 1u)) return;  // light-cone culled for this shade point (wave-uniform)
         Obj ob = load_obj_static<NOBJ <= 0>(S, i);
         if ((ob.bits & SHAPE_KIND_MASK) == SHAPE_NONE) return;  // padding record (wave-uniform)
         V3 po = obj_point(ob, o);
@@ -958,12 +960,12 @@ DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, float t_max
 
 // world.rs:104-119
 template <int NOBJ>
-DI bool is_shadowed(const SceneHdr& H, const SceneSoA& S, V3 light_position, V3 p, Counters& cnt) {
+DI bool is_shadowed(const SceneHdr& H, const SceneSoA& S, V3 light_position, V3 p, Counters& cnt, uint32_t skip = 0u) {
     V3 v = light_position - p;
     float distance = mag3(v);
     V3 direction = norm3(v);
     cnt.rays++;
-    Hit h = nearest_hit<NOBJ>(H, S, p, direction, distance, H.all_cast != 0u);
+    Hit h = nearest_hit<NOBJ>(H, S, p, direction, distance, H.all_cast != 0u, skip);
     if (h.obj < 0) return false;
     bool casts = (__float_as_uint(S.geo[h.obj].w) & SHAPE_CASTS) != 0;
     return casts && h.t < distance;
@@ -1124,7 +1126,8 @@ DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* p
 // sphere / cube blown up by 10 % in radius, the cone of directions widened by 1e-3 in cosine, and it is only
 // trusted when the shade point is within 100 radii (beyond that the quadratic's cancellation error grows and
 // the object is simply kept).  Everything here is approximate arithmetic; NaNs fail every comparison and so
-// keep the object.  Scale+translate-only spheres, cubes and planes are handled, the rest is kept.
+// keep the object.  Spheres, cubes, bounded cylinders and planes under any affine transform are handled; cones,
+// unbounded cylinders and triangles are always kept.
 template <int NOBJ>
 DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p) {
     uint32_t mask = 0;
@@ -1132,42 +1135,55 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p) {
     // the samples stay inside the parallelogram only for jitter in [0, 1] (the hashed source draws from (0, 1])
     const bool hashed = spec_jitter_mode(H.jitter_mode) == RTC_JITTER_HASHED;
     if (!hashed && !(H.jitter_const >= 0.0f && H.jitter_const <= 1.0f)) return 0u;
-#pragma unroll
-    for (uint32_t i = 0; i < (uint32_t)NOBJ; i++) {
-        const float4 g = S.geo[i];
-        const uint32_t bits = spec_bits(i, __float_as_uint(g.w));
+    // a decision costs about as much as four or five ray-object tests: not worth it for a handful of samples
+    if (H.u_steps * H.v_steps < 8) return 0u;
+    // unrolled kernels: all NOBJ records; any-count loops and tree walks: up to 32 objects (the mask's width)
+    if (NOBJ <= 0 && H.n_objects > 31u) return 0u;
+    auto per_object = [&](uint32_t i) {
+        const Obj ob = load_obj_static<NOBJ <= 0>(S, i);
+        const uint32_t bits = ob.bits;
         const uint32_t kind = bits & SHAPE_KIND_MASK;
-        if (kind == SHAPE_NONE) continue;
-        if (!(bits & SHAPE_DIAG) || (kind != RTC_SPHERE && kind != RTC_CUBE && kind != RTC_PLANE)) {  // uniform
-            if (bits & SHAPE_CASTS) casters_left = true;
-            continue;
+        if (kind == SHAPE_NONE) return;
+        // Bounding sphere of the shape in its own space (centre = origin), inflated by 10 %.  Every intersection
+        // these kinds report lies on the shape.  (Not so for cones -- the near-parallel branch, cone.rs:99-107,
+        // returns a root of the unbounded double cone without a range check -- nor for unbounded cylinders;
+        // triangles are kept as well.)
+        float r2 = 0.0f;  // 0: keep
+        if (kind == RTC_SPHERE) r2 = 1.21f;
+        else if (kind == RTC_CUBE) r2 = 3.63f;
+        else if (kind == RTC_CYLINDER) {
+            const float hy = fmaxf(fabsf(ob.min_y()), fabsf(ob.max_y()));
+            if (hy < 1e6f) r2 = 1.21f * (1.0f + hy * hy);
         }
-        // the object-space shade point, as shadow_prepare computes it (same operations, same value)
-        const float4 tq = S.trn[i];
-        const V3 tr = v3(tq.x, tq.y, tq.z);
-        const V3 o = v3(g.x * p.x + tr.x, g.y * p.y + tr.y, g.z * p.z + tr.z);
+        if (kind != RTC_PLANE && !(r2 > 0.0f)) {  // wave-uniform
+            if (bits & SHAPE_CASTS) casters_left = true;
+            return;
+        }
+        // the object-space shade point, computed as the exact tests compute it (same function, same value)
+        const V3 o = obj_point(ob, p);
+        const float4 l0 = S.lcorn[3 * i], l1 = S.lcorn[3 * i + 1], l2 = S.lcorn[3 * i + 2];  // the light's corners, wave-uniform
+        auto corner = [&](int k) {
+            return k == 0 ? v3(l0.x, l0.y, l0.z) : k == 1 ? v3(l0.w, l1.x, l1.y) : k == 2 ? v3(l1.z, l1.w, l2.x) : v3(l2.y, l2.z, l2.w);
+        };
         bool cull;
         if (kind == RTC_PLANE) {
-            // plane.rs:45-56 gives no t >= 0 unless the object-space origin height o.y and the direction's d.y have
-            // strictly opposite signs.  d.y = g.y * (lp.y - p.y) / |lp - p| up to sign-preserving roundings, so if
-            // g.y * (lp.y - p.y) has o.y's sign (or is zero) for the whole y range of the light -- widened by far more
-            // than the sample points' rounding error --, every sample either runs parallel (rejected) or leaves the
+            // plane.rs:45-56 gives a t >= 0 only if the object-space origin height o.y and the direction's d.y have
+            // strictly opposite signs, and d.y is a positive multiple of L.y - o.y for the sample's object-space
+            // position L.  If every corner -- hence every sample -- is at least as far from the plane as o on o's own
+            // side (by a margin far above the rounding of either), every sample runs parallel (rejected) or leaves the
             // plane behind.  o.y is the very value the exact test uses.
-            const float a = g.y * (H.light_y_lo - p.y), b = g.y * (H.light_y_hi - p.y);
-            cull = (o.y > 0.0f && fminf(a, b) >= 0.0f) || (o.y < 0.0f && fmaxf(a, b) <= 0.0f);
+            const float lo = fminf(fminf(corner(0).y, corner(1).y), fminf(corner(2).y, corner(3).y));
+            const float hi = fmaxf(fmaxf(corner(0).y, corner(1).y), fmaxf(corner(2).y, corner(3).y));
+            const float m = 1e-4f * (fabsf(lo) + fabsf(hi) + fabsf(o.y));
+            cull = (o.y > 0.0f && lo - o.y >= m) || (o.y < 0.0f && hi - o.y <= -m);
         } else {
             // The rays fill the pyramid with apex o over the (object-space) parallelogram: the intersection of the four
-            // half-spaces through o bounded by its faces.  The inflated bounding sphere (centre = origin) lies outside
-            // as soon as ONE face plane separates it: signed distance of the origin beyond that face > radius.
+            // half-spaces through o bounded by its faces.  The inflated bounding sphere lies outside as soon as ONE
+            // face plane separates it: signed distance of the origin beyond that face > radius.
             // Unnormalised throughout: n.(-o) > R |n|  <=>  n.(-o) > 0 and (n.o)^2 > R^2 |n|^2.
-            const float r2 = kind == RTC_SPHERE ? 1.21f : 3.63f;  // (1.1 r)^2 of the unit sphere / the cube's circumsphere
             const float oo = o.x * o.x + o.y * o.y + o.z * o.z;
-            const float4 l0 = S.lcorn[3 * i], l1 = S.lcorn[3 * i + 1], l2 = S.lcorn[3 * i + 2];  // wave-uniform
-            auto edge = [&](int k) {  // object-space vector from the shade point to corner k
-                const V3 c = k == 0 ? v3(l0.x, l0.y, l0.z) : k == 1 ? v3(l0.w, l1.x, l1.y) : k == 2 ? v3(l1.z, l1.w, l2.x) : v3(l2.y, l2.z, l2.w);
-                return c - o;
-            };
-            const V3 m = edge(0) + edge(2);  // towards the parallelogram's centre: inside the pyramid
+            auto edge = [&](int k) { return corner(k) - o; };  // object-space vector from the shade point to corner k
+            const V3 m = edge(0) + edge(2);                    // towards the parallelogram's centre: inside the pyramid
             bool narrow = true, outside = false, leaving = true;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -1189,9 +1205,15 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p) {
         }
         if (__all(cull)) mask |= 1u << i;
         else if (bits & SHAPE_CASTS) casters_left = true;
+    };
+    if constexpr (NOBJ > 0) {
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)NOBJ; i++) per_object(i);
+    } else {
+        for (uint32_t i = 0; i < H.n_objects; i++) per_object(i);
     }
     // no shadow caster can be reached from this shade point: every sample is lit whatever else is in the way
-    // (world.rs:104-119 asks for the nearest hit to BE a caster), see is_shadowed_pre
+    // (world.rs:104-119 asks for the nearest hit to BE a caster), see intensity_at
     if (!casters_left) mask |= LIGHT_CULL_ALL_CASTERS;
     return mask;
 }
@@ -1227,19 +1249,16 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
     // every shadow ray of this shade point starts at p: do the origin-only work once per object
     constexpr bool PRE = NOBJ > 0;
     ShadowPre pre[PRE ? NOBJ : 1];
-    uint32_t skip = 0u;
-    if constexpr (PRE) {
-        skip = light_cull_mask<NOBJ>(H, S, p);  // before pre[] becomes live: the cull needs registers of its own
-        shadow_prepare<NOBJ>(H, S, p, pre);
-        if (skip & LIGHT_CULL_ALL_CASTERS) {
-            // wave-uniform: no shadow caster is reachable, so each of the u_steps * v_steps is_shadowed() calls answers
-            // "lit": total = 1.0 + ... + 1.0 = cells exactly (an integer below 2^24), and cells / cells = 1.0
-            const uint32_t cells = (uint32_t)(H.u_steps * H.v_steps);
-            cnt.rays += cells;
-            cnt.shaded += cells << CNT_CULLED_SHIFT;  // statistics: rays answered without an object test
-            return (float)cells / H.cells_f;
-        }
+    const uint32_t skip = light_cull_mask<NOBJ>(H, S, p);  // before pre[] becomes live: the cull needs registers of its own
+    if (skip & LIGHT_CULL_ALL_CASTERS) {
+        // wave-uniform: no shadow caster is reachable, so each of the u_steps * v_steps is_shadowed() calls answers
+        // "lit": total = 1.0 + ... + 1.0 = cells exactly (an integer below 2^24), and cells / cells = 1.0
+        const uint32_t cells = (uint32_t)(H.u_steps * H.v_steps);
+        cnt.rays += cells;
+        cnt.shaded += cells << CNT_CULLED_SHIFT;  // statistics: rays answered without an object test
+        return (float)cells / H.cells_f;
     }
+    if constexpr (PRE) shadow_prepare<NOBJ>(H, S, p, pre);
     float total = 0.0f;
     for (int v = 0; v < H.v_steps; v++) {
         for (int u = 0; u < H.u_steps; u++) {
@@ -1254,7 +1273,7 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
             V3 lp = corner + uvec * ((float)u + j1) + vvec * ((float)v + j2);
             bool blocked;
             if constexpr (PRE) blocked = is_shadowed_pre<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt, skip);
-            else blocked = is_shadowed<NOBJ>(H, S, lp, p, cnt);
+            else blocked = is_shadowed<NOBJ>(H, S, lp, p, cnt, skip & 0x7fffffffu);
             if (!blocked) total += 1.0f;
         }
     }

@@ -18,7 +18,7 @@ f32 = np.float32
 def _random_world(rng, n_objects, jitter):
     objs = []
     for k in range(n_objects):
-        kind = rng.choice(["sphere", "sphere", "cube", "plane"]) if k else "plane"
+        kind = rng.choice(["sphere", "sphere", "cube", "plane", "cylinder"]) if k else "plane"
         casts = bool(rng.random() < 0.8)
         scale = float(10.0 ** rng.uniform(-1.2, 0.5))
         pos = rng.uniform(-4, 4, 3)
@@ -32,6 +32,13 @@ def _random_world(rng, n_objects, jitter):
             if rng.random() < 0.15:
                 sx = -sx
             t = P.chain(P.translation(*pos), P.scaling(float(sx), float(sy), float(sz)))
+            if rng.random() < 0.4:  # the cull works in the object's own space under any affine transform
+                t = P.chain(t, P.rotation_z(float(rng.uniform(-3, 3))), P.rotation_x(float(rng.uniform(-3, 3))))
+            if kind == "cylinder":
+                lo = float(rng.uniform(-2, 0))
+                objs.append(P.Cylinder(t, P.Material(color=tuple(rng.uniform(0.2, 1, 3))), casts_shadow=casts, minimum_y=lo,
+                                       maximum_y=lo + float(rng.uniform(0.2, 3)), closed=bool(rng.random() < 0.5)))
+                continue
             ctor = P.Sphere if kind == "sphere" else P.Cube
             transparent = rng.random() < 0.2
             objs.append(ctor(t, P.Material(color=tuple(rng.uniform(0.2, 1, 3)), reflective=float(rng.choice([0.0, 0.3])),
@@ -43,8 +50,9 @@ def _random_world(rng, n_objects, jitter):
         axes = [np.array([rng.uniform(0.3, 3), 0, 0]), np.array([0, rng.choice([0.0, rng.uniform(0.3, 3)]), rng.uniform(0.3, 3)])]
     u = axes[0] / max(np.linalg.norm(axes[0]), 1e-6) * rng.uniform(0.3, 3)
     v = axes[1] / max(np.linalg.norm(axes[1]), 1e-6) * rng.uniform(0.3, 3)
-    light = P.RectangleLight(P.color(1.2, 1.1, 1.0), P.point(*corner), P.vector(*u), int(rng.integers(1, 5)), P.vector(*v),
-                             int(rng.integers(1, 5)), jitter)
+    # 3..5 steps each way: the cull is only attempted for lights of >= 8 cells
+    light = P.RectangleLight(P.color(1.2, 1.1, 1.0), P.point(*corner), P.vector(*u), int(rng.integers(3, 6)), P.vector(*v),
+                             int(rng.integers(3, 6)), jitter)
     return P.World(objs, light)
 
 
@@ -82,7 +90,9 @@ def test_intensity_at_matches_oracle_on_random_scenes(seed):
 def test_random_area_light_scenes_render_like_the_oracle(seed):
     rng = np.random.default_rng(5000 + seed)
     jitter = JITTERS[seed % 4]
-    world = _random_world(rng, int(rng.integers(2, 9)), jitter)
+    # seeds 14..19: 10-24 objects, i.e. the any-count loop (and its like-objects specialisation does not apply)
+    n_objects = int(rng.integers(10, 25)) if seed >= 14 else int(rng.integers(2, 9))
+    world = _random_world(rng, n_objects, jitter)
     cam = P.Camera(72, 56, scenes.PI / f32(2.5),
                    P.view_transform(P.point(*rng.uniform(-6, 6, 3)) + np.array([0, 2, 0, 0], dtype=f32), P.point(0, 0.5, 0), P.vector(0, 1, 0)))
     for mode in ("0", "1"):
