@@ -1519,11 +1519,16 @@ struct LaneStash {
 };
 
 // One suspended shade_hit (world.rs:62-86) waiting for a child colour.
+// Split in two so that the common frame -- a mirror-like hit waiting for its reflection only -- moves 6 dwords
+// through scratch instead of 13: the refraction half is written and read only when there is a refraction child.
 struct Frame {
     V3 acc;       // surface colour, later surface + reflected[*R]
-    V3 ro, rd;    // pending refraction ray (under_point, direction)
-    float reflective, transparency, R;
+    float reflective, R;
     uint32_t flags;  // bit0: waiting for the refraction child; bit1: has refraction child; bit2: Schlick
+};
+struct FrameRefr {
+    V3 ro, rd;    // pending refraction ray (under_point, direction)
+    float transparency;
 };
 enum { F_WAIT_REFR = 1, F_HAS_REFR = 2, F_SCHLICK = 4 };
 
@@ -1535,6 +1540,7 @@ template <int NOBJ, bool SIMPLE>
 DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint32_t pixel, Counters& cnt,
                const LaneStash stash) {
     Frame stack[RTC_MAX_DEPTH];
+    FrameRefr stack_refr[RTC_MAX_DEPTH];
     int sp = 0;
     int rem = depth;
     uint32_t path = 1;
@@ -1633,11 +1639,15 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
             } else {
                 Frame f;
                 f.reflective = reflective;
-                f.transparency = transparency;
                 f.R = R;
                 f.flags = (has_refr ? F_HAS_REFR : 0) | (use_schlick ? F_SCHLICK : 0);
-                f.ro = under_point;
-                f.rd = rdir;
+                if (has_refr) {
+                    FrameRefr fr;
+                    fr.ro = under_point;
+                    fr.rd = rdir;
+                    fr.transparency = transparency;
+                    stack_refr[sp] = fr;
+                }
                 if (has_refl) {
                     f.acc = surface;
                     o = over_point;
@@ -1669,8 +1679,8 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                 if (f.flags & F_HAS_REFR) {
                     f.acc = partial;
                     f.flags |= F_WAIT_REFR;
-                    o = f.ro;
-                    d = f.rd;
+                    o = stack_refr[sp - 1].ro;
+                    d = stack_refr[sp - 1].rd;
                     rem--;
                     path = path * 2u + 1u;
                     break;
@@ -1679,7 +1689,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                 ret = (f.flags & F_SCHLICK) ? partial + black * (1.0f - f.R) : partial + black;
                 sp--;
             } else {
-                V3 refracted = ret * f.transparency;  // world.rs:159-160
+                V3 refracted = ret * stack_refr[sp - 1].transparency;  // world.rs:159-160
                 ret = (f.flags & F_SCHLICK) ? f.acc + refracted * (1.0f - f.R) : f.acc + refracted;
                 sp--;
             }
