@@ -7,7 +7,10 @@
 #include <hip/hiprtc.h>
 
 #include <dlfcn.h>
+#include <sys/stat.h>
 #include <unistd.h>
+
+#include <cerrno>
 
 #include <cmath>
 #include <cstdio>
@@ -496,7 +499,7 @@ rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunct
         hiprtcDestroyProgram(&prog);
         // best effort: a read-only tree just means every process compiles for itself
         std::string tmp = cache_path + "." + std::to_string((long)getpid());
-        if (system(("mkdir -p '" + cache_dir + "' 2>/dev/null").c_str()) == 0) {
+        if (::mkdir(cache_dir.c_str(), 0777) == 0 || errno == EEXIST) {
             std::ofstream f(tmp, std::ios::binary);
             if (f) {
                 f.write(code.data(), (std::streamsize)code.size());
