@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--scene", default="soft_shadows", help="scene function in ray_tracer_challenge_amd.scenes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU oracle sample (0 = skip)")
     ap.add_argument("--no-verify", action="store_true", help="skip the sampled-row parity check before timing")
+    ap.add_argument("--extra-parts", type=int, default=-1, help="N>1: parts rendered by rank 0 on top of its own in an "
+                    "(N+E)-way band split; -1 = from the measured gather/render ratio, 0 = even split")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank code path on a box with fewer GPUs than ranks)")
     return ap.parse_args()
@@ -110,23 +112,41 @@ def main():
             dist.init_process_group(args.backend)
 
     world, camera, depth = getattr(scenes, args.scene)(args.size, args.size)
-    renderer = Renderer(world, camera, device=dev_index)
-    part = Renderer.partition(64, world_size, rank)
-    gather = BandGather(camera.height, camera.width, 3, torch.float32, device, rank, world_size)
-    assert gather.local_view(0).shape[0] == renderer.rows(part)
+    renderers = {}  # one context per part this rank renders: each keeps the counters and event timings of its own launches
 
-    def run(n_steps):
-        """n_steps frames, software-pipelined: frame i's band gather (comm stream) overlaps frame i+1's render."""
-        image = None
-        for i in range(n_steps):
-            slot = i % 2
-            renderer.render(depth, out=gather.local_view(slot), part=part)
-            gather.start(slot)
-            if i > 0:
-                image = gather.finish((i - 1) % 2)
-        if n_steps > 0:
-            image = gather.finish((n_steps - 1) % 2)
-        return image
+    def renderer_for(p):
+        if p not in renderers:
+            renderers[p] = Renderer(world, camera, device=dev_index)
+        return renderers[p]
+
+    def make_runner(g, quantise=False):
+        """K frames, software-pipelined: frame i's band gather (comm stream) overlaps frame i+1's render.  With
+        `quantise` the rows travel as the bytes Canvas::to_ppm prints (device scale_color, canvas.rs:39-43)."""
+        parts = g.parts()
+        pdesc = {p: Renderer.partition(64, g.n_parts, p) for p in parts}
+        scratch = None
+        if quantise:
+            scratch = {(s_, p): torch.empty(tuple(g.local_view(s_, p).shape), dtype=torch.float32, device=device)
+                       for s_ in range(2) for p in parts}
+
+        def run(n_steps):
+            image = None
+            for k in range(n_steps):
+                slot = k % 2
+                for p in parts:
+                    r = renderer_for(p)
+                    if quantise:
+                        r.render(depth, out=scratch[(slot, p)], part=pdesc[p])
+                        r.quantize(scratch[(slot, p)], out=g.local_view(slot, p))
+                    else:
+                        r.render(depth, out=g.local_view(slot, p), part=pdesc[p])
+                g.start(slot)
+                if k > 0:
+                    image = g.finish((k - 1) % 2)
+            if n_steps > 0:
+                image = g.finish((n_steps - 1) % 2)
+            return image
+        return run
 
     def fence():
         torch.cuda.synchronize()
@@ -134,16 +154,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def drain():
+        """-> this rank's counters summed over its parts' last launches, and its kernel time per frame (the parts'
+        mean launch times added up: they run back to back on one stream)."""
+        tot = {"rays": 0, "shaded_hits": 0, "pixels": 0, "culled_shadow_rays": 0, "kernel_ms": 0.0}
+        for r in renderers.values():
+            st_ = r.stats()
+            if st_["launches"]:
+                for key in tot:
+                    tot[key] += st_[key]
+        return tot
+
+    gather = BandGather(camera.height, camera.width, 3, torch.float32, device, rank, world_size)
+    assert gather.local_view(0).shape[0] == renderer_for(rank).rows(Renderer.partition(64, world_size, rank))
+    run = make_runner(gather)
     run(args.warmup)
     fence()
-    renderer.stats()  # drain the event ring so the timed launches are averaged alone
+    warm = drain()
+
+    # xGMI is point-to-point: every peer's rows reach rank 0 over that peer's one link.  When moving a peer's share
+    # takes longer than rendering it, rank 0 -- whose rows never travel -- takes E extra parts of an (N + E)-way split
+    # (dist.BandGather).  E comes from the measured ratio of an un-overlapped gather to a render of one even share.
+    extra_parts, calib = 0, None
+    if world_size > 1 and args.steps > 0:
+        t0 = time.perf_counter()
+        for _ in range(3):
+            gather.start(0)
+            gather.finish(0)
+            torch.cuda.synchronize()
+        t_gather = (time.perf_counter() - t0) / 3 * 1e3
+        both = torch.tensor([warm["kernel_ms"], t_gather], dtype=torch.float64, device=device)
+        dist.all_reduce(both, op=dist.ReduceOp.MAX)  # every rank derives the same E from the same two numbers
+        k_ms, g_ms = float(both[0].item()), float(both[1].item())
+        if args.extra_parts >= 0:
+            extra_parts = args.extra_parts
+        elif k_ms > 0:
+            extra_parts = max(0, min(6, int(round(g_ms / k_ms)) - 1))
+        calib = {"render_ms_even_share": round(k_ms, 4), "gather_ms_even_share_unoverlapped": round(g_ms, 4)}
+        if extra_parts > 0:
+            gather = BandGather(camera.height, camera.width, 3, torch.float32, device, rank, world_size, extra_parts=extra_parts)
+            run = make_runner(gather)
+            run(max(2, min(args.warmup, 3)))
+        fence()
+        drain()
 
     t0 = time.perf_counter()
     image = run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
 
-    st = renderer.stats()  # counters of the last launch + mean kernel time over the K timed launches
+    st = drain()  # counters of the last frame's launches + kernel time per frame on this rank
+    st["kernel_ms"] = st["kernel_ms"] if st["kernel_ms"] > 0 else 0.0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     counts = torch.tensor([st["rays"], st["shaded_hits"], st["pixels"], st["culled_shadow_rays"]], dtype=torch.float64,
                           device=device)
@@ -154,39 +215,29 @@ def main():
         dist.all_reduce(kern, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     rays, shaded, pixels, culled = (int(v) for v in counts.tolist())
+    renderer = renderer_for(rank)
 
-    # N > 1, informational: the same K frames delivered to rank 0 as the bytes Canvas::to_ppm would print (device
-    # scale_color, canvas.rs:39-43) -- a quarter of the xGMI traffic of the f32 Canvas rows that `value` is measured
-    # with.  Never fatal: a failure is reported in the field instead.
+    # N > 1, informational: the same K frames delivered to rank 0 as the bytes Canvas::to_ppm would print -- a quarter
+    # of the xGMI traffic of the f32 Canvas rows that `value` is measured with.  Never fatal: a failure is reported
+    # in the field instead.
     wire = None
     if world_size > 1 and args.steps > 0:
         try:
             gather8 = BandGather(camera.height, camera.width, 3, torch.uint8, device, rank, world_size)
-            scratch = [torch.empty((renderer.rows(part), camera.width, 3), dtype=torch.float32, device=device) for _ in range(2)]
-
-            def run8(n_steps):
-                img8 = None
-                for i in range(n_steps):
-                    slot = i % 2
-                    renderer.render(depth, out=scratch[slot], part=part)
-                    renderer.quantize(scratch[slot], out=gather8.local_view(slot))
-                    gather8.start(slot)
-                    if i > 0:
-                        img8 = gather8.finish((i - 1) % 2)
-                return gather8.finish((n_steps - 1) % 2) if n_steps > 0 else img8
-            run8(min(args.warmup, 2))
+            run8 = make_runner(gather8, quantise=True)
+            run8(2)
             fence()
-            renderer.stats()
+            drain()
             t1 = time.perf_counter()
             img8 = run8(args.steps)
             fence()
             e8 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
             dist.all_reduce(e8, op=dist.ReduceOp.MAX)
-            renderer.stats()
+            drain()
             ok8 = None
             if rank == 0 and image is not None and img8 is not None:
-                ok8 = bool(torch.equal(img8, renderer.quantize(image.contiguous())))  # the gathered bytes == bytes of the gathered f32 frame
-            wire = {"encoding": "u8 (scale_color on the device)", "ms_per_step": round(float(e8.item()) / args.steps * 1e3, 4),
+                ok8 = bool(torch.equal(img8, renderer.quantize(image.contiguous())))  # == bytes of the gathered f32 frame
+            wire = {"encoding": "u8 (scale_color on the device), even split", "ms_per_step": round(float(e8.item()) / args.steps * 1e3, 4),
                     "value": round(rays / (float(e8.item()) / args.steps) / 1e6, 2), "unit": "Mrays/s",
                     "gathered_bytes_per_step": int(camera.height * camera.width * 3 * (world_size - 1) // world_size),
                     "equals_quantised_f32_frame": ok8}
@@ -222,8 +273,9 @@ def main():
                        # of rays_per_frame: area-light shadow rays whose answer followed from the conservative
                        # light-cone cull (no object test needed); they are counted because the reference casts them
                        "shadow_rays_resolved_by_light_cone_cull": culled,
-                       "partition": "64-row bands round-robin over %d rank(s)%s" % (
-                           world_size, ", RCCL gather of f32 rows to rank 0" if world_size > 1 else "")},
+                       "partition": "64-row bands round-robin over %d part(s)%s" % (
+                           world_size + extra_parts, (", rank 0 renders %d of them; RCCL gather of f32 rows to rank 0"
+                                                      % (extra_parts + 1)) if world_size > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": renderer.kernel_name, "kernel_ms": round(st["kernel_ms"], 4),
@@ -240,9 +292,12 @@ def main():
         if world_size > 1:
             # `value` gathers the f32 Canvas rows (12 B / pixel) to rank 0 over xGMI: one link per peer, so the step is
             # max(render, rows_of_one_peer / link rate).  Render and transport separately:
+            n_parts = world_size + extra_parts
             line["multi_gpu"] = {"gather": "f32 Canvas rows to rank 0, double-buffered (frame i's gather overlaps frame i+1's render)",
+                                 "split": "%d parts; rank 0 renders %d (its rows do not travel), each peer 1" % (n_parts, extra_parts + 1),
+                                 "calibration": calib,
                                  "render_kernel_ms_max_over_ranks": round(float(kern.item()), 4),
-                                 "gathered_bytes_per_step": int(camera.height * camera.width * 12 * (world_size - 1) // world_size),
+                                 "gathered_bytes_per_step": int(camera.height * camera.width * 12 * (world_size - 1) // n_parts),
                                  "wire_format_gather": wire}
         if args.cpu_seconds > 0 and world_size == 1:
             line["cpu_baseline"] = cpu_baseline(world, camera, depth, args.cpu_seconds)

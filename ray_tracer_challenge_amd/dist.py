@@ -41,35 +41,56 @@ def band_layout(height, n_parts, band_rows=BAND_ROWS):
 
 
 class BandGather:
-    """Pre-allocated, double-buffered gather of (rows_r, W, C) band buffers to rank `dst`."""
+    """Pre-allocated, double-buffered gather of (rows_r, W, C) band buffers to rank `dst`.
+
+    `extra_parts` = E > 0 deals the bands over N + E parts instead of N: rank r renders part r as before, and `dst`
+    additionally renders parts N .. N+E-1 straight into its own memory.  xGMI is point-to-point -- each peer's rows
+    reach `dst` over that peer's one link -- so when moving a peer's share takes longer than rendering it, giving
+    `dst` (whose rows never travel) a larger share shortens the step; the messages stay equal-sized, so the
+    collective is the same dist.gather.  bench.py picks E from a measured gather / render ratio."""
 
     def __init__(self, height, width, channels, dtype, device, rank, world_size, dst=0, band_rows=BAND_ROWS,
-                 slots=2):
+                 slots=2, extra_parts=0):
+        if world_size == 1:
+            extra_parts = 0
         self.rank, self.world_size, self.dst, self.slots = rank, world_size, dst, slots
         self.height, self.width, self.channels = height, width, channels
-        self.rows, self.max_rows, perm = band_layout(height, world_size, band_rows)
+        self.extra_parts, self.n_parts = extra_parts, world_size + extra_parts
+        self.rows, self.max_rows, perm = band_layout(height, self.n_parts, band_rows)
         self.local_rows = self.rows[rank]
-        # send buffers padded to the largest part so that every message has one size
-        self.send = [torch.zeros((self.max_rows, width, channels), dtype=dtype, device=device) for _ in range(slots)]
         self.work = [None] * slots
         if rank == dst and world_size > 1:
-            self.recv = [torch.zeros((world_size, self.max_rows, width, channels), dtype=dtype, device=device)
-                         for _ in range(slots)]
+            # one buffer per slot holding every part: [0, N) filled by the gather, [N, N+E) rendered here
+            self.all = [torch.zeros((self.n_parts, self.max_rows, width, channels), dtype=dtype, device=device)
+                        for _ in range(slots)]
+            self.send = [torch.zeros((self.max_rows, width, channels), dtype=dtype, device=device) for _ in range(slots)]
             self.perm = perm.to(device)
             self.image = [torch.zeros((height, width, channels), dtype=dtype, device=device) for _ in range(slots)]
         else:
-            self.recv = self.perm = self.image = None
+            # send buffers padded to the largest part so that every message has one size
+            self.send = [torch.zeros((self.max_rows, width, channels), dtype=dtype, device=device) for _ in range(slots)]
+            self.all = self.perm = self.image = None
 
-    def local_view(self, slot=0):
-        """Where the renderer writes this rank's rows for `slot` (compact, band after band)."""
-        return self.send[slot][: self.local_rows]
+    def parts(self):
+        """The parts this rank renders: its own, plus the extra ones on dst."""
+        own = [self.rank]
+        if self.rank == self.dst and self.world_size > 1:
+            own += list(range(self.world_size, self.n_parts))
+        return own
+
+    def local_view(self, slot=0, part=None):
+        """Where the renderer writes part `part` (default: this rank's gather part) for `slot` -- compact, band after band."""
+        if part is None or part == self.rank:
+            return self.send[slot][: self.local_rows]
+        assert self.rank == self.dst and self.world_size <= part < self.n_parts
+        return self.all[slot][part][: self.rows[part]]
 
     def start(self, slot=0):
         """Enqueue the gather of `slot` (after whatever filled it on the current stream); returns immediately."""
         if self.world_size == 1:
             return
         if self.rank == self.dst:
-            self.work[slot] = dist.gather(self.send[slot], [self.recv[slot][r] for r in range(self.world_size)],
+            self.work[slot] = dist.gather(self.send[slot], [self.all[slot][r] for r in range(self.world_size)],
                                           dst=self.dst, async_op=True)
         else:
             self.work[slot] = dist.gather(self.send[slot], None, dst=self.dst, async_op=True)
@@ -83,7 +104,7 @@ class BandGather:
             self.work[slot] = None
         if self.rank != self.dst:
             return None
-        flat = self.recv[slot].view(self.world_size * self.max_rows, self.width, self.channels)
+        flat = self.all[slot].view(self.n_parts * self.max_rows, self.width, self.channels)
         torch.index_select(flat, 0, self.perm, out=self.image[slot])
         return self.image[slot]
 

@@ -33,21 +33,25 @@ def _global_rows(height, n_parts, part, band_rows=64):
     return rows
 
 
-def _worker(rank, world_size, port, height, width, ok):
+def _worker(rank, world_size, port, height, width, ok, extra_parts=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     try:
-        g = BandGather(height, width, 3, torch.float32, torch.device("cpu"), rank, world_size)
-        rows = _global_rows(height, world_size, rank)
-        assert g.local_rows == len(rows)
+        g = BandGather(height, width, 3, torch.float32, torch.device("cpu"), rank, world_size, extra_parts=extra_parts)
+        n_parts = world_size + extra_parts
+        assert g.n_parts == n_parts and g.local_rows == len(_global_rows(height, n_parts, rank))
+        assert g.parts() == ([rank] + list(range(world_size, n_parts)) if rank == 0 else [rank])
 
         def fill(slot, frame):
-            # stand-in for the kernel: pixel value encodes (frame, global row, column, channel)
-            local = g.local_view(slot)
-            for i, y in enumerate(rows):
-                local[i] = (frame * 1e6 + y * 1000.0 + torch.arange(width, dtype=torch.float32)[:, None]
-                            + torch.tensor([0.0, 0.25, 0.5]))
+            # stand-in for the kernel: pixel value encodes (frame, global row, column, channel); one "launch" per owned part
+            for part in g.parts():
+                local = g.local_view(slot, part)
+                rows = _global_rows(height, n_parts, part)
+                assert local.shape[0] == len(rows)
+                for i, y in enumerate(rows):
+                    local[i] = (frame * 1e6 + y * 1000.0 + torch.arange(width, dtype=torch.float32)[:, None]
+                                + torch.tensor([0.0, 0.25, 0.5]))
 
         def expected(frame):
             return (frame * 1e6 + torch.arange(height, dtype=torch.float32)[:, None, None] * 1000.0
@@ -80,6 +84,14 @@ def _worker(rank, world_size, port, height, width, ok):
 def test_band_gather_gloo(world_size, height):
     ok = mp.get_context("spawn").Array("i", [0] * world_size)
     mp.spawn(_worker, args=(world_size, _free_port(), height, 17, ok), nprocs=world_size, join=True)
+    assert list(ok) == [1] * world_size
+
+
+@pytest.mark.parametrize("world_size,height,extra", [(2, 256, 2), (2, 1000, 3), (3, 700, 1), (2, 63, 2)])
+def test_band_gather_with_extra_parts_on_the_root(world_size, height, extra):
+    """The bandwidth-aware split: N + E parts, rank 0 renders E of them locally; the assembled image is the same."""
+    ok = mp.get_context("spawn").Array("i", [0] * world_size)
+    mp.spawn(_worker, args=(world_size, _free_port(), height, 17, ok, extra), nprocs=world_size, join=True)
     assert list(ok) == [1] * world_size
 
 
