@@ -12,6 +12,7 @@
 
 #include <cerrno>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -107,6 +108,95 @@ static void pack_triangle(const rtc_object& o, float4 rec[3]) {
 }
 static rtc_status pack_uv_pattern(const rtc_uv_pattern& u, std::vector<float4>* uvrec, std::vector<float>* texels,
                                   std::vector<std::pair<const float*, size_t>>* seen);
+static bool env_flag(const char* name, bool dflt) {
+    const char* e = std::getenv(name);
+    return (e && *e) ? e[0] != '0' : dflt;
+}
+
+// An internal bounding-volume hierarchy for FLAT worlds (World.objects without GroupShapes) of many bounded objects:
+// the object list is left as it is, and a traversal stream with groups of the library's own making is laid over it,
+// walked by the same packet kernel as real GroupShapes.  Unlike a GroupShape's box -- which is part of the
+// reference's semantics -- these boxes must never change an answer.  They cannot: every box is the hull of its
+// objects' world-space bounds INFLATED by 10 % (plus an absolute epsilon), so a ray that misses a box passes at
+// least 0.1 radius away from every object inside, where the exact intersection test reports a miss with a margin far
+// above its rounding error -- the same argument, and the same proviso, as for light-cone culling: the
+// quadratic's cancellation error grows with the ray origin's distance in radii, so the hierarchy is only built when
+// no ray can start more than 100 radii from any object (origins are the camera or points on the objects).  Ties in
+// hit distance go by object index in the tree kernels, so the visiting order does not matter either.
+// Eligible: scale+translate-only spheres and cubes, all of them (a plane's bounds are infinite).
+static bool build_flat_bvh(const rtc_scene* scene, const float cam_origin[4], std::vector<float4>* trav) {
+    const uint32_t n = scene->n_objects;
+    struct Box {
+        float lo[3], hi[3];
+    };
+    std::vector<Box> box(n);
+    float all_lo[3] = {cam_origin[0], cam_origin[1], cam_origin[2]}, all_hi[3] = {cam_origin[0], cam_origin[1], cam_origin[2]};
+    float r_min = INFINITY;
+    for (uint32_t i = 0; i < n; i++) {
+        const rtc_object& o = scene->objects[i];
+        if (o.kind != RTC_SPHERE && o.kind != RTC_CUBE) return false;
+        const float* m = o.inv;
+        if (!(m[1] == 0.0f && m[2] == 0.0f && m[4] == 0.0f && m[6] == 0.0f && m[8] == 0.0f && m[9] == 0.0f)) return false;
+        for (int a = 0; a < 3; a++) {
+            const float g = m[5 * a], t = m[4 * a + 3];  // x_obj = g * x_world + t, |x_obj| <= 1 (sphere and cube alike)
+            if (!(std::fabs(g) > 1e-20f) || !std::isfinite(g) || !std::isfinite(t)) return false;
+            const float c = -t / g, h = 1.0f / std::fabs(g);  // world centre and half extent along this axis
+            const float pad = 0.1f * h + 1e-4f * (std::fabs(c) + h);
+            box[i].lo[a] = c - h - pad;
+            box[i].hi[a] = c + h + pad;
+            all_lo[a] = std::fmin(all_lo[a], c - h);
+            all_hi[a] = std::fmax(all_hi[a], c + h);
+            r_min = std::fmin(r_min, h);
+        }
+    }
+    float diag2 = 0.0f;
+    for (int a = 0; a < 3; a++) diag2 += (all_hi[a] - all_lo[a]) * (all_hi[a] - all_lo[a]);
+    if (!(std::sqrt(diag2) < 100.0f * r_min)) return false;  // some ray could start more than 100 radii from an object
+    auto as_f = [](uint32_t u) {
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    };
+    // median split of the centres along the widest axis, down to two objects per group
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    struct Rec {
+        static void go(std::vector<uint32_t>& ord, size_t b, size_t e, const std::vector<Box>& box, std::vector<float4>* out,
+                       float (*as_f)(uint32_t)) {
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (size_t k = b; k < e; k++)
+                for (int a = 0; a < 3; a++) {
+                    lo[a] = std::fmin(lo[a], box[ord[k]].lo[a]);
+                    hi[a] = std::fmax(hi[a], box[ord[k]].hi[a]);
+                }
+            const size_t head = out->size();
+            float big = 0.0f;
+            for (int a = 0; a < 3; a++) big = std::fmax(big, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+            out->push_back(make_float4(lo[0], lo[1], lo[2], 0.0f));
+            out->push_back(make_float4(hi[0], hi[1], hi[2], 1e-3f * big));
+            if (e - b <= 2) {
+                for (size_t k = b; k < e; k++) {
+                    out->push_back(make_float4(0.0f, 0.0f, 0.0f, as_f(ord[k])));
+                    out->push_back(make_float4(0.0f, 0.0f, 0.0f, TRAV_LEAF_TAG));
+                }
+            } else {
+                int axis = 0;
+                for (int a = 1; a < 3; a++)
+                    if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+                const size_t mid = b + (e - b) / 2;
+                std::nth_element(ord.begin() + b, ord.begin() + mid, ord.begin() + e, [&](uint32_t x, uint32_t y) {
+                    return box[x].lo[axis] + box[x].hi[axis] < box[y].lo[axis] + box[y].hi[axis];
+                });
+                go(ord, b, mid, box, out, as_f);
+                go(ord, mid, e, box, out, as_f);
+            }
+            (*out)[head].w = as_f((uint32_t)(out->size() / 2));  // skip: the entry after this subtree
+        }
+    };
+    Rec::go(order, 0, n, box, trav, +as_f);
+    return true;
+}
+
 // TextureMap / CubicMap: the pattern's second record points at its UV patterns, which are appended to `uvrec`.
 static rtc_status pack_texture_map(const rtc_pattern& pt, float4 rec[5], std::vector<float4>* uvrec, std::vector<float>* texels,
                                    std::vector<std::pair<const float*, size_t>>* seen) {
@@ -227,6 +317,17 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
                 rtc_status ust = pack_texture_map(pt, rec, &uvrec, texels, &seen_images);
                 if (ust != RTC_OK) return ust;
             }
+        }
+    }
+    // A flat world of many bounded objects gets a bounding-volume hierarchy of the library's own (see build_flat_bvh)
+    if (!scene->n_groups && cam && n >= 16 && env_flag("RTC_AMD_BVH", true)) {
+        std::vector<float4> trav;
+        float cam_origin[4];
+        const float zero[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+        mat_vec4(cam->inv, zero, cam_origin);
+        if (build_flat_bvh(scene, cam_origin, &trav)) {
+            hdr->n_trav = (uint32_t)(trav.size() / 2);
+            soa->insert(soa->end(), trav.begin(), trav.end());
         }
     }
     // GroupShapes: write the depth-first traversal out as an entry list (see SceneSoA::trav)
@@ -618,7 +719,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     snprintf(nm, sizeof(nm), "render_kernel<%d,%s>", n <= 4 ? 4 : n <= 8 ? 8 : 0, (n <= 8 && c->simple) ? "simple" : "general");
     c->kernel_name = nm;
     if (hdr.n_trav) {  // GroupShapes: packet traversal of the group tree; no per-scene specialisation
-        c->kernel_name = "render_kernel<tree>";
+        c->kernel_name = scene->n_groups ? "render_kernel<tree>" : "render_kernel<tree,bvh>";
         return RTC_OK;
     }
     const int policy = specialise_policy();

@@ -948,7 +948,11 @@ DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, float t_max
         V3 po = obj_point(ob, o);
         V3 pd = obj_vector(ob, d);
         local_intersect<true>(ob.bits, ob.min_y(), ob.max_y(), S.tri, i, po, pd, [&](float t) {
-            if (t >= 0.0f && (best.obj < 0 || t < best.t)) {
+            // first-minimum in list order: the flat loops visit objects in that order; a tree walk may not (the
+            // library's own bounding-volume hierarchy over a flat world reorders visits), so there ties go to the lower index
+            bool better = best.obj < 0 || t < best.t;
+            if constexpr (NOBJ < 0) better = better || (t == best.t && (int)i < best.obj);
+            if (t >= 0.0f && better) {
                 best.t = t;
                 best.obj = (int)i;
                 if constexpr (NOBJ < 0) wr.limit = (any_hit && t < t_max) ? -RTC_INF : fminf(wr.limit, t);
@@ -1464,12 +1468,18 @@ DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int
         });
         if (negatives & 1) {
             if ((int)i == hit_obj) hit_inside = true;
-            if (c1 < 0 || tmax >= t1) {  // later object wins ties: it sorts after
+            // the later object (in list order) wins ties: it sorts after.  Flat loops visit in list order; tree walks
+            // compare indices explicitly (see nearest_hit).
+            auto after = [&](float ta, int ia, float tb, int ib) {  // does (ta, ia) sort after (tb, ib)?
+                if constexpr (NOBJ < 0) return ta > tb || (ta == tb && ia > ib);
+                else return ta >= tb;
+            };
+            if (c1 < 0 || after(tmax, (int)i, t1, c1)) {
                 t2 = t1;
                 c2 = c1;
                 t1 = tmax;
                 c1 = (int)i;
-            } else if (c2 < 0 || tmax >= t2) {
+            } else if (c2 < 0 || after(tmax, (int)i, t2, c2)) {
                 t2 = tmax;
                 c2 = (int)i;
             }

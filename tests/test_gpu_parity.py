@@ -303,6 +303,7 @@ def test_specialised_kernel_matches_generic_and_oracle(name, size, kw, monkeypat
     count and the shaded-hit count must equal the ahead-of-time kernel's and the oracle's."""
     from ray_tracer_challenge_amd.renderer import Renderer
     world, camera, depth = getattr(scenes, name)(*size, **kw)
+    monkeypatch.setenv("RTC_AMD_BVH", "0")  # sphere_grid would otherwise take the tree kernel (test_flat_bvh.py)
     out = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("RTC_AMD_SPECIALIZE", mode)
@@ -326,6 +327,8 @@ def test_specialisation_policy_defaults(monkeypatch):
     world, camera, _ = scenes.soft_shadows(1024, 512)
     assert Renderer(world, camera, device=0).kernel_name.startswith("render_kernel_spec[")  # >= 2^18 pixels
     world, camera, _ = scenes.sphere_grid(1024, 512)
+    assert Renderer(world, camera, device=0).kernel_name == "render_kernel<tree,bvh>"      # 64 bounded objects
+    monkeypatch.setenv("RTC_AMD_BVH", "0")
     assert Renderer(world, camera, device=0).kernel_name == "render_kernel_spec[all 0x500]"  # 64 like objects
     world.objects[3].casts_shadow = False                                                  # ... no longer alike
     assert Renderer(world, camera, device=0).kernel_name == "render_kernel<0,general>"
