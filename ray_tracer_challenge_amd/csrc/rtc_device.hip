@@ -108,6 +108,12 @@ static void pack_triangle(const rtc_object& o, float4 rec[3]) {
 }
 static rtc_status pack_uv_pattern(const rtc_uv_pattern& u, std::vector<float4>* uvrec, std::vector<float>* texels,
                                   std::vector<std::pair<const float*, size_t>>* seen);
+// occupancy target of a specialised traversal kernel (RTC_AMD_TREE_WAVES: development override)
+static std::string tree_jit_waves() {
+    const char* e = std::getenv("RTC_AMD_TREE_WAVES");
+    return (e && *e >= '1' && *e <= '8' && !e[1]) ? std::string(e) : std::string("6");
+}
+
 static bool env_flag(const char* name, bool dflt) {
     const char* e = std::getenv(name);
     return (e && *e) ? e[0] != '0' : dflt;
@@ -564,7 +570,9 @@ rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunct
                                      "-I" + csrc, "-I" + inc};
     for (const auto& d : defines) opts.push_back(d);
     // occupancy target of the specialised kernel: measured 4 -> 3.39, 5 -> 3.42, 6 -> 3.24, 7 -> 3.17, 8 -> 3.17 ms (C3)
-    opts.push_back("-DRTC_WAVES_PER_SIMD=8");
+    bool waves_given = false;
+    for (const auto& d : defines) waves_given = waves_given || d.rfind("-DRTC_WAVES_PER_SIMD=", 0) == 0;
+    if (!waves_given) opts.push_back("-DRTC_WAVES_PER_SIMD=8");
     if (const char* extra = std::getenv("RTC_AMD_JIT_FLAGS")) {  // development: extra -D / -m flags, space separated
         std::istringstream ss(extra);
         std::string tok;
@@ -719,7 +727,37 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     snprintf(nm, sizeof(nm), "render_kernel<%d,%s>", n <= 4 ? 4 : n <= 8 ? 8 : 0, (n <= 8 && c->simple) ? "simple" : "general");
     c->kernel_name = nm;
     if (hdr.n_trav) {  // GroupShapes: packet traversal of the group tree; no per-scene specialisation
-        c->kernel_name = scene->n_groups ? "render_kernel<tree>" : "render_kernel<tree,bvh>";
+        const std::string how = scene->n_groups ? "tree" : "tree,bvh";
+        c->kernel_name = "render_kernel<" + how + ">";
+        const int policy = specialise_policy();
+        if (policy == 1 || (policy == 2 && (uint64_t)hdr.width * hdr.height >= (1ull << 18))) {
+            // the traversal kernel compiled for this scene's light kind / jitter mode / pattern use and, when every object
+            // shares one kind / flags word (a triangle mesh, a grid of spheres), for that word as well
+            uint32_t first;
+            std::memcpy(&first, &soa[0].w, 4);
+            bool uniform = true;
+            for (uint32_t i = 1; i < n && uniform; i++) {
+                uint32_t bits;
+                std::memcpy(&bits, &soa[i].w, 4);
+                uniform = bits == first;
+            }
+            char b[16];
+            snprintf(b, sizeof(b), "0x%x", first);
+            std::vector<std::string> defs = {std::string("-DRTC_SPEC_LIST=") + b,
+                                             uniform ? std::string("-DRTC_SPEC_UNIFORM_BITS=") + b : std::string("-DRTC_SPEC_RUNTIME_BITS=1"),
+                                             "-DRTC_SPEC_NOBJ=-1", "-DRTC_SPEC_SIMPLE=0", "-DRTC_WAVES_PER_SIMD=" + tree_jit_waves(),
+                                             "-DRTC_SPEC_LIGHT_KIND=" + std::to_string(hdr.light_kind),
+                                             "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
+                                             std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
+            rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
+            if (jst != RTC_OK) {
+                if (policy == 1) return jst;
+                c->spec_fn = nullptr;
+            } else {
+                c->kernel_name = std::string("render_kernel_spec[") + how + (uniform ? std::string(";all ") + b : std::string()) +
+                                 (hdr.has_patterns ? ";patterns" : "") + "]";
+            }
+        }
         return RTC_OK;
     }
     const int policy = specialise_policy();

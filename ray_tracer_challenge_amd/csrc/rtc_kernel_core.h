@@ -552,6 +552,9 @@ enum : uint32_t {
 #ifdef RTC_SPEC_UNIFORM_BITS
 // any number of objects, all with the same kind / flags word (C5: 64 scale+translate spheres)
 DI uint32_t spec_bits(uint32_t, uint32_t) { return RTC_SPEC_UNIFORM_BITS; }
+#elif defined(RTC_SPEC_RUNTIME_BITS)
+// a tree of mixed objects: only the light / jitter / pattern switches are compile-time
+DI uint32_t spec_bits(uint32_t, uint32_t runtime_bits) { return runtime_bits; }
 #else
 DI uint32_t spec_bits(uint32_t i, uint32_t) {
     constexpr uint32_t table[8] = {RTC_SPEC_LIST};

@@ -297,6 +297,12 @@ def test_boundary_errors_on_device():
     ("patterns_medley", (128, 96), {}),
     ("sphere_grid", (128, 128), {}),          # 64 like objects: the any-count loop specialised on their shared flags word
     ("sphere_grid", (96, 64), {"n": 5}),      # 25 objects: the remainder loop
+    ("hexagons", (128, 64), {}),              # GroupShape trees: the traversal kernel compiled for the scene
+    ("groups_medley", (96, 64), {}),
+    ("grouped_grid", (96, 96), {}),
+    ("mesh", (64, 64), {}),                   # triangles only: their flags word is a compile-time constant
+    ("first_textures", (96, 48), {}),
+    ("skybox", (64, 64), {}),
 ])
 def test_specialised_kernel_matches_generic_and_oracle(name, size, kw, monkeypatch):
     """RTC_AMD_SPECIALIZE=1 compiles the kernel for this scene's shape with hiprtc; the image, the ray
@@ -327,7 +333,7 @@ def test_specialisation_policy_defaults(monkeypatch):
     world, camera, _ = scenes.soft_shadows(1024, 512)
     assert Renderer(world, camera, device=0).kernel_name.startswith("render_kernel_spec[")  # >= 2^18 pixels
     world, camera, _ = scenes.sphere_grid(1024, 512)
-    assert Renderer(world, camera, device=0).kernel_name == "render_kernel<tree,bvh>"      # 64 bounded objects
+    assert Renderer(world, camera, device=0).kernel_name == "render_kernel_spec[tree,bvh;all 0x500]"  # 64 bounded objects
     monkeypatch.setenv("RTC_AMD_BVH", "0")
     assert Renderer(world, camera, device=0).kernel_name == "render_kernel_spec[all 0x500]"  # 64 like objects
     world.objects[3].casts_shadow = False                                                  # ... no longer alike
