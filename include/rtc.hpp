@@ -287,23 +287,23 @@ struct Shape {
             std::vector<Shape> left, right, keep;
             for (Shape& c : children) {
                 BoundingBox cb = c.parent_space_bounding_box();
-                if (halves.first.contains_bounding_box(cb)) left.push_back(c);
-                else if (halves.second.contains_bounding_box(cb)) right.push_back(c);
-                else keep.push_back(c);
+                if (halves.first.contains_bounding_box(cb)) left.push_back(std::move(c));
+                else if (halves.second.contains_bounding_box(cb)) right.push_back(std::move(c));
+                else keep.push_back(std::move(c));
             }
-            children = keep;
-            if (!left.empty()) make_subgroup(left);
-            if (!right.empty()) make_subgroup(right);
+            children = std::move(keep);
+            if (!left.empty()) make_subgroup(std::move(left));
+            if (!right.empty()) make_subgroup(std::move(right));
         }
         for (Shape& c : children) c.divide(threshold);
     }
-    void make_subgroup(const std::vector<Shape>& kids) {  // group.rs:66-73
+    void make_subgroup(std::vector<Shape> kids) {  // group.rs:66-73
         if (kids.size() == 1) {
-            children.push_back(kids[0]);
+            children.push_back(std::move(kids[0]));
         } else {
             Shape g(GROUP);
-            g.children = kids;
-            children.push_back(g);
+            g.children = std::move(kids);
+            children.push_back(std::move(g));
         }
     }
     rtc_object c() const {

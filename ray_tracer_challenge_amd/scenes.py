@@ -359,6 +359,96 @@ def mesh(width=512, height=384, nu=16, nv=10, threshold=6):
     return world, camera, 5
 
 
+def dragon_stand_in_obj(nu=48, nv=32):
+    """Wavefront OBJ text of a closed, ridged, flattened blob whose normalised bounds are close to those the demo
+    notes for its dragon (x in [-1, 1], |y| <= 0.69, |z| <= 0.44; here_be_dragons.rs:296-298): stands in for the
+    `dragon.obj` the reference's demo reads from a path that is not in its repository.  nu * (nv - 2) quads (fan-
+    triangulated by the parser) + 2 * nu cap triangles."""
+    import math
+    lines = ["# stand-in for dragon.obj: %d x %d" % (nu, nv)]
+    verts = []
+    for j in range(1, nv):
+        th = math.pi * j / nv
+        for i in range(nu):
+            ph = 2.0 * math.pi * i / nu
+            r = 1.0 + 0.12 * math.sin(5 * ph) * math.sin(3 * th) + 0.05 * math.cos(9 * ph + 2 * th)
+            verts.append((r * math.sin(th) * math.cos(ph), 0.69 * r * math.cos(th), 0.44 * r * math.sin(th) * math.sin(ph)))
+    verts.append((0.0, 0.69, 0.0))
+    verts.append((0.0, -0.69, 0.0))
+    for v in verts:
+        lines.append("v %.5f %.5f %.5f" % v)
+    top, bottom = len(verts) - 1, len(verts)
+    for j in range(nv - 2):
+        for i in range(nu):
+            a = j * nu + i + 1
+            b2 = j * nu + (i + 1) % nu + 1
+            lines.append("f %d %d %d %d" % (a, b2, b2 + nu, a + nu))
+    for i in range(nu):
+        a, b2 = i + 1, (i + 1) % nu + 1
+        lines.append("f %d %d %d" % (top, b2, a))
+        a2, b3 = (nv - 2) * nu + i + 1, (nv - 2) * nu + (i + 1) % nu + 1
+        lines.append("f %d %d %d" % (bottom, a2, b3))
+    return "\n".join(lines) + "\n"
+
+
+def here_be_dragons_objects(api, obj_text=None, nu=48, nv=32, threshold=4):
+    """demos/src/bin/here_be_dragons.rs:36-337: six copies of one parsed mesh, each on a pedestal, five of them inside
+    a transparent display case that casts no shadow; every element a GroupShape divided with threshold 4."""
+    from .obj_parser import parse_obj
+    if obj_text is None:
+        obj_text = dragon_stand_in_obj(nu, nv)
+    pi = PI
+
+    def dragon_material(rgb):
+        return api.Material(color=rgb, ambient=0.1, diffuse=0.6, specular=0.3, shininess=15.0)
+
+    def case_material(diffuse, transparency):
+        return api.Material(ambient=0.0, diffuse=diffuse, specular=0.0, transparency=transparency)
+
+    elements = [  # (element transform, dragon colour, display case material) -- :41-141
+        (api.chain(api.translation(0.0, 0.5, -4.0), api.rotation_y(pi)), (1, 1, 1), None),
+        (api.translation(0.0, 2.0, 2.0), (1, 0, 0.1), case_material(0.4, 0.6)),
+        (api.chain(api.translation(-2.0, 0.75, -1.0), api.rotation_y(-pi / f32(8.0)), api.scaling(0.75, 0.75, 0.75)),
+         (0.9, 0.5, 0.1), case_material(0.2, 0.8)),
+        (api.chain(api.translation(-4.0, 0.0, -2.0), api.rotation_y(-pi / f32(16.0)), api.scaling(0.5, 0.5, 0.5)),
+         (1, 0.9, 0.1), case_material(0.1, 0.9)),
+        (api.chain(api.translation(2.0, 1.0, -1.0), api.rotation_y(f32(5.0) * pi / f32(4.0)), api.scaling(0.75, 0.75, 0.75)),
+         (1, 0.5, 0.1), case_material(0.2, 0.8)),
+        (api.chain(api.translation(4.0, 0.0, -2.0), api.rotation_y(f32(21.0) * pi / f32(20.0)), api.scaling(0.5, 0.5, 0.5)),
+         (0.9, 1, 0.1), case_material(0.1, 0.9)),
+    ]
+    objects = []
+    for transform, rgb, case in elements:
+        dragon = parse_obj(obj_text, api).take_all_as_group()          # get_dragon, :290-304 (the demo clones one parse)
+        dragon.set_transformation(api.translation(0.0, 0.69, 0.0))
+        element = api.GroupShape()                                     # get_scene_element, :306-337
+        element.set_transformation(transform)
+        dragon.set_material(dragon_material(rgb))
+        if case is not None:
+            display_case = api.Cube(api.chain(api.scaling(1.1, 0.77, 0.49), api.translation(0.0, 1.001, 0.0)), case,
+                                    casts_shadow=False)                # :246-254
+            dragon_box = api.GroupShape()
+            dragon_box.add_child(dragon)
+            dragon_box.add_child(display_case)
+        else:
+            dragon_box = dragon
+        element.add_child(dragon_box)
+        element.add_child(api.Cylinder(api.identity_4x4(), api.Material(color=(0.2, 0.2, 0.2), ambient=0.0, diffuse=0.8,
+                                                                        specular=0.0, reflective=0.2),
+                                       minimum_y=-0.15, maximum_y=0.0, closed=True))  # :269-288
+        element.divide(threshold)
+        objects.append(element)
+    return objects
+
+
+def here_be_dragons(width=1000, height=400, obj_text=None, nu=48, nv=32):
+    """The BVH bonus-chapter demo (here_be_dragons.rs; camera :211-216, light :240-242, depth 5 :218)."""
+    from . import api
+    world = World(here_be_dragons_objects(api, obj_text, nu, nv), PointLight(point(-10, 100, -100), color(1, 1, 1)))
+    camera = Camera(width, height, f32(1.2), view_transform(point(0, 2.5, -10), point(0, 1, 0), vector(0, 1, 0)))
+    return world, camera, 5
+
+
 def synthetic_ppm(width, height, seed=1, scale=255):
     """P3 text of a deterministic test image (smooth bands + blocks + speckle): stands in for the earth / skybox
     photographs the reference's texture demos read from files that are not in its repository."""

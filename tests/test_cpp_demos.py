@@ -23,7 +23,8 @@ def built():
 
 
 def test_demos_build_and_refuse_to_run_without_gpu(built):
-    for name in ("soft_shadows", "first_scene", "first_plane", "first_patterns", "reflect_refract", "hexagons", "first_textures"):
+    for name in ("soft_shadows", "first_scene", "first_plane", "first_patterns", "reflect_refract", "hexagons", "first_textures",
+                 "here_be_dragons"):
         assert os.access(os.path.join(built, name), os.X_OK)
     if P.device_count() == 0:
         p = subprocess.run([os.path.join(built, "first_plane"), "8x8"], capture_output=True, text=True)
@@ -55,3 +56,23 @@ def test_first_textures_demo_reads_its_image_from_a_ppm_file(built, tmp_path):
     assert p.stdout == O.to_ppm(img) + b"\n"
     bad = subprocess.run([os.path.join(built, "first_textures"), str(tmp_path / "missing.ppm")], capture_output=True, text=True)
     assert bad.returncode == 1 and "cannot open" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_here_be_dragons_demo_parses_its_mesh_from_an_obj_file(built, tmp_path):
+    """here_be_dragons.rs takes the mesh as an OBJ file on its command line; the C++ counterpart parses it with
+    include/rtc_obj.hpp (a second implementation of obj_parser.rs next to obj_parser.py), builds and divides the six
+    elements natively and must print the PPM the oracle renders from the Python-built scene."""
+    text = scenes.dragon_stand_in_obj(14, 9)
+    path = tmp_path / "blob.obj"
+    path.write_text(text)
+    p = subprocess.run([os.path.join(built, "here_be_dragons"), str(path), "150x60"], capture_output=True)
+    assert p.returncode == 0, p.stderr
+    world, camera, depth = scenes.here_be_dragons(150, 60, obj_text=text)
+    img, _ = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=8)
+    assert p.stdout == O.to_ppm(img) + b"\n"
+    bad = subprocess.run([os.path.join(built, "here_be_dragons"), str(tmp_path / "missing.obj")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "cannot open" in bad.stderr
+    (tmp_path / "broken.obj").write_text("v 0 0 0\nv 1 0 0\nf 1 2\n")
+    bad = subprocess.run([os.path.join(built, "here_be_dragons"), str(tmp_path / "broken.obj")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Not enough vertices" in bad.stderr

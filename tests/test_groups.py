@@ -162,13 +162,14 @@ def _strip_kind(sig):
     return ("g", sig[1], sig[2], [_strip_kind(c) for c in sig[3]]) if sig[0] == "g" else ("s", None, sig[2])
 
 
-@pytest.mark.parametrize("name", ["hexagons", "grouped_grid", "groups_medley"])
+@pytest.mark.parametrize("name", ["hexagons", "grouped_grid", "groups_medley", "here_be_dragons"])
 def test_product_and_oracle_build_identical_trees(name):
     """The same construction script run against the product API and against the oracle's API: same tree shape,
     bit-identical baked leaf transforms and group bounding boxes (two independent implementations of
     add_child / set_transformation / divide / bounding_box)."""
     build = getattr(scenes, name + "_objects")
-    for p_node, o_node in zip(build(P), build(O)):
+    kw = {"nu": 12, "nv": 8} if name == "here_be_dragons" else {}
+    for p_node, o_node in zip(build(P, **kw), build(O, **kw)):
         if isinstance(p_node, P.GroupShape):
             assert _strip_kind(_tree_signature_p(p_node)) == _tree_signature_o(o_node)
 

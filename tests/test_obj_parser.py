@@ -161,6 +161,24 @@ def test_mesh_scene_matches_oracle_bitwise(size, kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size,kw", [((125, 50), {"nu": 12, "nv": 8}), ((250, 100), {"nu": 20, "nv": 12})])
+def test_here_be_dragons_scene_matches_oracle_bitwise(size, kw):
+    """demos/src/bin/here_be_dragons.rs with a procedural stand-in for its dragon.obj: six divided mesh groups on
+    pedestals, five inside transparent display cases that cast no shadow."""
+    world, camera, depth = scenes.here_be_dragons(*size, **kw)
+    canvas = camera.render(world, depth)
+    oc = H.oracle_camera(camera)
+    img, rays = oc.render(H.oracle_world(world), depth, threads=8)
+    H.assert_images_equal(canvas.data, img, "here_be_dragons")
+    assert camera.last_stats["rays"] == rays
+    assert canvas.to_ppm() == O.to_ppm(img)
+    own = O.World(scenes.here_be_dragons_objects(O, **kw), O.PointLight(world.light.position, world.light.intensity))
+    img2, rays2 = oc.render(own, depth, threads=8)
+    H.assert_images_equal(canvas.data, img2, "here_be_dragons (oracle-parsed, oracle-built tree)")
+    assert rays2 == rays
+
+
+@pytest.mark.gpu
 def test_flat_world_of_triangles_uses_the_unrolled_kernels():
     """Triangles outside any group take the flat kernels (AOT and scene-specialised): a tetrahedron."""
     from ray_tracer_challenge_amd.renderer import Renderer
