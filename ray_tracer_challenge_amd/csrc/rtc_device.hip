@@ -108,6 +108,126 @@ static void pack_triangle(const rtc_object& o, float4 rec[3]) {
 }
 static rtc_status pack_uv_pattern(const rtc_uv_pattern& u, std::vector<float4>* uvrec, std::vector<float>* texels,
                                   std::vector<std::pair<const float*, size_t>>* seen);
+
+// ---- triangle pre-culling (kernel side and error analysis: rtc_kernel_core.h tri_precull) ------------------------
+// world = F * object + f for an object whose (affine) inverse is `inv`; false if the 3x3 part is singular
+static bool forward_affine(const float inv[16], double F[9], double f[3]) {
+    const double a[9] = {inv[0], inv[1], inv[2], inv[4], inv[5], inv[6], inv[8], inv[9], inv[10]};
+    const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+    F[0] = (a[4] * a[8] - a[5] * a[7]) / det, F[1] = (a[2] * a[7] - a[1] * a[8]) / det, F[2] = (a[1] * a[5] - a[2] * a[4]) / det;
+    F[3] = (a[5] * a[6] - a[3] * a[8]) / det, F[4] = (a[0] * a[8] - a[2] * a[6]) / det, F[5] = (a[2] * a[3] - a[0] * a[5]) / det;
+    F[6] = (a[3] * a[7] - a[4] * a[6]) / det, F[7] = (a[1] * a[6] - a[0] * a[7]) / det, F[8] = (a[0] * a[4] - a[1] * a[3]) / det;
+    const double t[3] = {inv[3], inv[7], inv[11]};
+    for (int r = 0; r < 3; r++) f[r] = -(F[3 * r] * t[0] + F[3 * r + 1] * t[1] + F[3 * r + 2] * t[2]);
+    for (int k = 0; k < 9; k++)
+        if (!std::isfinite(F[k])) return false;
+    return std::isfinite(f[0]) && std::isfinite(f[1]) && std::isfinite(f[2]);
+}
+// largest and smallest singular value of a 3x3 matrix (cyclic Jacobi on A^T A)
+static void singular_range(const double a[9], double* s_max, double* s_min) {
+    double m[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) m[3 * r + c] = a[r] * a[c] + a[3 + r] * a[3 + c] + a[6 + r] * a[6 + c];
+    for (int sweep = 0; sweep < 12; sweep++)
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (std::fabs(m[3 * p + q]) < 1e-300) continue;
+                const double th = 0.5 * std::atan2(2.0 * m[3 * p + q], m[3 * q + q] - m[3 * p + p]), c = std::cos(th), sn = std::sin(th);
+                double r[9];
+                for (int k = 0; k < 9; k++) r[k] = m[k];
+                for (int k = 0; k < 3; k++) {  // columns p, q
+                    r[3 * k + p] = c * m[3 * k + p] - sn * m[3 * k + q];
+                    r[3 * k + q] = sn * m[3 * k + p] + c * m[3 * k + q];
+                }
+                for (int k = 0; k < 9; k++) m[k] = r[k];
+                for (int k = 0; k < 3; k++) {  // rows p, q
+                    r[3 * p + k] = c * m[3 * p + k] - sn * m[3 * q + k];
+                    r[3 * q + k] = sn * m[3 * p + k] + c * m[3 * q + k];
+                }
+                for (int k = 0; k < 9; k++) m[k] = r[k];
+            }
+    const double e0 = std::fmax(m[0], 0.0), e1 = std::fmax(m[4], 0.0), e2 = std::fmax(m[8], 0.0);
+    *s_max = std::sqrt(std::fmax(e0, std::fmax(e1, e2)));
+    *s_min = std::sqrt(std::fmin(e0, std::fmin(e1, e2)));
+}
+// World-space extent of a bounded object; false for unbounded / unsupported ones.
+static bool world_extent(const rtc_object& o, double lo[3], double hi[3]) {
+    double F[9], f[3];
+    if (!forward_affine(o.inv, F, f)) return false;
+    double pts[8][3];
+    int n = 0;
+    if (o.kind == RTC_TRIANGLE) {
+        for (const float* p : {o.p1, o.p2, o.p3}) pts[n][0] = p[0], pts[n][1] = p[1], pts[n][2] = p[2], n++;
+    } else {
+        double y0 = -1.0, y1 = 1.0;
+        if (o.kind == RTC_CYLINDER || o.kind == RTC_CONE) {
+            if (!std::isfinite(o.min_y) || !std::isfinite(o.max_y)) return false;
+            y0 = o.min_y, y1 = o.max_y;
+        } else if (o.kind != RTC_SPHERE && o.kind != RTC_CUBE) {
+            return false;  // planes
+        }
+        const double rxz = o.kind == RTC_CONE ? std::fmax(std::fabs(y0), std::fabs(y1)) : 1.0;
+        for (int k = 0; k < 8; k++) pts[n][0] = (k & 1) ? rxz : -rxz, pts[n][1] = (k & 2) ? y1 : y0, pts[n][2] = (k & 4) ? rxz : -rxz, n++;
+    }
+    for (int a = 0; a < 3; a++) lo[a] = INFINITY, hi[a] = -INFINITY;
+    for (int k = 0; k < n; k++)
+        for (int a = 0; a < 3; a++) {
+            const double w = F[3 * a] * pts[k][0] + F[3 * a + 1] * pts[k][1] + F[3 * a + 2] * pts[k][2] + f[a];
+            if (!std::isfinite(w)) return false;
+            lo[a] = std::fmin(lo[a], w), hi[a] = std::fmax(hi[a], w);
+        }
+    return true;
+}
+// The pre-culling box of one triangle (see tri_precull for the derivation of P); `d_world`: bound on the distance
+// between a pre-culling ray's origin and the triangle.  Leaves rec[0].w = 0 when no safe box exists.
+static void triangle_box(const rtc_object& o, const float4 tri[3], double d_world, float4 rec[3]) {
+    rec[0] = rec[1] = rec[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    double F[9], f[3];
+    if (!forward_affine(o.inv, F, f)) return;
+    const double A[9] = {o.inv[0], o.inv[1], o.inv[2], o.inv[4], o.inv[5], o.inv[6], o.inv[8], o.inv[9], o.inv[10]};
+    double s_max, s_min;  // object = A * world: object lengths are within [s_min, s_max] times world lengths
+    singular_range(A, &s_max, &s_min);
+    if (!(s_min > 0.0) || !std::isfinite(s_max)) return;
+    const double kappa = s_max / s_min;
+    // the triangle the kernel intersects: p1, p1 + e1, p1 + e2 with the stored (f32) edges
+    const double p[3][3] = {{tri[0].x, tri[0].y, tri[0].z},
+                            {(double)tri[0].x + tri[1].x, (double)tri[0].y + tri[1].y, (double)tri[0].z + tri[1].z},
+                            {(double)tri[0].x + tri[2].x, (double)tri[0].y + tri[2].y, (double)tri[0].z + tri[2].z}};
+    auto len = [](const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    const double e1[3] = {tri[1].x, tri[1].y, tri[1].z}, e2[3] = {tri[2].x, tri[2].y, tri[2].z};
+    const double e3[3] = {e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2]};
+    const double l1 = len(e1), l2 = len(e2), l3 = len(e3);
+    if (!(l1 > 0.0 && l2 > 0.0 && l3 > 0.0)) return;
+    auto angle_sin_half = [](double a, double b, double c) {  // sin(angle/2) at the vertex between sides a, b opposite c
+        const double cosv = std::fmax(-1.0, std::fmin(1.0, (a * a + b * b - c * c) / (2.0 * a * b)));
+        return std::sqrt(std::fmax(0.0, (1.0 - cosv) / 2.0));
+    };
+    const double sh = std::fmin(angle_sin_half(l1, l2, l3), std::fmin(angle_sin_half(l1, l3, l2), angle_sin_half(l2, l3, l1)));
+    if (!(sh > 1e-3)) return;  // a sliver: its rejections are not robust at any useful padding
+    const double rho = std::fmax(1.0, (l1 + l2) / l3), s_obj = std::fmax(l1, std::fmax(l2, l3));
+    const double eps = 5.9604644775390625e-08, guard = 0.05;  // 2^-24; TRI_GUARD
+    const double d_obj = s_max * d_world;
+    const double pad_obj = 4.0 * eps * rho * kappa * (8.0 * d_obj + 10.0 * s_obj) / (guard * sh);
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, w[3][3];
+    for (int k = 0; k < 3; k++)
+        for (int a = 0; a < 3; a++) {
+            w[k][a] = F[3 * a] * p[k][0] + F[3 * a + 1] * p[k][1] + F[3 * a + 2] * p[k][2] + f[a];
+            lo[a] = std::fmin(lo[a], w[k][a]), hi[a] = std::fmax(hi[a], w[k][a]);
+        }
+    const double u[3] = {w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2]}, v[3] = {w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2]};
+    double nrm[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+    const double nl = len(nrm);
+    if (!(nl > 0.0) || !std::isfinite(nl)) return;
+    double big = 0.0;
+    for (int a = 0; a < 3; a++) big = std::fmax(big, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+    // object distance >= s_min * world distance; 1e-5 of the coordinates covers the slab test's own rounding in f32
+    const double pad = pad_obj / s_min + 1e-5 * (big + d_world);
+    if (!std::isfinite(pad)) return;
+    rec[0] = make_float4((float)(lo[0] - pad), (float)(lo[1] - pad), (float)(lo[2] - pad), 1.0f);
+    rec[1] = make_float4((float)(hi[0] + pad), (float)(hi[1] + pad), (float)(hi[2] + pad), 0.0f);
+    rec[2] = make_float4((float)(nrm[0] / nl), (float)(nrm[1] / nl), (float)(nrm[2] / nl), 0.0f);
+}
 // occupancy target of a specialised traversal kernel (RTC_AMD_TREE_WAVES: development override)
 static std::string tree_jit_waves() {
     const char* e = std::getenv("RTC_AMD_TREE_WAVES");
@@ -180,10 +300,12 @@ static bool build_flat_bvh(const rtc_scene* scene, const float cam_origin[4], st
             for (int a = 0; a < 3; a++) big = std::fmax(big, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
             out->push_back(make_float4(lo[0], lo[1], lo[2], 0.0f));
             out->push_back(make_float4(hi[0], hi[1], hi[2], 1e-3f * big));
+            out->push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));
             if (e - b <= 2) {
                 for (size_t k = b; k < e; k++) {
                     out->push_back(make_float4(0.0f, 0.0f, 0.0f, as_f(ord[k])));
                     out->push_back(make_float4(0.0f, 0.0f, 0.0f, TRAV_LEAF_TAG));
+                    out->push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 }
             } else {
                 int axis = 0;
@@ -196,7 +318,7 @@ static bool build_flat_bvh(const rtc_scene* scene, const float cam_origin[4], st
                 go(ord, b, mid, box, out, as_f);
                 go(ord, mid, e, box, out, as_f);
             }
-            (*out)[head].w = as_f((uint32_t)(out->size() / 2));  // skip: the entry after this subtree
+            (*out)[head].w = as_f((uint32_t)(out->size() / TRAV_STRIDE));  // skip: the entry after this subtree
         }
     };
     Rec::go(order, 0, n, box, trav, +as_f);
@@ -325,6 +447,37 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
             }
         }
     }
+    // Triangles met by tree walks get a pre-culling box (tri_precull): the ball around everything bounded (and the camera)
+    // bounds the distance between a ray's origin and a triangle; rays that start outside it do not pre-cull
+    std::vector<float4> tbox;  // 3 records per object: { box.min, usable }, { box.max, 0 }, { unit normal, 0 }, world space
+    if (scene->n_groups && env_flag("RTC_AMD_TRI_PRECULL", true)) {
+        bool any_triangle = false;
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = 0; i < n; i++) {
+            any_triangle = any_triangle || scene->objects[i].kind == RTC_TRIANGLE;
+            double olo[3], ohi[3];
+            if (world_extent(scene->objects[i], olo, ohi))
+                for (int a = 0; a < 3; a++) lo[a] = std::fmin(lo[a], olo[a]), hi[a] = std::fmax(hi[a], ohi[a]);
+        }
+        if (cam) {
+            float org[4];
+            const float zero[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+            mat_vec4(cam->inv, zero, org);
+            for (int a = 0; a < 3; a++) lo[a] = std::fmin(lo[a], (double)org[a]), hi[a] = std::fmax(hi[a], (double)org[a]);
+        }
+        double r2 = 0.0;
+        for (int a = 0; a < 3; a++) r2 += 0.25 * (hi[a] - lo[a]) * (hi[a] - lo[a]);
+        if (any_triangle && std::isfinite(r2) && r2 > 0.0) {
+            const double radius = 1.05 * std::sqrt(r2);  // a little room: hit points are computed, not exact
+            hdr->has_tbox = 1;
+            for (int a = 0; a < 3; a++) hdr->cull_c[a] = (float)(0.5 * (lo[a] + hi[a]));
+            hdr->cull_r2 = (float)(radius * radius);
+            tbox.assign(3 * (size_t)n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            for (uint32_t i = 0; i < n; i++)
+                if (scene->objects[i].kind == RTC_TRIANGLE)
+                    triangle_box(scene->objects[i], &(*soa)[12 * (size_t)np + 3 * (size_t)i], 2.0 * radius, &tbox[3 * (size_t)i]);
+        }
+    }
     // A flat world of many bounded objects gets a bounding-volume hierarchy of the library's own (see build_flat_bvh)
     if (!scene->n_groups && cam && n >= 16 && env_flag("RTC_AMD_BVH", true)) {
         std::vector<float4> trav;
@@ -332,7 +485,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         const float zero[4] = {0.0f, 0.0f, 0.0f, 1.0f};
         mat_vec4(cam->inv, zero, cam_origin);
         if (build_flat_bvh(scene, cam_origin, &trav)) {
-            hdr->n_trav = (uint32_t)(trav.size() / 2);
+            hdr->n_trav = (uint32_t)(trav.size() / TRAV_STRIDE);
             soa->insert(soa->end(), trav.begin(), trav.end());
         }
     }
@@ -354,7 +507,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         };
         for (uint32_t p = 0; p <= n; p++) {
             while (!open.empty() && open.back().end == p) {  // close: skip index = next entry
-                trav[2 * open.back().entry].w = as_f((uint32_t)(trav.size() / 2));
+                trav[TRAV_STRIDE * open.back().entry].w = as_f((uint32_t)(trav.size() / TRAV_STRIDE));
                 open.pop_back();
             }
             for (;;) {
@@ -365,7 +518,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
                 if (end > n || (!open.empty() && end > open.back().end))
                     return fail(RTC_ERR_INVALID_ARG, "group %u: objects [%u, %u) do not nest inside the enclosing group / the world",
                                 gi, g.first_object, (unsigned)end);
-                open.push_back({(uint32_t)end, trav.size() / 2});
+                open.push_back({(uint32_t)end, trav.size() / TRAV_STRIDE});
                 float big = 0.0f;  // pruning slack: 1e-3 of the largest |coordinate| (NaN-propagating on purpose)
                 for (int a = 0; a < 3; a++) {
                     const float lo = std::fabs(g.bounds_min[a]), hi = std::fabs(g.bounds_max[a]);
@@ -373,18 +526,23 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
                 }
                 trav.push_back(make_float4(g.bounds_min[0], g.bounds_min[1], g.bounds_min[2], 0.0f));
                 trav.push_back(make_float4(g.bounds_max[0], g.bounds_max[1], g.bounds_max[2], 1e-3f * big));
+                trav.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 any = true;
                 gi++;
             }
             if (p < n) {
-                trav.push_back(make_float4(0.0f, 0.0f, 0.0f, as_f(p)));
-                trav.push_back(make_float4(0.0f, 0.0f, 0.0f, TRAV_LEAF_TAG));
+                // a leaf; a triangle with a usable pre-culling box carries it along (tri_precull)
+                const float4* tb = tbox.empty() ? nullptr : &tbox[3 * (size_t)p];
+                const bool boxed = tb && tb[0].w > 0.0f;
+                trav.push_back(boxed ? make_float4(tb[0].x, tb[0].y, tb[0].z, as_f(p)) : make_float4(0.0f, 0.0f, 0.0f, as_f(p)));
+                trav.push_back(boxed ? make_float4(tb[1].x, tb[1].y, tb[1].z, TRAV_BOXED_LEAF_TAG) : make_float4(0.0f, 0.0f, 0.0f, TRAV_LEAF_TAG));
+                trav.push_back(boxed ? tb[2] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
             }
         }
         if (gi != scene->n_groups)
             return fail(RTC_ERR_INVALID_ARG, "group %u: groups must be listed in pre-order with first_object inside [0, n_objects)", gi);
         if (any) {
-            hdr->n_trav = (uint32_t)(trav.size() / 2);
+            hdr->n_trav = (uint32_t)(trav.size() / TRAV_STRIDE);
             soa->insert(soa->end(), trav.begin(), trav.end());
         }
     }

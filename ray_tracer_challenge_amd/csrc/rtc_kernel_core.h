@@ -489,6 +489,10 @@ struct SceneHdr {
     float light_y_lo, light_y_hi;  // world-space y range of the area light's sample points, widened (light-cone culling)
     uint32_t uvrec_off;            // where SceneSoA::uvrec starts inside the scene buffer, in float4 units (host use)
     uint32_t all_cast;             // every object casts shadows: a shadow ray may stop at its first hit before the light
+    // Triangle pre-culling (tree walks, see tri_precull): some triangle carries a box in SceneSoA::tbox; rays that start
+    // within cull_r2 (squared) of cull_c are the ones the boxes' padding was computed for
+    uint32_t has_tbox;
+    float cull_c[3], cull_r2;
 };
 
 // Structure-of-arrays scene records in HBM: 4 float4 of geometry (64 B) and
@@ -512,10 +516,12 @@ struct SceneSoA {
     //   {a.rgb, kind}, {b.rgb -- or distance = b - a for gradient / sine_2d --, 0}, rows 0..2 of the pattern's t_inverse
     const float4* __restrict__ pat;
     // Worlds with GroupShapes (shape/group.rs): the object records are the tree's leaves in depth-first order and
-    // `trav` is that traversal written out, two float4 per entry:
-    //   group: { bounds.min.xyz, skip }, { bounds.max.xyz, slack }   skip = entry index after the group's subtree,
+    // `trav` is that traversal written out, TRAV_STRIDE (three) float4 per entry:
+    //   group: { bounds.min.xyz, skip }, { bounds.max.xyz, slack }, unused   skip = entry index after the group's subtree,
     //          slack = 1e-3 * the box's largest |coordinate| (pruning margin, see for_each_object)
-    //   leaf : { 0, 0, 0, object index }, { 0, 0, 0, -1 }
+    //   leaf : { 0, 0, 0, object index }, { 0, 0, 0, -1 }, unused
+    //   leaf, a triangle with a pre-culling box (tri_precull; world space, padded on the host -- rtc_device.hip triangle_box):
+    //          { box.min.xyz, object index }, { box.max.xyz, -2 }, { unit normal.xyz, 0 }
     const float4* __restrict__ trav;
     // Triangles (shape/triangle.rs:9-17), 3 records per object, read only for RTC_TRIANGLE objects:
     //   { p1.xyz, normal.x }, { e1.xyz, normal.y }, { e2.xyz, normal.z }
@@ -534,6 +540,8 @@ struct SceneSoA {
     const float* __restrict__ texels;
 };
 constexpr float TRAV_LEAF_TAG = -1.0f;  // e1.w of a leaf entry; a group's e1.w is its pruning slack (>= 0)
+constexpr float TRAV_BOXED_LEAF_TAG = -2.0f;
+constexpr uint32_t TRAV_STRIDE = 3;
 enum : uint32_t {
     SHAPE_KIND_MASK = 0xffu,
     SHAPE_NONE = 0xffu,      // padding record: never intersects (arrays are padded to a multiple of 8)
@@ -859,11 +867,55 @@ DI bool aabb_hit(V3 o, V3 inv, float4 mn, float4 mx, float& tmin) {
 struct WorldRay {
     V3 o, inv;
     float limit;
+    V3 d;
+    float guard;  // TRI_GUARD * |d|, or +inf when this ray may not pre-cull triangles (see tri_precull)
 };
+constexpr float TRI_GUARD = 0.05f;  // sine of the smallest ray-to-plane angle at which a triangle may be pre-culled
 template <int NOBJ>
-DI WorldRay world_ray(V3 o, V3 d) {
-    if constexpr (NOBJ < 0) return {o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), RTC_INF};
-    else return {o, o, RTC_INF};  // unused
+DI WorldRay world_ray(const SceneHdr& H, V3 o, V3 d) {
+    if constexpr (NOBJ < 0) {
+        const V3 c = o - v3(H.cull_c[0], H.cull_c[1], H.cull_c[2]);
+        const bool near = H.has_tbox != 0u && dot3(c, c) <= H.cull_r2;  // NaN: false
+        return {o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), RTC_INF, d, near ? TRI_GUARD * sqrtf(dot3(d, d)) : RTC_INF};
+    } else {
+        return {o, o, RTC_INF, o, RTC_INF};  // unused
+    }
+}
+
+// Tree walks meet long runs of triangle leaves (the reference's divide() keeps every child that straddles the split
+// plane in the parent group: a closed mesh leaves a ring of them at every level), and the exact test costs ~150
+// operations per leaf (general inverse transform of the ray + Moeller-Trumbore with an IEEE division).  Most of those
+// rays pass nowhere near the triangle.  This is a ~25-operation test that says so in a way the exact f32 evaluation
+// is GUARANTEED to agree with -- i.e. it only skips triangles for which triangle.rs:45-68, evaluated in f32 on this
+// ray, returns no intersection:
+//   * the ray's line (no t >= 0 restriction: the n1/n2 walk wants intersections behind the origin as well) misses
+//     the triangle's world-space bounding box, PADDED on the host by a distance P derived below, and
+//   * the ray is not within asin(TRI_GUARD) of the triangle's plane (|d.n| >= TRI_GUARD |d|), and
+//   * the ray starts inside the ball the padding was derived for (WorldRay::guard is +inf otherwise).
+// Why that is safe (object-space quantities; D = |origin - p1|, s = longest edge, theta = angle between ray and plane,
+// alpha = smallest interior angle, q = where the ray's line meets the plane, eps = 2^-24):  the three rejections of
+// the reference's test compare N_u = p1o.(d x e2), N_v = d.(p1o x e1) and their sum with 0 and det = e1.(d x e2).
+// Geometrically |N_u| = |d||e2| m_u sin(theta) with m_u the in-plane distance from q to the edge line through p1
+// along e2 (likewise for the other two edges), and the rounding of each N is at most 8 eps D |d||e|, that of det at
+// most 7 eps |e1||d||e2|, so a rejection that holds in exact arithmetic can only be lost to rounding if
+//       m_j sin(theta) <= eps rho (8 D + 10 s),    rho = max(1, (|e1| + |e2|) / |e2 - e1|).
+// A line that misses the padded box passes at least P from the triangle, so q lies at least P outside it in the
+// plane, which puts it at least P sin(alpha / 2) beyond one of the three edge lines.  With sin(theta) >= TRI_GUARD /
+// kappa (kappa: condition number of the object's transform, which distorts the angle) the host chooses
+//       P = 4 eps rho kappa (8 D + 10 s) / (TRI_GUARD sin(alpha / 2))          (4: safety factor; it also covers the
+// rounding of the ray's own transformation into object space, which moves q by ~4 eps D / sin(theta)),
+// with D bounded through the ball: every ray that pre-culls starts within it, every triangle lies within it.  The sign of
+// det is safe as well (|det| = |d| |e1 x e2| sin(theta) >> 7 eps |e1||d||e2| under the same conditions; triangles too
+// thin for that get no box).  NaNs fail the comparisons and keep the triangle.
+DI bool tri_precull(const WorldRay& wr, float4 b0, float4 b1, float4 b2) {
+    const float dn = wr.d.x * b2.x + wr.d.y * b2.y + wr.d.z * b2.z;
+    if (!(fabsf(dn) >= wr.guard)) return false;
+    const float x0 = (b0.x - wr.o.x) * wr.inv.x, x1 = (b1.x - wr.o.x) * wr.inv.x;
+    const float y0 = (b0.y - wr.o.y) * wr.inv.y, y1 = (b1.y - wr.o.y) * wr.inv.y;
+    const float z0 = (b0.z - wr.o.z) * wr.inv.z, z1 = (b1.z - wr.o.z) * wr.inv.z;
+    const float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    const float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    return lo > hi;
 }
 
 // Applies `body(i)` to every object the reference's World::intersect would reach.  NOBJ > 0: the scene has at
@@ -884,7 +936,9 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
         // the limit -- three orders of magnitude more than those errors.
         uint32_t resume = 0;  // this lane ignores entries below `resume`
         for (uint32_t k = 0; k < H.n_trav;) {
-            const float4 e0 = load_uniform(S.trav, 2u * k), e1 = load_uniform(S.trav, 2u * k + 1u);
+            // the three records are fetched together: a dependent fetch costs more than the 16 bytes
+            const float4 e0 = load_uniform(S.trav, TRAV_STRIDE * k), e1 = load_uniform(S.trav, TRAV_STRIDE * k + 1u),
+                         e2 = load_uniform(S.trav, TRAV_STRIDE * k + 2u);
             const bool active = k >= resume && wr.limit > -RTC_INF;
             if (!(e1.w < 0.0f)) {  // a group: e1.w is its slack (>= 0, inf or NaN); leaves carry -1
                 const uint32_t skip = __float_as_uint(e0.w);
@@ -897,7 +951,9 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
                 }
                 k = __any(inside) ? k + 1u : skip;
             } else {
-                if (active) body(__float_as_uint(e0.w));
+                bool visit = active;
+                if (e1.w == TRAV_BOXED_LEAF_TAG) visit = visit && !tri_precull(wr, e0, e1, e2);  // wave-uniform branch
+                if (visit) body(__float_as_uint(e0.w));
                 k++;
             }
         }
@@ -942,7 +998,7 @@ template <int NOBJ>
 DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, float t_max = RTC_INF, bool any_hit = false,
                    uint32_t skip = 0u) {
     Hit best = {0.0f, -1};
-    WorldRay wr = world_ray<NOBJ>(o, d);
+    WorldRay wr = world_ray<NOBJ>(H, o, d);
     wr.limit = t_max;
     for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) {
         if (i < 32u && ((skip >> i) & 1u)) return;  // light-cone culled for this shade point (wave-uniform)
@@ -1042,7 +1098,7 @@ struct ShadowPre {
 template <int NOBJ>
 DI void shadow_prepare(const SceneHdr& H, const SceneSoA& S, V3 p, ShadowPre* pre) {
     static_assert(NOBJ > 0, "flat unrolled scenes only");
-    WorldRay wr = world_ray<NOBJ>(p, p);
+    WorldRay wr = world_ray<NOBJ>(H, p, p);
     for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) {
         Obj ob = load_obj_static<NOBJ <= 0>(S, i);
         pre[i].o = obj_point(ob, p);
@@ -1072,7 +1128,7 @@ DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* p
     V3 dir;
     normalize_exact(v, distance, dir);  // == mag3(v), norm3(v)
     cnt.rays++;
-    WorldRay wr = world_ray<NOBJ>(p, dir);  // unused: NOBJ > 0 here
+    WorldRay wr = world_ray<NOBJ>(H, p, dir);  // unused: NOBJ > 0 here
     auto object_ts = [&](uint32_t i, const float4 g, uint32_t bits, auto&& f) {
         V3 pd;
         if (SIMPLE || (bits & SHAPE_DIAG)) {
@@ -1452,7 +1508,7 @@ DI V3 phong(const SceneHdr& H, V3 material_color, float4 ma, float4 mb, V3 p, V3
 // (t_max_negative, index); toggling the hit object then gives n2.
 template <int NOBJ>
 DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int hit_obj, float& n1, float& n2) {
-    WorldRay wr = world_ray<NOBJ>(o, d);
+    WorldRay wr = world_ray<NOBJ>(H, o, d);
     wr.limit = 0.0f;             // only intersections behind the origin (t < 0) matter here
     float t1 = 0.0f, t2 = 0.0f;  // best and runner-up container keys
     int c1 = -1, c2 = -1;
