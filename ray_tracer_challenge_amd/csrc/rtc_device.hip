@@ -181,7 +181,7 @@ static bool world_extent(const rtc_object& o, double lo[3], double hi[3]) {
 }
 // The pre-culling box of one triangle (see tri_precull for the derivation of P); `d_world`: bound on the distance
 // between a pre-culling ray's origin and the triangle.  Leaves rec[0].w = 0 when no safe box exists.
-static void triangle_box(const rtc_object& o, const float4 tri[3], double d_world, float4 rec[3]) {
+static void triangle_box(const rtc_object& o, const float4 tri[3], double d_world, double guard, double pad_scale, float4 rec[3]) {
     rec[0] = rec[1] = rec[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     double F[9], f[3];
     if (!forward_affine(o.inv, F, f)) return;
@@ -206,7 +206,7 @@ static void triangle_box(const rtc_object& o, const float4 tri[3], double d_worl
     const double sh = std::fmin(angle_sin_half(l1, l2, l3), std::fmin(angle_sin_half(l1, l3, l2), angle_sin_half(l2, l3, l1)));
     if (!(sh > 1e-3)) return;  // a sliver: its rejections are not robust at any useful padding
     const double rho = std::fmax(1.0, (l1 + l2) / l3), s_obj = std::fmax(l1, std::fmax(l2, l3));
-    const double eps = 5.9604644775390625e-08, guard = 0.05;  // 2^-24; TRI_GUARD
+    const double eps = 5.9604644775390625e-08;  // 2^-24
     const double d_obj = s_max * d_world;
     const double pad_obj = 4.0 * eps * rho * kappa * (8.0 * d_obj + 10.0 * s_obj) / (guard * sh);
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, w[3][3];
@@ -222,7 +222,7 @@ static void triangle_box(const rtc_object& o, const float4 tri[3], double d_worl
     double big = 0.0;
     for (int a = 0; a < 3; a++) big = std::fmax(big, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
     // object distance >= s_min * world distance; 1e-5 of the coordinates covers the slab test's own rounding in f32
-    const double pad = pad_obj / s_min + 1e-5 * (big + d_world);
+    const double pad = pad_scale * (pad_obj / s_min + 1e-5 * (big + d_world));
     if (!std::isfinite(pad)) return;
     rec[0] = make_float4((float)(lo[0] - pad), (float)(lo[1] - pad), (float)(lo[2] - pad), 1.0f);
     rec[1] = make_float4((float)(hi[0] + pad), (float)(hi[1] + pad), (float)(hi[2] + pad), 0.0f);
@@ -469,13 +469,17 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         for (int a = 0; a < 3; a++) r2 += 0.25 * (hi[a] - lo[a]) * (hi[a] - lo[a]);
         if (any_triangle && std::isfinite(r2) && r2 > 0.0) {
             const double radius = 1.05 * std::sqrt(r2);  // a little room: hit points are computed, not exact
+            // RTC_AMD_TRI_NAIVE=1 (tests only): no angle guard, no padding -- what tests/test_tri_precull.py must catch
+            const bool naive = env_flag("RTC_AMD_TRI_NAIVE", false);
+            hdr->tri_guard = naive ? 0.0f : TRI_GUARD;
             hdr->has_tbox = 1;
             for (int a = 0; a < 3; a++) hdr->cull_c[a] = (float)(0.5 * (lo[a] + hi[a]));
             hdr->cull_r2 = (float)(radius * radius);
             tbox.assign(3 * (size_t)n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
             for (uint32_t i = 0; i < n; i++)
                 if (scene->objects[i].kind == RTC_TRIANGLE)
-                    triangle_box(scene->objects[i], &(*soa)[12 * (size_t)np + 3 * (size_t)i], 2.0 * radius, &tbox[3 * (size_t)i]);
+                    triangle_box(scene->objects[i], &(*soa)[12 * (size_t)np + 3 * (size_t)i], 2.0 * radius, TRI_GUARD, naive ? 0.0 : 1.0,
+                                 &tbox[3 * (size_t)i]);
         }
     }
     // A flat world of many bounded objects gets a bounding-volume hierarchy of the library's own (see build_flat_bvh)

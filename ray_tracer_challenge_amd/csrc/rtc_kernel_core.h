@@ -493,6 +493,7 @@ struct SceneHdr {
     // within cull_r2 (squared) of cull_c are the ones the boxes' padding was computed for
     uint32_t has_tbox;
     float cull_c[3], cull_r2;
+    float tri_guard;  // TRI_GUARD (the boxes' padding is derived from it on the host)
 };
 
 // Structure-of-arrays scene records in HBM: 4 float4 of geometry (64 B) and
@@ -876,7 +877,7 @@ DI WorldRay world_ray(const SceneHdr& H, V3 o, V3 d) {
     if constexpr (NOBJ < 0) {
         const V3 c = o - v3(H.cull_c[0], H.cull_c[1], H.cull_c[2]);
         const bool near = H.has_tbox != 0u && dot3(c, c) <= H.cull_r2;  // NaN: false
-        return {o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), RTC_INF, d, near ? TRI_GUARD * sqrtf(dot3(d, d)) : RTC_INF};
+        return {o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), RTC_INF, d, near ? H.tri_guard * sqrtf(dot3(d, d)) : RTC_INF};
     } else {
         return {o, o, RTC_INF, o, RTC_INF};  // unused
     }

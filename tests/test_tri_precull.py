@@ -1,0 +1,128 @@
+"""Triangle pre-culling in the tree walks (rtc_kernel_core.h tri_precull, rtc_device.hip triangle_box): a cheap
+world-space test that skips the exact Moeller-Trumbore evaluation (triangle.rs:45-68) for rays that pass nowhere
+near a triangle.  It is not part of the reference's semantics, so it must agree with the exact f32 evaluation on
+EVERY ray -- including the ones where that evaluation is ill-conditioned and reports hits that are not there
+geometrically: rays nearly parallel to a triangle's plane that pass close to it.  Those are generated here on purpose."""
+import numpy as np
+import pytest
+
+import ray_tracer_challenge_amd as P
+from ray_tracer_challenge_amd import scenes
+from ray_tracer_challenge_amd.obj_parser import parse_obj
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def _world():
+    """A tessellated flat plate (coplanar neighbours: the worst case for grazing rays), a bumpy closed mesh of glass and
+    a mirror mesh, all in divided groups under rotations and non-uniform scalings; a sphere and a point light."""
+    plate = P.GroupShape()
+    n = 10
+    for i in range(n):
+        for j in range(n):
+            x0, x1, z0, z1 = i / n - 0.5, (i + 1) / n - 0.5, j / n - 0.5, (j + 1) / n - 0.5
+            for k, pts in enumerate((((x0, 0, z0), (x1, 0, z0), (x1, 0, z1)), ((x0, 0, z0), (x1, 0, z1), (x0, 0, z1)))):
+                m = P.Material(color=(0.2 + 0.8 * i / n, 0.2 + 0.8 * j / n, 0.3 + 0.6 * k), reflective=0.3 if (i + j) % 3 == 0 else 0.0)
+                plate.add_child(P.Triangle(P.point(*pts[0]), P.point(*pts[1]), P.point(*pts[2]), None, m))
+    plate.set_transformation(P.chain(P.translation(0.3, 0.2, 0.5), P.rotation_z(f32(0.3)), P.rotation_x(f32(-0.2)), P.scaling(4.0, 1.0, 2.5)))
+    plate.divide(4)
+    glass = parse_obj(scenes.bumpy_mesh_obj(14, 9, False)).take_all_as_group()
+    glass.set_material(P.Material(color=(0.1, 0.1, 0.2), transparency=0.8, refractive_index=1.4, reflective=0.4, diffuse=0.3))
+    glass.set_transformation(P.chain(P.translation(-0.8, 1.3, 0.2), P.rotation_y(f32(0.7)), P.scaling(0.9, 0.6, 0.7)))
+    glass.divide(3)
+    mirror = parse_obj(scenes.dragon_stand_in_obj(16, 10)).take_all_as_group()
+    mirror.set_material(P.Material(color=(0.8, 0.7, 0.2), reflective=0.5))
+    mirror.set_transformation(P.chain(P.translation(1.4, 0.9, -0.4), P.rotation_z(f32(0.4)), P.scaling(0.8, 0.8, 0.8)))
+    mirror.divide(5)
+    ball = P.Sphere(P.chain(P.translation(0.0, 2.4, 1.0), P.scaling(0.4, 0.4, 0.4)), P.Material(color=(0.9, 0.2, 0.2)))
+    return P.World([plate, glass, mirror, ball], P.PointLight(P.point(-4, 7, -6), P.color(1, 1, 1)))
+
+
+def _adversarial_rays(world, n, seed):
+    """Rays that cross a triangle's plane at a point near (inside or outside) the triangle, at an angle to the plane
+    drawn log-uniformly from [1e-8, 0.5] rad, starting 0.05 .. 6 units away -- plus a share of plain random rays."""
+    rng = np.random.default_rng(seed)
+    tris = []
+    for obj in world.objects:
+        if isinstance(obj, P.GroupShape):
+            for leaf in obj.leaves():
+                if leaf.points is not None:
+                    m = np.asarray(leaf.transform, dtype=np.float64)
+                    tris.append([(m @ np.asarray(p, dtype=np.float64))[:3] for p in leaf.points])
+    tris = np.array(tris)
+    t = tris[rng.integers(0, len(tris), n)]
+    a, e1, e2 = t[:, 0], t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]
+    nrm = np.cross(e1, e2)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    uv = rng.uniform(-0.6, 1.6, (n, 2))
+    q = a + uv[:, :1] * e1 + uv[:, 1:] * e2
+    phi = rng.uniform(0, 2 * np.pi, n)[:, None]
+    e1n = e1 / np.linalg.norm(e1, axis=1, keepdims=True)
+    w = np.cos(phi) * e1n + np.sin(phi) * np.cross(nrm, e1n)
+    theta = np.exp(rng.uniform(np.log(1e-8), np.log(0.5), n))[:, None] * rng.choice([-1.0, 1.0], (n, 1))
+    d = np.cos(theta) * w + np.sin(theta) * nrm
+    o = q - d * rng.uniform(0.05, 6.0, (n, 1))
+    plain = rng.random(n) < 0.15
+    o[plain] = rng.uniform(-5, 5, (int(plain.sum()), 3))
+    dp = rng.normal(size=(int(plain.sum()), 3))
+    d[plain] = dp / np.linalg.norm(dp, axis=1, keepdims=True)
+    d32 = d.astype(f32)
+    d32 /= np.sqrt((d32 * d32).sum(axis=1, keepdims=True, dtype=f32))
+    return (np.concatenate([o.astype(f32), np.ones((n, 1), f32)], axis=1),
+            np.concatenate([d32, np.zeros((n, 1), f32)], axis=1))
+
+
+def test_adversarial_rays_match_oracle_bitwise():
+    world = _world()
+    o, d = _adversarial_rays(world, 12000, seed=5)
+    got = world.color_at(o, d, 3)
+    ow = H.oracle_world(world)
+    exp = np.array([ow.color_at(o[i], d[i], 3) for i in range(len(o))], dtype=f32)
+    bad = ~((got == exp) | (np.isnan(got) & np.isnan(exp)))
+    assert not bad.any(), "%d of %d rays differ, first %d" % (bad.any(axis=1).sum(), len(o), np.argwhere(bad)[0][0])
+    assert (got.sum(axis=1) > 0).mean() > 0.3  # the rays do hit things
+
+
+def test_pre_culling_never_changes_a_ray(monkeypatch):
+    """2 M adversarial rays, depth 4 (reflections, refractions with their n1/n2 walks, shadow rays): identical with the
+    pre-culling switched off."""
+    world = _world()
+    o, d = _adversarial_rays(world, 2_000_000, seed=11)
+    monkeypatch.setenv("RTC_AMD_TRI_PRECULL", "1")
+    on = world.color_at(o, d, 4)
+    monkeypatch.setenv("RTC_AMD_TRI_PRECULL", "0")
+    off = world.color_at(o, d, 4)
+    same = (on.view(np.uint32) == off.view(np.uint32)) | (np.isnan(on) & np.isnan(off))
+    assert same.all(), "%d rays differ" % (~same).any(axis=1).sum()
+
+
+@pytest.mark.parametrize("size", [(640, 480)])
+def test_mesh_scenes_render_identically_with_and_without(size, monkeypatch):
+    from ray_tracer_challenge_amd.renderer import Renderer
+    for world, camera, depth in (scenes.mesh(*size), scenes.here_be_dragons(*size, nu=24, nv=14)):
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("RTC_AMD_TRI_PRECULL", mode)
+            r = Renderer(world, camera, device=0)
+            out[mode] = (r.render(depth).cpu().numpy(), r.stats())
+            r.close()
+        H.assert_images_equal(out["1"][0], out["0"][0], "pre-culling on vs off")
+        assert out["1"][1]["rays"] == out["0"][1]["rays"] and out["1"][1]["shaded_hits"] == out["0"][1]["shaded_hits"]
+
+
+def test_the_adversarial_rays_do_catch_a_naive_cull(monkeypatch):
+    """The same rays against a cull WITHOUT the plane-angle guard and the padding (RTC_AMD_TRI_NAIVE=1, a test-only
+    switch): the exact f32 test reports hits for some rays that miss the triangle's bounding box -- the cases the
+    guard and the padding exist for.  If this stopped failing, the tests above would prove nothing."""
+    world = _world()
+    o, d = _adversarial_rays(world, 2_000_000, seed=11)
+    monkeypatch.setenv("RTC_AMD_TRI_PRECULL", "0")
+    off = world.color_at(o, d, 4)
+    monkeypatch.setenv("RTC_AMD_TRI_PRECULL", "1")
+    monkeypatch.setenv("RTC_AMD_TRI_NAIVE", "1")
+    naive = world.color_at(o, d, 4)
+    differ = ((naive.view(np.uint32) != off.view(np.uint32)) & ~(np.isnan(naive) & np.isnan(off))).any(axis=1).sum()
+    print("rays changed by a naive cull: %d of %d" % (differ, len(o)))
+    assert differ > 0
