@@ -181,14 +181,26 @@ static bool world_extent(const rtc_object& o, double lo[3], double hi[3]) {
 }
 // The pre-culling box of one triangle (see tri_precull for the derivation of P); `d_world`: bound on the distance
 // between a pre-culling ray's origin and the triangle.  Leaves rec[0].w = 0 when no safe box exists.
-static void triangle_box(const rtc_object& o, const float4 tri[3], double d_world, double guard, double pad_scale, float4 rec[3]) {
+struct TransformFacts {  // of the last object's inverse transform: the triangles of a mesh share theirs
+    float inv[16];
+    bool valid = false, usable = false;
+    double F[9], f[3], s_max, s_min;  // object = A * world: object lengths are within [s_min, s_max] times world lengths
+};
+static void triangle_box(const rtc_object& o, const float4 tri[3], double d_world, double guard, double pad_scale, TransformFacts* tf,
+                         float4 rec[3]) {
     rec[0] = rec[1] = rec[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    double F[9], f[3];
-    if (!forward_affine(o.inv, F, f)) return;
-    const double A[9] = {o.inv[0], o.inv[1], o.inv[2], o.inv[4], o.inv[5], o.inv[6], o.inv[8], o.inv[9], o.inv[10]};
-    double s_max, s_min;  // object = A * world: object lengths are within [s_min, s_max] times world lengths
-    singular_range(A, &s_max, &s_min);
-    if (!(s_min > 0.0) || !std::isfinite(s_max)) return;
+    if (!tf->valid || std::memcmp(tf->inv, o.inv, sizeof(tf->inv)) != 0) {
+        std::memcpy(tf->inv, o.inv, sizeof(tf->inv));
+        tf->valid = true;
+        tf->usable = forward_affine(o.inv, tf->F, tf->f);
+        if (tf->usable) {
+            const double A[9] = {o.inv[0], o.inv[1], o.inv[2], o.inv[4], o.inv[5], o.inv[6], o.inv[8], o.inv[9], o.inv[10]};
+            singular_range(A, &tf->s_max, &tf->s_min);
+            tf->usable = tf->s_min > 0.0 && std::isfinite(tf->s_max);
+        }
+    }
+    if (!tf->usable) return;
+    const double *F = tf->F, *f = tf->f, s_max = tf->s_max, s_min = tf->s_min;
     const double kappa = s_max / s_min;
     // the triangle the kernel intersects: p1, p1 + e1, p1 + e2 with the stored (f32) edges
     const double p[3][3] = {{tri[0].x, tri[0].y, tri[0].z},
@@ -476,10 +488,11 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
             for (int a = 0; a < 3; a++) hdr->cull_c[a] = (float)(0.5 * (lo[a] + hi[a]));
             hdr->cull_r2 = (float)(radius * radius);
             tbox.assign(3 * (size_t)n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            TransformFacts tf;
             for (uint32_t i = 0; i < n; i++)
                 if (scene->objects[i].kind == RTC_TRIANGLE)
                     triangle_box(scene->objects[i], &(*soa)[12 * (size_t)np + 3 * (size_t)i], 2.0 * radius, TRI_GUARD, naive ? 0.0 : 1.0,
-                                 &tbox[3 * (size_t)i]);
+                                 &tf, &tbox[3 * (size_t)i]);
         }
     }
     // A flat world of many bounded objects gets a bounding-volume hierarchy of the library's own (see build_flat_bvh)
