@@ -937,9 +937,11 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
         // the limit -- three orders of magnitude more than those errors.
         uint32_t resume = 0;  // this lane ignores entries below `resume`
         for (uint32_t k = 0; k < H.n_trav;) {
-            // the three records are fetched together: a dependent fetch costs more than the 16 bytes
-            const float4 e0 = load_uniform(S.trav, TRAV_STRIDE * k), e1 = load_uniform(S.trav, TRAV_STRIDE * k + 1u),
-                         e2 = load_uniform(S.trav, TRAV_STRIDE * k + 2u);
+            // one address computation for the entry's three records (the walk executes as many scalar as vector instructions)
+            const ConstF4Ptr ep = ((ConstF4Ptr)(unsigned long)S.trav) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(TRAV_STRIDE * k));
+            const RawF4 r0 = ep[0], r1 = ep[1], r2 = ep[2];
+            const float4 e0 = make_float4(r0.x, r0.y, r0.z, r0.w), e1 = make_float4(r1.x, r1.y, r1.z, r1.w),
+                         e2 = make_float4(r2.x, r2.y, r2.z, r2.w);
             const bool active = k >= resume && wr.limit > -RTC_INF;
             if (!(e1.w < 0.0f)) {  // a group: e1.w is its slack (>= 0, inf or NaN); leaves carry -1
                 const uint32_t skip = __float_as_uint(e0.w);
