@@ -1031,6 +1031,7 @@ rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, 
     a.soa = soa_view(c->d_soa, c->hdr, c->d_texels);
     a.out = (float*)d_out_rgb;
     a.block_counts = c->d_block_counts;
+    a.total = c->d_total;
     a.rows = rows;
     a.band_rows = q.band_rows;
     a.n_parts = q.n_parts;
@@ -1060,7 +1061,8 @@ rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, 
     else if (c->n_objects <= 8) hipLaunchKernelGGL((render_kernel<8, false>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, 0, stream, a);
     HIP_TRY(hipEventRecord(ev.second, stream));
-    hipLaunchKernelGGL(sum_counts_kernel, dim3(1), dim3(1024), 0, stream, c->d_block_counts, (uint32_t)n_blocks, c->d_total);
+    hipLaunchKernelGGL(sum_counts_kernel, dim3((uint32_t)((n_blocks + SUM_COUNTS_SLICE - 1) / SUM_COUNTS_SLICE)), dim3(1024), 0, stream,
+                       c->d_block_counts, (uint32_t)n_blocks, c->d_total);
     HIP_TRY(hipGetLastError());
     c->rendered = true;
     return RTC_OK;
