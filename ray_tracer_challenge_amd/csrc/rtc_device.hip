@@ -420,7 +420,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     const uint32_t n = scene->n_objects;
     hdr->n_objects = n;
     const uint32_t np = padded_count(n);  // stride of each SoA array
-    soa->assign((size_t)19 * np, make_float4(0, 0, 0, 0));
+    soa->assign((size_t)20 * np, make_float4(0, 0, 0, 0));
     {
         uint32_t none = SHAPE_NONE;
         float none_f;
@@ -440,6 +440,20 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         pack_geometry(o, g);
         for (int k = 0; k < 4; k++) (*soa)[(size_t)k * np + i] = g[k];
         (*soa)[18 * (size_t)np + i] = make_float4(o.inv[3], o.inv[7], o.inv[11], 0.0f);
+        {
+            double lo[3], hi[3];  // bounding sphere: around the world-space box of the shape's own bounds
+            float4 bs = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
+            // (a cone's near-parallel branch, cone.rs:99-107, reports roots off the bounded cone: no sphere holds its hits)
+            if (o.kind != RTC_CONE && world_extent(o, lo, hi)) {
+                double r2 = 0.0;
+                for (int a = 0; a < 3; a++) r2 += 0.25 * (hi[a] - lo[a]) * (hi[a] - lo[a]);
+                bs = make_float4((float)(0.5 * (lo[0] + hi[0])), (float)(0.5 * (lo[1] + hi[1])), (float)(0.5 * (lo[2] + hi[2])),
+                                 (float)(1.001 * std::sqrt(r2)));
+                if (!std::isfinite(bs.x) || !std::isfinite(bs.y) || !std::isfinite(bs.z) || !std::isfinite(bs.w))
+                    bs = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
+            }
+            (*soa)[19 * (size_t)np + i] = bs;
+        }
         const rtc_material& m = o.material;
         (*soa)[4 * np + i] = make_float4(m.color[0], m.color[1], m.color[2], m.ambient);
         (*soa)[5 * np + i] = make_float4(m.diffuse, m.specular, m.shininess, m.reflective);
@@ -818,7 +832,8 @@ static SceneSoA soa_view(const float4* base, const SceneHdr& hdr, const float* d
     s.tri = base + 12 * (size_t)m;
     s.lcorn = base + 15 * (size_t)m;
     s.trn = base + 18 * (size_t)m;
-    s.trav = base + 19 * (size_t)m;
+    s.bsph = base + 19 * (size_t)m;
+    s.trav = base + 20 * (size_t)m;
     return s;
 }
 

@@ -533,6 +533,9 @@ struct SceneSoA {
     // { m03, m13, m23, 0 }: the translation column again, so that scale+translate-only objects need two records
     // (geo + trn = 32 B) instead of four
     const float4* __restrict__ trn;
+    // { centre.xyz, radius } of a world-space sphere around the object; radius = +inf for unbounded objects.  Approximate
+    // (margins apply): used to leave non-casters out of shadow tests when they lie behind every caster (light_cull_mask)
+    const float4* __restrict__ bsph;
     // Texture maps (pattern/uv.rs).  A TEXTURE_MAP / CUBE_MAP pattern's second record is { mapping, first UV pattern,
     // 0, 0 }; each UV pattern is six records in `uvrec`:
     //   { kind, width, height, first texel }, { image width, image height, 0, 0 }, then five RGB colours packed
@@ -1122,7 +1125,8 @@ DI void shadow_prepare(const SceneHdr& H, const SceneSoA& S, V3 p, ShadowPre* pr
 // loop-invariant uniform working set is 4 SGPRs per object and stays resident across the sample loop.
 constexpr uint32_t LIGHT_CULL_ALL_CASTERS = 0x80000000u;
 // `skip`: wave-uniform mask from light_cull_mask() -- objects that provably have no intersection at t >= 0 with
-// any ray from this shade point to the light; they cannot change either pass.
+// any ray from this shade point to the light, and non-casters that provably lie behind every caster left: neither
+// can change either pass.
 template <int NOBJ, bool SIMPLE>
 DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* pre, V3 lp, V3 p, Counters& cnt,
                         uint32_t skip) {
@@ -1280,7 +1284,39 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p) {
     }
     // no shadow caster can be reached from this shade point: every sample is lit whatever else is in the way
     // (world.rs:104-119 asks for the nearest hit to BE a caster), see intensity_at
-    if (!casters_left) mask |= LIGHT_CULL_ALL_CASTERS;
+    if (!casters_left) {
+        mask |= LIGHT_CULL_ALL_CASTERS;
+        return mask;
+    }
+    // Objects that cast no shadow (the demo's lampshade around its area light) matter to a shadow ray only by being hit
+    // BEFORE the nearest caster.  One that lies, as seen from p, wholly behind every caster still in play cannot be:
+    // nearest point of its bounding sphere farther than the farthest point of theirs, by 1e-3 (the computed hit
+    // distances are off by parts in 1e6).  It is then left out of this shade point's shadow tests like a culled object.
+    if (H.all_cast == 0u) {
+        float far_casters = 0.0f;  // per lane
+        auto reach = [&](uint32_t i, bool caster) {
+            const uint32_t bits = spec_bits(i, __float_as_uint(load_obj_static<NOBJ <= 0>(S, i).geo.w));
+            if ((bits & SHAPE_KIND_MASK) == SHAPE_NONE || ((bits & SHAPE_CASTS) != 0u) != caster || ((mask >> i) & 1u)) return;
+            const float4 b = S.bsph[i];  // wave-uniform
+            const V3 c = p - v3(b.x, b.y, b.z);
+            const float dist = sqrtf(dot3(c, c));
+            if (caster) {
+                far_casters = fmaxf(far_casters, dist + b.w);  // +inf for an unbounded caster (and NaN-safe: fmaxf keeps inf)
+                if (!(b.w < RTC_INF)) far_casters = RTC_INF;
+            } else if (__all(dist - b.w > 1.001f * far_casters + 1e-3f)) {
+                mask |= 1u << i;
+            }
+        };
+        if constexpr (NOBJ > 0) {
+#pragma unroll
+            for (uint32_t i = 0; i < (uint32_t)NOBJ; i++) reach(i, true);
+#pragma unroll
+            for (uint32_t i = 0; i < (uint32_t)NOBJ; i++) reach(i, false);
+        } else {
+            for (uint32_t i = 0; i < H.n_objects; i++) reach(i, true);
+            for (uint32_t i = 0; i < H.n_objects; i++) reach(i, false);
+        }
+    }
     return mask;
 }
 

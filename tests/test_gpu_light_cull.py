@@ -142,3 +142,33 @@ def test_dense_sweep_across_shadow_edges(jitter):
                 exp = ow.intensity_at(pts[i])
                 assert got[i] == exp, (jitter, len(objs), z, pts[i], got[i], exp)
             assert 0.0 < got.mean() < 1.0 or len(objs) == 2
+
+
+@pytest.mark.parametrize("jitter", [("hashed", 5), ("constant", 0.5)])
+def test_non_casters_in_front_of_and_behind_casters(jitter):
+    """A non-caster matters to a shadow ray only when it is hit before the nearest caster (world.rs:104-119 takes the
+    nearest hit of ALL objects and asks whether it casts).  The kernel leaves a non-caster out when its bounding sphere
+    lies behind every caster still in play as seen from the shade point: ghosts -- spheres, a slab like the demo's
+    lampshade, a bounded cylinder -- slide along the line from the floor to the light, through and past the casters."""
+    light = P.RectangleLight(P.color(1, 1, 1), P.point(-1.0, 6.0, -1.0), P.vector(2, 0, 0), 4, P.vector(0, 0, 2), 4, jitter)
+    floor = P.Plane(None, P.Material())
+    ball = P.Sphere(P.chain(P.translation(0.0, 2.0, 0.0), P.scaling(0.8, 0.8, 0.8)), P.Material())
+    box = P.Cube(P.chain(P.translation(1.6, 1.2, 0.4), P.scaling(0.4, 0.6, 0.4), P.rotation_y(f32(0.5))), P.Material())
+    xs = np.arange(-3.0, 3.0, 0.01, dtype=np.float64)
+    pts = np.stack([xs, np.full_like(xs, 1.19e-3), np.full_like(xs, 0.1), np.ones_like(xs)], axis=1).astype(f32)
+    lit_fraction = []
+    for h in (0.6, 1.3, 2.0, 2.9, 3.4, 4.5, 5.9, 6.5):  # below, inside, just above the casters; at and beyond the light
+        ghosts = [P.Sphere(P.chain(P.translation(0.1, h, 0.0), P.scaling(1.0, 0.3, 1.0)), P.Material(), casts_shadow=False),
+                  P.Cube(P.chain(P.translation(0.0, h + 0.2, 0.0), P.scaling(1.5, 0.01, 1.5)), P.Material(), casts_shadow=False),
+                  P.Cylinder(P.chain(P.translation(1.5, h, 0.3), P.scaling(0.5, 1.0, 0.5)), P.Material(), casts_shadow=False,
+                             minimum_y=-0.2, maximum_y=0.2, closed=True)]
+        for objs in ([floor, ball, box] + ghosts, [ball, ghosts[0], box, ghosts[1]]):
+            world = P.World(objs, light)
+            ow = H.oracle_world(world)
+            got = world.intensity_at(pts)
+            for i in range(pts.shape[0]):
+                ow.set_pixel(i)
+                exp = ow.intensity_at(pts[i])
+                assert got[i] == exp, (jitter, h, len(objs), pts[i], got[i], exp)
+            lit_fraction.append(float(got.mean()))
+    assert min(lit_fraction) < 0.9 and max(lit_fraction) > min(lit_fraction) + 0.02  # the ghosts do change the answer when in front
