@@ -1198,9 +1198,12 @@ DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* p
 // the object is simply kept).  Everything here is approximate arithmetic; NaNs fail every comparison and so
 // keep the object.  Spheres, cubes, bounded cylinders and planes under any affine transform are handled; cones,
 // unbounded cylinders and triangles are always kept.
+// `dark` (per lane): every sample of this shade point is shadowed -- it sits on the far side of a casting sphere, see
+// the end of per_object -- so intensity_at may answer 0 without a test.
 template <int NOBJ>
-DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p) {
+DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p, bool& dark) {
     uint32_t mask = 0;
+    dark = false;
     bool casters_left = false;  // wave-uniform
     // the samples stay inside the parallelogram only for jitter in [0, 1] (the hashed source draws from (0, 1])
     const bool hashed = spec_jitter_mode(H.jitter_mode) == RTC_JITTER_HASHED;
@@ -1254,7 +1257,8 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p) {
             const float oo = o.x * o.x + o.y * o.y + o.z * o.z;
             auto edge = [&](int k) { return corner(k) - o; };  // object-space vector from the shade point to corner k
             const V3 m = edge(0) + edge(2);                    // towards the parallelogram's centre: inside the pyramid
-            bool narrow = true, outside = false, leaving = true;
+            bool narrow = true, outside = false, leaving = true, entering = true;
+            const float c_own = oo - 1.0f;  // the sphere quadratic's constant term, as the exact test computes it
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const V3 e0 = edge(k), e1 = edge((k + 1) & 3);
@@ -1262,6 +1266,8 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p) {
                 narrow = narrow && me > 0.0f && me * me > 0.16f * dot3(m, m) * dot3(e0, e0);
                 const float oe = dot3(o, e0);  // corner direction at least ~3 degrees above the sphere's tangent plane at o
                 leaving = leaving && oe > 0.0f && oe * oe > 0.0025f * oo * dot3(e0, e0);
+                // corner direction at least ~2 sqrt(c) below the tangent plane, and the corner beyond the sphere's far side
+                entering = entering && oe < 0.0f && oe * oe > 4.2f * c_own * oo * dot3(e0, e0) && oe * oe > 4.84f * oo;
                 V3 n = cross3(e0, e1);
                 if (dot3(n, m) > 0.0f) n = -n;  // outward
                 const float h = -dot3(n, o);    // (distance of the origin outside face k) * |n|
@@ -1272,6 +1278,15 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p) {
             // c = |o|^2 - 1 > 0 and b = 2 pd.o > 0 both roots (-b -+ sqrt(b^2 - 4ac)) / 2a are negative, and by more
             // than rounding can undo because 4ac / b^2 >= c / (1 + c) >= 8e-5 (c is the exact test's own value).
             if (kind == RTC_SPHERE) cull = cull || (oo - 1.0f > 1e-4f && oo <= r2 && leaving);
+            // The mirror image: a shade point just outside a CASTING unit sphere whose whole light pyramid points into it.
+            // The directions to the samples are positive combinations of the corner directions, and {d : o.d <= -s |d|}
+            // is a convex cone, so every sample direction satisfies (o.d)^2 > 4.2 c |o|^2 |d|^2 with o.d < 0: the
+            // discriminant 4 ((o.d)^2 - |d|^2 c) is positive by three quarters of its value, the first root
+            // 2c / (|b| + sqrt(disc)) is positive (c > 1e-4 keeps the cancellation in (-b - sqrt(disc)) / 2a at parts in
+            // 1e3 of |b|), and it lies before the light because every sample is more than 2.2 radii beyond o along -o
+            // while the sphere ends within 2.1.  So is_shadowed finds a hit below `distance`; the nearest hit may belong
+            // to another object, but if that is a caster the answer is the same, and non-casters are dealt with below.
+            if (kind == RTC_SPHERE && (bits & SHAPE_CASTS) && c_own > 1e-4f && oo <= r2 && entering) dark = true;
         }
         if (__all(cull)) mask |= 1u << i;
         else if (bits & SHAPE_CASTS) casters_left = true;
@@ -1286,8 +1301,9 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p) {
     // (world.rs:104-119 asks for the nearest hit to BE a caster), see intensity_at
     if (!casters_left) {
         mask |= LIGHT_CULL_ALL_CASTERS;
-        return mask;
+        return mask;  // (dark is false for every lane: the sphere it sits behind would have been kept)
     }
+    bool noncasters_left = false;  // wave-uniform
     // Objects that cast no shadow (the demo's lampshade around its area light) matter to a shadow ray only by being hit
     // BEFORE the nearest caster.  One that lies, as seen from p, wholly behind every caster still in play cannot be:
     // nearest point of its bounding sphere farther than the farthest point of theirs, by 1e-3 (the computed hit
@@ -1305,6 +1321,8 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p) {
                 if (!(b.w < RTC_INF)) far_casters = RTC_INF;
             } else if (__all(dist - b.w > 1.001f * far_casters + 1e-3f)) {
                 mask |= 1u << i;
+            } else {
+                noncasters_left = true;
             }
         };
         if constexpr (NOBJ > 0) {
@@ -1317,6 +1335,7 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p) {
             for (uint32_t i = 0; i < H.n_objects; i++) reach(i, false);
         }
     }
+    if (noncasters_left) dark = false;  // a non-caster might be hit first
     return mask;
 }
 
@@ -1351,7 +1370,8 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
     // every shadow ray of this shade point starts at p: do the origin-only work once per object
     constexpr bool PRE = NOBJ > 0;
     ShadowPre pre[PRE ? NOBJ : 1];
-    const uint32_t skip = light_cull_mask<NOBJ>(H, S, p);  // before pre[] becomes live: the cull needs registers of its own
+    bool dark;
+    const uint32_t skip = light_cull_mask<NOBJ>(H, S, p, dark);  // before pre[] becomes live: the cull needs registers of its own
     if (skip & LIGHT_CULL_ALL_CASTERS) {
         // wave-uniform: no shadow caster is reachable, so each of the u_steps * v_steps is_shadowed() calls answers
         // "lit": total = 1.0 + ... + 1.0 = cells exactly (an integer below 2^24), and cells / cells = 1.0
@@ -1359,6 +1379,13 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
         cnt.rays += cells;
         cnt.shaded += cells << CNT_CULLED_SHIFT;  // statistics: rays answered without an object test
         return (float)cells / H.cells_f;
+    }
+    if (dark) {
+        // per lane: every is_shadowed() call answers "shadowed": total stays 0.0, and 0.0 / cells = 0.0
+        const uint32_t cells = (uint32_t)(H.u_steps * H.v_steps);
+        cnt.rays += cells;
+        cnt.shaded += cells << CNT_CULLED_SHIFT;
+        return 0.0f / H.cells_f;
     }
     if constexpr (PRE) shadow_prepare<NOBJ>(H, S, p, pre);
     float total = 0.0f;

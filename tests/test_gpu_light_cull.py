@@ -172,3 +172,35 @@ def test_non_casters_in_front_of_and_behind_casters(jitter):
                 assert got[i] == exp, (jitter, h, len(objs), pts[i], got[i], exp)
             lit_fraction.append(float(got.mean()))
     assert min(lit_fraction) < 0.9 and max(lit_fraction) > min(lit_fraction) + 0.02  # the ghosts do change the answer when in front
+
+
+@pytest.mark.parametrize("jitter", [("hashed", 8), ("constant", 1.0)])
+def test_points_on_the_far_side_of_a_casting_sphere(jitter):
+    """'Every sample blocked' is answered without a test for shade points just outside a casting sphere whose whole
+    light pyramid points into it.  Points at heights 1e-6 .. 0.3 radii all around spheres (round, squashed, rotated,
+    mirrored), with and without a non-caster that may be hit first, against the oracle."""
+    rng = np.random.default_rng(17)
+    light = P.RectangleLight(P.color(1, 1, 1), P.point(-1.5, 5.0, 3.0), P.vector(3, 0, 0), 5, P.vector(0, 2, 1), 4, jitter)
+    for k in range(6):
+        t = P.chain(P.translation(*rng.uniform(-1, 1, 3)), P.rotation_z(float(rng.uniform(-3, 3))),
+                    P.scaling(*[float(s) for s in rng.uniform(0.3, 1.5, 3) * rng.choice([1.0, 1.0, -1.0], 3)]))
+        ball = P.Sphere(t, P.Material())
+        objs = [ball, P.Plane(P.translation(0.0, -3.0, 0.0), P.Material())]
+        if k % 3 == 1:   # a non-caster hugging the ball: may be hit first, the closed form must stand down
+            objs.append(P.Sphere(P.chain(t, P.scaling(1.05, 1.05, 1.05)), P.Material(), casts_shadow=False))
+        if k % 3 == 2:   # a non-caster far behind: left out, the closed form applies
+            objs.append(P.Cube(P.chain(P.translation(0.0, 5.5, 3.5), P.scaling(2.0, 1.5, 0.01)), P.Material(), casts_shadow=False))
+        n = 4000
+        d = rng.normal(size=(n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        h = 10.0 ** rng.uniform(-6, -0.5, (n, 1))
+        local = np.concatenate([d * (1.0 + h), np.ones((n, 1))], axis=1)
+        pts = (np.asarray(t, dtype=np.float64) @ local.T).T.astype(f32)
+        world = P.World(objs, light)
+        ow = H.oracle_world(world)
+        got = world.intensity_at(pts)
+        for i in range(n):
+            ow.set_pixel(i)
+            exp = ow.intensity_at(pts[i])
+            assert got[i] == exp, (jitter, k, pts[i], got[i], exp)
+        assert (got == 0.0).mean() > 0.2 and (got == 1.0).mean() > 0.2
