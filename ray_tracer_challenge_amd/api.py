@@ -26,8 +26,20 @@ def _a(x, n=None):
     return arr
 
 
+_FLOAT_ARRAYS = {}
+
+
 def _p(arr):
-    return arr.ctypes.data_as(L.FP)
+    """float* for a contiguous float32 array (a ctypes array sharing its buffer: a third of data_as's cost, which
+    dominates building a mesh through this API)."""
+    n = arr.size
+    t = _FLOAT_ARRAYS.get(n)
+    if t is None:
+        t = _FLOAT_ARRAYS[n] = C.c_float * n
+    try:
+        return t.from_buffer(arr)
+    except (TypeError, ValueError):  # read-only or empty buffers
+        return arr.ctypes.data_as(L.FP)
 
 
 # ------------------------------------------------------------- tuple.rs, color.rs
@@ -524,7 +536,22 @@ def _shape_bounds(shape, parent_space):
 
 # Shape::bounding_box / parent_space_bounding_box (shape.rs:23,162-164); divide is a no-op for leaves (:167)
 Shape.bounding_box = lambda self: _shape_bounds(self, False)
-Shape.parent_space_bounding_box = lambda self: _shape_bounds(self, True)
+
+
+def _parent_space_bounds_cached(self):
+    """divide() asks every leaf for its parent-space box once per level of the tree; the answer is a pure function
+    of what is keyed on here, so it is computed once (a 100 k-triangle mesh otherwise spends its build time here)."""
+    pts = self.points
+    key = (self.transform.tobytes(), self.kind, float(self.minimum_y), float(self.maximum_y),
+           None if pts is None else tuple(np.asarray(q, dtype=f32).tobytes() for q in pts))
+    hit = getattr(self, "_psbb", None)
+    if hit is None or hit[0] != key:
+        hit = (key, _shape_bounds(self, True))
+        self._psbb = hit
+    return BoundingBox(hit[1].min.copy(), hit[1].max.copy())
+
+
+Shape.parent_space_bounding_box = _parent_space_bounds_cached
 Shape.divide = lambda self, threshold: None
 Shape.transformation = lambda self: self.transform
 
