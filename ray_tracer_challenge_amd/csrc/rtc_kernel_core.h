@@ -1197,7 +1197,7 @@ DI bool is_shadowed_pre(const SceneHdr& H, const SceneSoA& S, const ShadowPre* p
 // is known, and therefore cannot change the image -- PROVIDED a culled object really yields no hit in the exact
 // f32 evaluation.  That is ensured by margins far above the evaluation's rounding error (DESIGN.md "Light-cone
 // culling"): the test works in the object's own space (where the exact quadratic is evaluated) with the unit
-// sphere / cube blown up by 10 % in radius, the cone of directions widened by 1e-3 in cosine, and it is only
+// sphere / cube blown up by 3 % in radius (LIGHT_CULL_INFLATE2), the cone of directions widened by 1e-3 in cosine, and it is only
 // trusted when the shade point is within 100 radii (beyond that the quadratic's cancellation error grows and
 // the object is simply kept).  Everything here is approximate arithmetic; NaNs fail every comparison and so
 // keep the object.  Spheres, cubes, bounded cylinders and planes under any affine transform are handled; cones,
@@ -1221,7 +1221,7 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p, bool& da
         const uint32_t bits = ob.bits;
         const uint32_t kind = bits & SHAPE_KIND_MASK;
         if (kind == SHAPE_NONE) return;
-        // Bounding sphere of the shape in its own space (centre = origin), inflated by 10 %.  Every intersection
+        // Bounding sphere of the shape in its own space (centre = origin), inflated by 3 % (LIGHT_CULL_INFLATE2).  Every intersection
         // these kinds report lies on the shape.  (Not so for cones -- the near-parallel branch, cone.rs:99-107,
         // returns a root of the unbounded double cone without a range check -- nor for unbounded cylinders;
         // triangles are kept as well.)
