@@ -89,6 +89,7 @@ def test_coincident_objects_resolve_ties_by_list_order(monkeypatch):
 
 def test_flat_bvh_eligibility(monkeypatch):
     monkeypatch.setenv("RTC_AMD_BVH", "1")
+    monkeypatch.setenv("RTC_AMD_SPECIALIZE", "0")
     world, camera = _cloud(7, 20)
     assert Renderer(world, camera, device=0).kernel_name == "render_kernel<tree,bvh>"
     monkeypatch.setenv("RTC_AMD_SPECIALIZE", "1")
