@@ -1,0 +1,8 @@
+#!/bin/bash
+# development: A/B of a macro-guarded kernel change through the scene-compiled kernels, interleaved on one box
+#   tools/ab_jit.sh "-DRTC_NO_ECLIPSE" soft_shadows 4096
+FLAGS="$1"; shift
+for r in 1 2 3; do
+  RTC_AMD_JIT_FLAGS="$FLAGS" python tools/time_scene.py "$@" 20 2>&1 | grep -v amdgpu.ids | sed "s/^/[with $FLAGS] /"
+  python tools/time_scene.py "$@" 20 2>&1 | grep -v amdgpu.ids | sed "s/^/[default] /"
+done
