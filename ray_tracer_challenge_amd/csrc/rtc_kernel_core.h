@@ -696,8 +696,19 @@ DI void local_intersect_c(uint32_t bits, float min_y, float max_y, const float4*
         if (!(disc < 0.0f)) {
             float two_a = 2.0f * a;
             float sq = sqrtf(disc);
-            f((-b - sq) / two_a);
-            f((-b + sq) / two_a);
+#ifndef RTC_NO_LAZY_ROOT
+            if constexpr (HITS_ONLY) {
+                // t1 <= t2 (two_a > 0, sq >= 0), and a caller that only looks at distances >= 0 takes the smaller of those:
+                // t1 if it is >= 0 -- which it is exactly when its numerator is (-0 included) -- and t2 otherwise.  One
+                // IEEE division instead of two; the quotient evaluated is the very one the reference would have used.
+                const float n1 = -b - sq;
+                f((n1 >= 0.0f ? n1 : -b + sq) / two_a);
+            } else
+#endif
+            {
+                f((-b - sq) / two_a);
+                f((-b + sq) / two_a);
+            }
         }
     } else if (kind == RTC_PLANE) {  // plane.rs:45-56
         if (!(fabsf(d.y) < PLANE_EPS)) {
