@@ -916,7 +916,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     char nm[96];
     snprintf(nm, sizeof(nm), "render_kernel<%d,%s>", n <= 4 ? 4 : n <= 8 ? 8 : 0, (n <= 8 && c->simple) ? "simple" : "general");
     c->kernel_name = nm;
-    if (hdr.n_trav) {  // GroupShapes: packet traversal of the group tree; no per-scene specialisation
+    if (hdr.n_trav) {  // a traversal stream (GroupShapes, or the library's own hierarchy): packet walk, compiled per scene like the flat kernels
         const std::string how = scene->n_groups ? "tree" : "tree,bvh";
         c->kernel_name = "render_kernel<" + how + ">";
         const int policy = specialise_policy();
