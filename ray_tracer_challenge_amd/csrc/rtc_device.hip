@@ -572,7 +572,22 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         }
         if (gi != scene->n_groups)
             return fail(RTC_ERR_INVALID_ARG, "group %u: groups must be listed in pre-order with first_object inside [0, n_objects)", gi);
-        if (any) {
+        // A small tree (<= 8 leaves under <= 8 groups) keeps the unrolled flat kernels: every group becomes a GATE -- its box,
+        // tested once per ray with the reference's own aabb test -- and a leaf is intersected only if the ray opens all the
+        // groups around it, which is all the recursive walk does (group.rs:115-133).  Same leaves in the same order.
+        uint32_t n_gates = 0;
+        for (uint32_t g = 0; g < scene->n_groups; g++) n_gates += scene->groups[g].n_objects != 0;
+        if (any && n <= 8 && n_gates <= RTC_MAX_GATES && env_flag("RTC_AMD_GATES", true)) {
+            uint32_t k = 0;
+            for (uint32_t g = 0; g < scene->n_groups; g++) {
+                const rtc_group& grp = scene->groups[g];
+                if (grp.n_objects == 0) continue;
+                for (int a = 0; a < 3; a++) hdr->gate_box[k][a] = grp.bounds_min[a], hdr->gate_box[k][3 + a] = grp.bounds_max[a];
+                for (uint32_t i = grp.first_object; i < grp.first_object + grp.n_objects; i++) hdr->gate_mask[i] |= 1u << k;
+                k++;
+            }
+            hdr->n_gates = n_gates;
+        } else if (any) {
             hdr->n_trav = (uint32_t)(trav.size() / TRAV_STRIDE);
             soa->insert(soa->end(), trav.begin(), trav.end());
         }
@@ -968,12 +983,14 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         defs.push_back("-DRTC_SPEC_LIGHT_KIND=" + std::to_string(hdr.light_kind));
         defs.push_back("-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode));
         defs.push_back(std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0"));
+        defs.push_back(std::string("-DRTC_SPEC_GATES=") + (hdr.n_gates ? "1" : "0"));
         rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
         if (jst != RTC_OK) {
             if (policy == 1) return jst;  // explicitly requested: report
             c->spec_fn = nullptr;         // auto: the ahead-of-time kernel computes the same image
         } else {
-            c->kernel_name = "render_kernel_spec[" + list.substr(16) + (c->simple ? ";simple" : "") + (hdr.has_patterns ? ";patterns" : "") + "]";
+            c->kernel_name = "render_kernel_spec[" + list.substr(16) + (c->simple ? ";simple" : "") + (hdr.has_patterns ? ";patterns" : "") +
+                             (hdr.n_gates ? ";gates" : "") + "]";
         }
     } else if (n > 8 && (policy == 1 || (policy == 2 && pixels >= (1ull << 18)))) {
         // many objects that all share one kind / flags word (C5: 64 scale+translate spheres): the any-count loop with

@@ -494,7 +494,13 @@ struct SceneHdr {
     uint32_t has_tbox;
     float cull_c[3], cull_r2;
     float tri_guard;  // TRI_GUARD (the boxes' padding is derived from it on the host)
+    // Small trees in the unrolled kernels (rtc_device.hip flatten): group boxes as gates.  gate_box[g] = min.xyz, max.xyz;
+    // bit g of gate_mask[i]: object i sits inside group g and is only intersected by rays that hit g's box
+    uint32_t n_gates;
+    float gate_box[8][6];
+    uint32_t gate_mask[8];
 };
+constexpr uint32_t RTC_MAX_GATES = 8;
 
 // Structure-of-arrays scene records in HBM: 4 float4 of geometry (64 B) and
 // 3 float4 of material (48 B) per object.  Every lane of a wave reads the same
@@ -576,11 +582,17 @@ DI uint32_t spec_bits(uint32_t i, uint32_t) {
 DI int32_t spec_light_kind(int32_t) { return RTC_SPEC_LIGHT_KIND; }
 DI int32_t spec_jitter_mode(int32_t) { return RTC_SPEC_JITTER; }
 DI bool spec_has_patterns(uint32_t) { return RTC_SPEC_PATTERNS != 0; }
+#ifdef RTC_SPEC_GATES
+DI bool spec_has_gates(uint32_t) { return RTC_SPEC_GATES != 0; }
+#else
+DI bool spec_has_gates(uint32_t n) { return n != 0; }
+#endif
 #else
 DI uint32_t spec_bits(uint32_t, uint32_t runtime_bits) { return runtime_bits; }
 DI int32_t spec_light_kind(int32_t k) { return k; }
 DI int32_t spec_jitter_mode(int32_t m) { return m; }
 DI bool spec_has_patterns(uint32_t h) { return h != 0; }
+DI bool spec_has_gates(uint32_t n) { return n != 0; }
 #endif
 
 constexpr float PLANE_EPS = 1.1920929e-7f * 10000.0f;  // plane.rs:49  f32::EPSILON * 10000.0
@@ -884,6 +896,7 @@ struct WorldRay {
     float limit;
     V3 d;
     float guard;  // TRI_GUARD * |d|, or +inf when this ray may not pre-cull triangles (see tri_precull)
+    uint32_t closed;  // unrolled kernels with gates: the groups whose box this ray misses (SceneHdr::gate_mask)
 };
 constexpr float TRI_GUARD = 0.05f;  // sine of the smallest ray-to-plane angle at which a triangle may be pre-culled
 template <int NOBJ>
@@ -891,11 +904,22 @@ DI WorldRay world_ray(const SceneHdr& H, V3 o, V3 d) {
     if constexpr (NOBJ < 0) {
         const V3 c = o - v3(H.cull_c[0], H.cull_c[1], H.cull_c[2]);
         const bool near = H.has_tbox != 0u && dot3(c, c) <= H.cull_r2;  // NaN: false
-        return {o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), RTC_INF, d, near ? H.tri_guard * sqrtf(dot3(d, d)) : RTC_INF};
+        return {o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), RTC_INF, d, near ? H.tri_guard * sqrtf(dot3(d, d)) : RTC_INF, 0u};
     } else {
-        return {o, o, RTC_INF, o, RTC_INF};  // unused
+        WorldRay wr = {o, o, RTC_INF, o, RTC_INF, 0u};  // unused but for `closed`
+        if (NOBJ > 0 && spec_has_gates(H.n_gates)) {
+            const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // ray.rs:16
+            for (uint32_t g = 0; g < H.n_gates; g++) {
+                float tmin;
+                const float* b = H.gate_box[g];
+                if (!aabb_hit(o, inv, make_float4(b[0], b[1], b[2], 0.0f), make_float4(b[3], b[4], b[5], 0.0f), tmin)) wr.closed |= 1u << g;
+            }
+        }
+        return wr;
     }
 }
+// a WorldRay for loops that run over ALL objects whatever their groups (per-shade-point preparation)
+DI WorldRay ungated_ray(V3 o) { return {o, o, RTC_INF, o, RTC_INF, 0u}; }
 
 // Tree walks meet long runs of triangle leaves (the reference's divide() keeps every child that straddles the split
 // plane in the parent group: a closed mesh leaves a ring of them at every level), and the exact test costs ~150
@@ -978,7 +1002,10 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
         // no `i < n_objects` guard: the record arrays are padded with SHAPE_NONE entries, so every
         // load is unconditional and can be hoisted / issued ahead of the arithmetic that needs it
 #pragma unroll
-        for (uint32_t i = 0; i < (uint32_t)NOBJ; i++) body(i);
+        for (uint32_t i = 0; i < (uint32_t)NOBJ; i++) {
+            if (spec_has_gates(H.n_gates) && (H.gate_mask[i & 7u] & wr.closed) != 0u) continue;  // inside a group this ray does not open
+            body(i);
+        }
     } else {
         // any object count: the record arrays are padded to a multiple of 8 with SHAPE_NONE entries (skipped by
         // the bodies), so the loop advances four records at a time and their loads are issued together
@@ -1115,7 +1142,7 @@ struct ShadowPre {
 template <int NOBJ>
 DI void shadow_prepare(const SceneHdr& H, const SceneSoA& S, V3 p, ShadowPre* pre) {
     static_assert(NOBJ > 0, "flat unrolled scenes only");
-    WorldRay wr = world_ray<NOBJ>(H, p, p);
+    WorldRay wr = ungated_ray(p);
     for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) {
         Obj ob = load_obj_static<NOBJ <= 0>(S, i);
         pre[i].o = obj_point(ob, p);

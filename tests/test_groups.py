@@ -277,3 +277,78 @@ def test_malformed_groups_are_refused():
     cs.groups[0].first_object = 1
     cs.groups[6].first_object = 40       # outside the object list
     assert render() == L.RTC_ERR_INVALID_ARG
+
+
+def _small_tree_world(seed, area_light):
+    """<= 8 leaves under <= 8 (nested) groups, some leaves outside any group: the case the unrolled kernels take with
+    the groups' boxes as gates."""
+    rng = np.random.default_rng(seed)
+
+    def leaf():
+        kind = rng.choice(["sphere", "cube", "cylinder", "sphere"])
+        t = P.chain(P.translation(*[float(v) for v in rng.uniform(-2.0, 2.0, 3)]), P.rotation_y(float(rng.uniform(-3, 3))),
+                    P.scaling(*[float(v) for v in rng.uniform(0.3, 0.9, 3)]))
+        u = rng.random()
+        m = P.Material(color=tuple(rng.uniform(0.2, 1.0, 3)), reflective=0.4 if u < 0.3 else 0.0,
+                       transparency=0.7 if 0.3 <= u < 0.55 else 0.0, refractive_index=1.4)
+        if kind == "cylinder":
+            return P.Cylinder(t, m, minimum_y=-1.0, maximum_y=1.0, closed=bool(rng.random() < 0.5), casts_shadow=bool(rng.random() < 0.8))
+        return (P.Sphere if kind == "sphere" else P.Cube)(t, m, casts_shadow=bool(rng.random() < 0.8))
+
+    def group(depth, budget):
+        g = P.GroupShape()
+        g.set_transformation(P.chain(P.translation(*[float(v) for v in rng.uniform(-0.5, 0.5, 3)]), P.rotation_z(float(rng.uniform(-0.5, 0.5)))))
+        n = int(rng.integers(1, 4))
+        for _ in range(n):
+            if budget[0] <= 0:
+                break
+            if depth < 2 and rng.random() < 0.35 and budget[1] > 0:
+                budget[1] -= 1
+                g.add_child(group(depth + 1, budget))
+            else:
+                budget[0] -= 1
+                g.add_child(leaf())
+        return g
+
+    budget = [int(rng.integers(3, 8)), 5]  # leaves, groups
+    objs = [P.Plane(P.translation(0.0, -2.5, 0.0), P.Material(color=(0.8, 0.8, 0.8), reflective=0.2))]
+    while budget[0] > 0:
+        if rng.random() < 0.7 and budget[1] > 0:
+            budget[1] -= 1
+            objs.append(group(0, budget))
+        else:
+            budget[0] -= 1
+            objs.append(leaf())
+    if area_light:
+        light = P.RectangleLight(P.color(1, 1, 1), P.point(-2, 5, -4), P.vector(2, 0, 0), 3, P.vector(0, 1, 1), 3, ("hashed", seed))
+    else:
+        light = P.PointLight(P.point(-4, 7, -6), P.color(1, 1, 1))
+    camera = P.Camera(120, 90, float(np.pi / 3), P.view_transform(P.point(0.5, 2.0, -7.5), P.point(0, 0, 0), P.vector(0, 1, 0)))
+    return P.World(objs, light), camera
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("specialise", ["0", "1"])
+def test_small_trees_through_the_unrolled_kernels(seed, specialise, monkeypatch):
+    """Group boxes as gates (rtc_device.hip flatten / SceneHdr::gate_mask) against the oracle's recursive walk and
+    against the traversal kernel (RTC_AMD_GATES=0)."""
+    from ray_tracer_challenge_amd.renderer import Renderer
+    world, camera = _small_tree_world(seed, area_light=seed % 2 == 0)
+    n_leaves = len(world._c().leaves)
+    assert n_leaves <= 8
+    monkeypatch.setenv("RTC_AMD_SPECIALIZE", specialise)
+    out = {}
+    for gates in ("1", "0"):
+        monkeypatch.setenv("RTC_AMD_GATES", gates)
+        r = Renderer(world, camera, device=0)
+        has_groups = any(isinstance(o, P.GroupShape) and o.leaves() for o in world.objects)
+        if has_groups:
+            assert ("tree" in r.kernel_name) == (gates == "0"), r.kernel_name
+        out[gates] = (r.render(4).cpu().numpy(), r.stats())
+        r.close()
+    exp, rays = H.oracle_camera(camera).render(H.oracle_world(world), 4, threads=8)
+    for gates in ("1", "0"):
+        H.assert_images_equal(out[gates][0], exp, "seed %d gates=%s" % (seed, gates))
+        assert out[gates][1]["rays"] == rays
+    assert out["1"][1]["shaded_hits"] == out["0"][1]["shaded_hits"]
