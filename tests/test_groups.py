@@ -352,3 +352,43 @@ def test_small_trees_through_the_unrolled_kernels(seed, specialise, monkeypatch)
         H.assert_images_equal(out[gates][0], exp, "seed %d gates=%s" % (seed, gates))
         assert out[gates][1]["rays"] == rays
     assert out["1"][1]["shaded_hits"] == out["0"][1]["shaded_hits"]
+
+
+def _stale_box_objects(api, many):
+    """group.rs:15,138-151: a group's bounding box is cached on first use and never invalidated.  A child added AFTER
+    that lies outside the box the group keeps testing rays against: it is visible only to rays that also pass
+    through the stale box.  The one place where a group's box visibly decides what a ray sees."""
+    g = api.GroupShape()
+    g.add_child(api.Sphere(api.translation(-1.5, 0.0, 0.0), api.Material(color=(1, 0.2, 0.2))))
+    g.bounding_box()  # cached here: around the first sphere only
+    g.add_child(api.Sphere(api.chain(api.translation(1.2, 0.4, 0.0), api.scaling(1.3, 1.3, 1.3)), api.Material(color=(0.2, 1, 0.2))))
+    g.add_child(api.Cube(api.chain(api.translation(-1.5, 1.8, 0.5), api.scaling(0.5, 0.5, 0.5)), api.Material(color=(0.2, 0.2, 1), reflective=0.3)))
+    objs = [g, api.Plane(api.translation(0.0, -1.0, 0.0), api.Material(color=(0.9, 0.9, 0.9), reflective=0.3))]
+    if many:  # more than 8 leaves: the traversal kernel
+        for k in range(7):
+            objs.append(api.Sphere(api.chain(api.translation(-4.0 + k * 1.3, -0.6, 3.0), api.scaling(0.4, 0.4, 0.4)), api.Material()))
+    return objs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("many", [False, True])
+def test_a_stale_cached_box_hides_late_children_like_the_reference(many, monkeypatch):
+    from ray_tracer_challenge_amd.renderer import Renderer
+    light = ((-5.0, 8.0, -6.0), (1.0, 1.0, 1.0))
+    camera = P.Camera(160, 120, float(np.pi / 3), P.view_transform(P.point(0, 1.0, -7), P.point(0, 0.3, 0), P.vector(0, 1, 0)))
+    world = P.World(_stale_box_objects(P, many), P.PointLight(P.point(*light[0]), P.color(*light[1])))
+    own = O.World(_stale_box_objects(O, many), O.PointLight(np.array(light[0] + (1.0,), dtype=f32), np.array(light[1], dtype=f32)))
+    exp, rays = H.oracle_camera(camera).render(own, 3, threads=8)
+    fresh = P.World(_stale_box_objects(P, many), world.light)
+    fresh.objects[0]._cached_box = None  # what the scene would look like if the box were recomputed
+    modes = ("1", "0") if not many else ("1",)
+    for gates in modes:
+        monkeypatch.setenv("RTC_AMD_GATES", gates)
+        r = Renderer(world, camera, device=0)
+        assert ("tree" in r.kernel_name) == (many or gates == "0"), r.kernel_name
+        img = r.render(3).cpu().numpy()
+        H.assert_images_equal(img, exp, "stale box, gates=%s many=%s" % (gates, many))
+        assert r.stats()["rays"] == rays
+        r.close()
+        seen = Renderer(fresh, camera, device=0).render(3).cpu().numpy()
+        assert (seen != img).any(axis=2).mean() > 0.02  # the late children really are hidden from most rays
