@@ -1301,6 +1301,17 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p, bool& da
             const V3 m = edge(0) + edge(2);                    // towards the parallelogram's centre: inside the pyramid
             bool narrow = true, outside = false, leaving = true, entering = true;
             const float c_own = oo - 1.0f;  // the sphere quadratic's constant term, as the exact test computes it
+            // Cubes and bounded cylinders: their own box [-1, 1] x [min_y, max_y] x [-1, 1] instead of the sphere around it
+            // (a tall cylinder's sphere swallows the floor it stands on), inflated by 3 % of each half extent (+1e-4 of the
+            // bounds): a face plane separates the box when the box centre lies further out than the box's half width
+            // along the plane's normal.  Every intersection these kinds report lies in the box (cylinder.rs: both roots
+            // are range-checked against min_y / max_y, the caps against the radius; cube.rs: the slabs themselves).
+            const bool boxy = kind == RTC_CUBE || kind == RTC_CYLINDER;  // wave-uniform
+            float cy = 0.0f, hy = 1.03f;
+            if (kind == RTC_CYLINDER) {
+                cy = 0.5f * (ob.min_y() + ob.max_y());
+                hy = 1.03f * (0.5f * (ob.max_y() - ob.min_y())) + 1e-4f * (fabsf(ob.min_y()) + fabsf(ob.max_y()) + 1.0f);
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const V3 e0 = edge(k), e1 = edge((k + 1) & 3);
@@ -1313,9 +1324,10 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p, bool& da
                 V3 n = cross3(e0, e1);
                 if (dot3(n, m) > 0.0f) n = -n;  // outward
                 const float h = -dot3(n, o);    // (distance of the origin outside face k) * |n|
-                outside = outside || (h > 0.0f && h * h > 1.01f * r2 * dot3(n, n));
+                if (boxy) outside = outside || h + n.y * cy > 1.005f * (1.03f * (fabsf(n.x) + fabsf(n.z)) + hy * fabsf(n.y));
+                else outside = outside || (h > 0.0f && h * h > 1.01f * r2 * dot3(n, n));
             }
-            cull = oo > r2 && oo < 1e4f * r2 && narrow && outside;
+            cull = (boxy || oo > r2) && oo < 1e4f * r2 && narrow && outside;
             // A shade point sitting just outside the unit sphere whose whole light pyramid points away from it: with
             // c = |o|^2 - 1 > 0 and b = 2 pd.o > 0 both roots (-b -+ sqrt(b^2 - 4ac)) / 2a are negative, and by more
             // than rounding can undo because 4ac / b^2 >= c / (1 + c) >= 8e-5 (c is the exact test's own value).
