@@ -246,6 +246,18 @@ static std::string tree_jit_waves() {
     return (e && *e >= '1' && *e <= '8' && !e[1]) ? std::string(e) : std::string("6");
 }
 
+// Lanes per pixel (RenderArgs::share_log2): only an area light has work to share; more lanes per pixel while the frame
+// would otherwise be fewer than ~4 waves per SIMD.  RTC_AMD_SHARE_LOG2=0..3 overrides.
+static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows) {
+    if (hdr.light_kind != RTC_LIGHT_RECT || hdr.u_steps * hdr.v_steps < 8) return 0u;
+    if (const char* e = std::getenv("RTC_AMD_SHARE_LOG2"))
+        if (e[0] >= '0' && e[0] <= '3' && !e[1]) return (uint32_t)(e[0] - '0');
+    const uint64_t waves = ((uint64_t)hdr.width * rows + 63) / 64;
+    uint32_t s = 0;
+    while (s < 3u && (waves << s) < 24576u) s++;
+    return s;
+}
+
 static bool env_flag(const char* name, bool dflt) {
     const char* e = std::getenv(name);
     return (e && *e) ? e[0] != '0' : dflt;
@@ -688,6 +700,7 @@ struct rtc_ctx {
     unsigned long long* d_ppm_rows = nullptr;  // per-row length, then offset; [h] is the total
     uint32_t* d_ppm_bits = nullptr;
     size_t ppm_rows_cap = 0, ppm_bits_cap = 0;
+    bool spec_shares = false;         // spec_fn was compiled with -DRTC_SPEC_SHARE=1
     hipFunction_t spec_fn = nullptr;  // scene-specialised kernel (hiprtc), or null: ahead-of-time kernels
     std::string kernel_name;          // what rtc_ctx_render launches, for rtc_ctx_kernel_name()
     uint4* d_block_counts = nullptr;
@@ -927,6 +940,9 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     c->has_scene = true;
     // which kernel will render this scene
     c->spec_fn = nullptr;
+    // sample-parallel rendering (render_body): compiled in when this frame is small enough to want it
+    c->spec_shares = choose_share_log2(hdr, hdr.height) != 0u;
+    const std::string share_def = std::string("-DRTC_SPEC_SHARE=") + (c->spec_shares ? "1" : "0");
     const uint32_t n = hdr.n_objects;
     char nm[96];
     snprintf(nm, sizeof(nm), "render_kernel<%d,%s>", n <= 4 ? 4 : n <= 8 ? 8 : 0, (n <= 8 && c->simple) ? "simple" : "general");
@@ -954,10 +970,12 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
                                              "-DRTC_SPEC_LIGHT_KIND=" + std::to_string(hdr.light_kind),
                                              "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
                                              std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
+            defs.push_back(share_def);
             rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
             if (jst != RTC_OK) {
                 if (policy == 1) return jst;
                 c->spec_fn = nullptr;
+                c->spec_shares = false;
             } else {
                 c->kernel_name = std::string("render_kernel_spec[") + how + (uniform ? std::string(";all ") + b : std::string()) +
                                  (hdr.has_patterns ? ";patterns" : "") + "]";
@@ -984,7 +1002,8 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         defs.push_back("-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode));
         defs.push_back(std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0"));
         defs.push_back(std::string("-DRTC_SPEC_GATES=") + (hdr.n_gates ? "1" : "0"));
-        rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
+        defs.push_back(share_def);
+            rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
         if (jst != RTC_OK) {
             if (policy == 1) return jst;  // explicitly requested: report
             c->spec_fn = nullptr;         // auto: the ahead-of-time kernel computes the same image
@@ -1011,10 +1030,12 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
                                              "-DRTC_SPEC_LIGHT_KIND=" + std::to_string(hdr.light_kind),
                                              "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
                                              std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
+            defs.push_back(share_def);
             rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
             if (jst != RTC_OK) {
                 if (policy == 1) return jst;
                 c->spec_fn = nullptr;
+                c->spec_shares = false;
             } else {
                 c->kernel_name = std::string("render_kernel_spec[all ") + b + (hdr.has_patterns ? ";patterns" : "") + "]";
             }
@@ -1033,7 +1054,9 @@ rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, 
     const uint32_t rows = partition_rows(c->hdr.height, part);
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(c->device));
-    dim3 grid((c->hdr.width + 15) / 16, (rows + 15) / 16), block(256);
+    const uint32_t share_log2 = (c->spec_fn && c->spec_shares) ? choose_share_log2(c->hdr, rows) : 0u;  // only kernels compiled for it share lanes
+    const uint32_t bw = 16u >> (share_log2 >> 1), bh = 16u >> ((share_log2 + 1u) >> 1);  // pixels per workgroup (2x2 wave tiles)
+    dim3 grid((c->hdr.width + bw - 1) / bw, (rows + bh - 1) / bh), block(256);
     const size_t n_blocks = (size_t)grid.x * grid.y;
     if (n_blocks > c->block_cap) {  // grow-only workspace (first call / larger image only)
         if (c->d_block_counts) HIP_TRY(hipFree(c->d_block_counts));
@@ -1069,6 +1092,7 @@ rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, 
     a.n_parts = q.n_parts;
     a.part = q.part;
     a.depth = depth;
+    a.share_log2 = share_log2;
     if (c->events_used == c->events.size()) {
         if (c->events.size() >= 4096) {
             c->events_used = 0;  // nobody is reading the timings: recycle

@@ -870,6 +870,22 @@ struct Counters {
     uint32_t rays;    // World::intersect evaluations
     uint32_t shaded;  // bits 0..11: shade_hit evaluations (<= 2^depth per pixel); bits 12..31: of `rays`, the shadow
                       // rays answered by the light-cone cull without testing any object (<= 2^depth * cells)
+    // Sample-parallel rendering (render_body): 2^share_log2 adjacent lanes trace the SAME pixel and split the area light's
+    // cells between them.  Wave-uniform.  Everything but the shadow rays is then computed identically by all of a
+    // pixel's lanes and counted by the first of them only.
+    // Compiled in only where it is used (-DRTC_SPEC_SHARE=1, hiprtc): with SHARE_LANES false everything below folds to
+    // "one lane per pixel" (the 4096^2 headline kernel is 3 % slower with the general form).
+    uint32_t share_log2_;
+#if defined(RTC_SPEC_SHARE) && RTC_SPEC_SHARE
+    static constexpr bool SHARE_LANES = true;
+#else
+    static constexpr bool SHARE_LANES = false;
+#endif
+    DI uint32_t share_log2() const { return SHARE_LANES ? share_log2_ : 0u; }
+    DI uint32_t share_mask() const { return (1u << share_log2()) - 1u; }
+    DI uint32_t sub() const { return threadIdx.x & share_mask(); }           // this lane's place among its pixel's lanes
+    DI uint32_t lead() const { return sub() == 0u ? 1u : 0u; }               // 1 on the lane that counts the shared work
+    DI uint32_t my_cells(uint32_t cells) const { return (cells + share_mask() - sub()) >> share_log2(); }  // cells c with c % 2^s == sub
 };
 constexpr uint32_t CNT_SHADED_MASK = 0xfffu, CNT_CULLED_SHIFT = 12u;
 
@@ -1430,36 +1446,65 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
         // wave-uniform: no shadow caster is reachable, so each of the u_steps * v_steps is_shadowed() calls answers
         // "lit": total = 1.0 + ... + 1.0 = cells exactly (an integer below 2^24), and cells / cells = 1.0
         const uint32_t cells = (uint32_t)(H.u_steps * H.v_steps);
-        cnt.rays += cells;
-        cnt.shaded += cells << CNT_CULLED_SHIFT;  // statistics: rays answered without an object test
+        cnt.rays += cnt.my_cells(cells);
+        cnt.shaded += cnt.my_cells(cells) << CNT_CULLED_SHIFT;  // statistics: rays answered without an object test
         return (float)cells / H.cells_f;
     }
     if (dark) {
         // per lane: every is_shadowed() call answers "shadowed": total stays 0.0, and 0.0 / cells = 0.0
         const uint32_t cells = (uint32_t)(H.u_steps * H.v_steps);
-        cnt.rays += cells;
-        cnt.shaded += cells << CNT_CULLED_SHIFT;
+        cnt.rays += cnt.my_cells(cells);
+        cnt.shaded += cnt.my_cells(cells) << CNT_CULLED_SHIFT;
         return 0.0f / H.cells_f;
     }
     if constexpr (PRE) shadow_prepare<NOBJ>(H, S, p, pre);
+    // The cells of the light in the reference's order (v outer, u inner), this lane's share of them: cell = sub, sub +
+    // 2^s, ...  `total` only ever holds a whole number of at most `cells` (< 2^24), so the order of the additions and
+    // their split over lanes cannot change it.
     float total = 0.0f;
-    for (int v = 0; v < H.v_steps; v++) {
-        for (int u = 0; u < H.u_steps; u++) {
-            float j1 = H.jitter_const, j2 = H.jitter_const;
-            if (hashed) {
-                uint32_t h = mix32(key);
-                key += 0x85EBCA6Bu;  // key = base + cell * 0x85EBCA6B, cell = v * u_steps + u
-                j1 = jitter_value(h >> 16);
-                j2 = jitter_value(h & 0xffffu);
+    if constexpr (!Counters::SHARE_LANES) {
+        for (int v = 0; v < H.v_steps; v++) {
+            for (int u = 0; u < H.u_steps; u++) {
+                float j1 = H.jitter_const, j2 = H.jitter_const;
+                if (hashed) {
+                    uint32_t h = mix32(key);
+                    key += 0x85EBCA6Bu;  // key = base + cell * 0x85EBCA6B, cell = v * u_steps + u
+                    j1 = jitter_value(h >> 16);
+                    j2 = jitter_value(h & 0xffffu);
+                }
+                // corner + u_vec * (u + jitter1) + v_vec * (v + jitter2)
+                V3 lp = corner + uvec * ((float)u + j1) + vvec * ((float)v + j2);
+                bool blocked;
+                if constexpr (PRE) blocked = is_shadowed_pre<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt, skip);
+                else blocked = is_shadowed<NOBJ>(H, S, lp, p, cnt, skip & 0x7fffffffu);
+                if (!blocked) total += 1.0f;
             }
-            // corner + u_vec * (u + jitter1) + v_vec * (v + jitter2)
-            V3 lp = corner + uvec * ((float)u + j1) + vvec * ((float)v + j2);
-            bool blocked;
-            if constexpr (PRE) blocked = is_shadowed_pre<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt, skip);
-            else blocked = is_shadowed<NOBJ>(H, S, lp, p, cnt, skip & 0x7fffffffu);
-            if (!blocked) total += 1.0f;
         }
+        return total / H.cells_f;
     }
+    const uint32_t stride = 1u << cnt.share_log2(), cells = (uint32_t)(H.u_steps * H.v_steps);
+    uint32_t cell = cnt.sub();
+    int u = (int)cell, v = 0;
+    while (u >= H.u_steps) u -= H.u_steps, v++;
+    key += cell * 0x85EBCA6Bu;  // key = base + cell * 0x85EBCA6B, cell = v * u_steps + u
+    for (; cell < cells; cell += stride) {
+        float j1 = H.jitter_const, j2 = H.jitter_const;
+        if (hashed) {
+            uint32_t h = mix32(key);
+            key += stride * 0x85EBCA6Bu;
+            j1 = jitter_value(h >> 16);
+            j2 = jitter_value(h & 0xffffu);
+        }
+        // corner + u_vec * (u + jitter1) + v_vec * (v + jitter2)
+        V3 lp = corner + uvec * ((float)u + j1) + vvec * ((float)v + j2);
+        bool blocked;
+        if constexpr (PRE) blocked = is_shadowed_pre<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt, skip);
+        else blocked = is_shadowed<NOBJ>(H, S, lp, p, cnt, skip & 0x7fffffffu);
+        if (!blocked) total += 1.0f;
+        u += (int)stride;
+        while (u >= H.u_steps) u -= H.u_steps, v++;
+    }
+    for (uint32_t m = 1u; m < stride; m <<= 1) total += __shfl_xor(total, (int)m, 64);  // the pixel's lanes are adjacent
     return total / H.cells_f;
 }
 
@@ -1736,7 +1781,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
     V3 ret = v3(0.0f, 0.0f, 0.0f);
     for (;;) {
         // ---------------- color_at(ray(o, d), rem)
-        cnt.rays++;
+        cnt.rays += cnt.lead();
         Hit h = nearest_hit<NOBJ>(H, S, o, d);
         bool descend = false;
         ret = v3(0.0f, 0.0f, 0.0f);
@@ -1759,7 +1804,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
             }
 
             // shade_hit, world.rs:62-86
-            cnt.shaded++;
+            cnt.shaded += cnt.lead();
             // park everything the sampling loop does not touch
             stash.put(0, o.x), stash.put(1, o.y), stash.put(2, o.z);
             stash.put(3, d.x), stash.put(4, d.y), stash.put(5, d.z);
@@ -1898,6 +1943,7 @@ struct RenderArgs {
     uint32_t rows;         // rows in `out`
     uint32_t band_rows, n_parts, part;
     int32_t depth;
+    uint32_t share_log2;   // 2^share_log2 lanes per pixel (see Counters): > 0 only for area lights on small images
 };
 
 // Camera::render (camera.rs:76-91): one lane per pixel, 8x8 pixel tile per
@@ -1909,9 +1955,15 @@ template <int NOBJ, bool SIMPLE>
 DI void render_body(const RenderArgs& A) {
     const SceneHdr& H = A.hdr;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t yl = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-    Counters cnt = {0u, 0u};
+    // Sample-parallel mode (small images under an area light, chosen by the host): a frame of a few thousand waves,
+    // each working through 64 pixels x 100 shadow rays, leaves most of the chip idle for the length of one wave.
+    // With 2^s lanes per pixel a wave takes a tile of 64 >> s pixels (8x8, 8x4, 4x4, 4x2) and every lane a 2^-s share of
+    // each shade point's light cells; all other work is replicated across a pixel's lanes (same inputs, same bits).
+    const uint32_t sl = Counters::SHARE_LANES ? A.share_log2 : 0u, q = lane >> sl;  // q: the pixel's slot in the wave's tile
+    const uint32_t tw_log2 = 3u - (sl >> 1), th_log2 = 3u - ((sl + 1u) >> 1);
+    const uint32_t x = ((blockIdx.x * 2u + (wave & 1u)) << tw_log2) + (q & ((1u << tw_log2) - 1u));
+    const uint32_t yl = ((blockIdx.y * 2u + (wave >> 1)) << th_log2) + (q >> tw_log2);
+    Counters cnt = {0u, 0u, sl};
     __shared__ float stash_lds[STASH_SLOTS * 256];
     const LaneStash stash = {stash_lds + threadIdx.x, 256u};
     if (x < H.width && yl < A.rows) {
@@ -1934,10 +1986,12 @@ DI void render_body(const RenderArgs& A) {
             V3 direction = norm3(pixel - origin);
             col = color_at<NOBJ, SIMPLE>(H, A.soa, origin, direction, A.depth, y * H.width + x, cnt, stash);
         }
-        float* dst = A.out + ((size_t)yl * H.width + x) * 3;
-        dst[0] = col.x;
-        dst[1] = col.y;
-        dst[2] = col.z;
+        if (cnt.lead()) {
+            float* dst = A.out + ((size_t)yl * H.width + x) * 3;
+            dst[0] = col.x;
+            dst[1] = col.y;
+            dst[2] = col.z;
+        }
     }
     // work statistics: wave reduce, then one partial per workgroup
     uint32_t rays = cnt.rays, shaded = cnt.shaded & CNT_SHADED_MASK, culled = cnt.shaded >> CNT_CULLED_SHIFT;

@@ -464,3 +464,36 @@ def test_pattern_boundary_errors_on_device():
     with pytest.raises(P.RtcError) as e:
         bad.color_at_world([P.point(0, 0, 0)])
     assert e.value.status == L.RTC_ERR_UNSUPPORTED
+
+
+# ------------------------------------------------- sample-parallel rendering (2^s lanes per pixel share the light's cells)
+@pytest.mark.parametrize("share", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("name,size,kw", [
+    ("soft_shadows", (101, 37), {"jitter": ("hashed", scenes.DEFAULT_SEED)}),   # sizes that leave partial tiles
+    ("soft_shadows", (45, 67), {"jitter": ("constant", 0.5)}),
+    ("shapes_medley", (96, 72), {}),
+    ("first_textures", (90, 50), {}),                                            # gates + patterns
+    ("groups_medley", (80, 60), {}),                                             # traversal kernel
+])
+def test_lanes_sharing_a_pixel_change_nothing(name, size, kw, share, monkeypatch):
+    """RTC_AMD_SHARE_LOG2=s: every pixel is traced by 2^s adjacent lanes that split each shade point's light cells
+    between them (how small frames under an area light fill the chip).  Image, ray count and shaded-hit count must be
+    those of one lane per pixel -- and of the oracle."""
+    from ray_tracer_challenge_amd.renderer import Renderer
+    world, camera, depth = getattr(scenes, name)(*size, **kw)
+    monkeypatch.setenv("RTC_AMD_SPECIALIZE", "1")  # lane sharing is compiled into the per-scene kernels only
+    monkeypatch.setenv("RTC_AMD_SHARE_LOG2", share)
+    r = Renderer(world, camera, device=0)
+    assert r.kernel_name.startswith("render_kernel_spec["), r.kernel_name
+    img = r.render(depth).cpu().numpy()
+    st = r.stats()
+    r.close()
+    exp, rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=8)
+    H.assert_images_equal(img, exp, "%s share=%s" % (name, share))
+    assert st["rays"] == rays
+    monkeypatch.setenv("RTC_AMD_SHARE_LOG2", "0")
+    r0 = Renderer(world, camera, device=0)
+    r0.render(depth)
+    # (culled_shadow_rays may differ: the cull is decided per wave, and a wave now holds other pixels)
+    assert r0.stats()["shaded_hits"] == st["shaded_hits"]
+    r0.close()
