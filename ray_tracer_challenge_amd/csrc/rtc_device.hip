@@ -786,10 +786,11 @@ rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunct
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
                                      "-I" + csrc, "-I" + inc};
     for (const auto& d : defines) opts.push_back(d);
-    // occupancy target of the specialised kernel: measured 4 -> 3.39, 5 -> 3.42, 6 -> 3.24, 7 -> 3.17, 8 -> 3.17 ms (C3)
+    // occupancy target of the specialised kernel: measured 4 -> 3.39, 5 -> 3.42, 6 -> 3.24, 7 -> 3.17, 8 -> 3.17 ms (C3) before
+    // light-cone culling; with it (more state per shade point) 5 -> 0.98, 6 -> 0.97, 7 -> 0.95, 8 -> 1.02 ms (tools/ab_waves.sh)
     bool waves_given = false;
     for (const auto& d : defines) waves_given = waves_given || d.rfind("-DRTC_WAVES_PER_SIMD=", 0) == 0;
-    if (!waves_given) opts.push_back("-DRTC_WAVES_PER_SIMD=8");
+    if (!waves_given) opts.push_back("-DRTC_WAVES_PER_SIMD=7");
     if (const char* extra = std::getenv("RTC_AMD_JIT_FLAGS")) {  // development: extra -D / -m flags, space separated
         std::istringstream ss(extra);
         std::string tok;
