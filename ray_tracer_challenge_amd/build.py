@@ -38,7 +38,7 @@ def build(force=False, verbose=False, extra_flags=()):
     if not force and not stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc] + FLAGS + list(extra_flags) + ["-o", LIB] + SOURCES + ["-lhiprtc", "-ldl"]
+    cmd = [hipcc] + FLAGS + list(extra_flags) + ["-o", LIB] + SOURCES + ["-lhiprtc", "-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

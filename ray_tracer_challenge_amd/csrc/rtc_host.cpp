@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rtc_internal.h"
@@ -565,51 +566,82 @@ static inline unsigned scale_color(float c) {
     return (unsigned)(uint8_t)v;
 }
 
+// One row of Canvas::to_ppm (canvas.rs:58-96) appended at `out` (WRITE) or merely measured; returns the end / the
+// length.  The 70-column wrap starts afresh on every row (`current_line`, canvas.rs:69), so rows are independent.
+extern "C++" {
+template <bool WRITE>
+static char* ppm_format_row(const float* row, uint32_t w, char* out) {
+    size_t line_len = 0;
+    auto put = [&](char ch) {
+        if (WRITE) *out = ch;
+        out++;
+    };
+    auto put_value = [&](unsigned v) {
+        if (v >= 100) put((char)('0' + v / 100)), line_len++;
+        if (v >= 10) put((char)('0' + (v / 10) % 10)), line_len++;
+        put((char)('0' + v % 10));
+        line_len++;
+    };
+    auto separator = [&]() {  // write_rgb_separator, canvas.rs:47-55 (70 - 3 = 67)
+        if (line_len < 67) {
+            put(' ');
+            line_len++;
+        } else {
+            put('\n');
+            line_len = 0;
+        }
+    };
+    for (uint32_t col = 0; col < w; col++) {
+        const float* p = row + (size_t)col * 3;
+        put_value(scale_color(p[0]));
+        separator();
+        put_value(scale_color(p[1]));
+        separator();
+        put_value(scale_color(p[2]));
+        if (col != w - 1) separator();
+    }
+    if (line_len != 0) put('\n');  // canvas.rs:90-93
+    return out;
+}
+}  // extern "C++"
+
 rtc_status rtc_to_ppm(const float* rgb, uint32_t w, uint32_t h, char** out_text, uint64_t* out_len) {
     if (!rgb || !out_text || !out_len) return fail(RTC_ERR_INVALID_ARG, "rtc_to_ppm: null argument");
-    // Single pass into one growing buffer; a row's text is at most 12 bytes per pixel + newlines.
-    std::string ppm;
-    ppm.reserve((size_t)w * h * 12 + 64);
     char head[64];
-    snprintf(head, sizeof(head), "P3\n%u %u\n255\n", w, h);
-    ppm += head;
-    for (uint32_t row = 0; row < h; row++) {
-        size_t line_len = 0;  // length of `current_line` (canvas.rs:69)
-        auto put_value = [&](unsigned v) {
-            char tmp[4];
-            int n = 0;
-            if (v >= 100) tmp[n++] = (char)('0' + v / 100);
-            if (v >= 10) tmp[n++] = (char)('0' + (v / 10) % 10);
-            tmp[n++] = (char)('0' + v % 10);
-            ppm.append(tmp, n);
-            line_len += n;
-        };
-        auto separator = [&]() {  // write_rgb_separator, canvas.rs:47-55 (70 - 3 = 67)
-            if (line_len < 67) {
-                ppm.push_back(' ');
-                line_len++;
-            } else {
-                ppm.push_back('\n');
-                line_len = 0;
-            }
-        };
-        for (uint32_t col = 0; col < w; col++) {
-            const float* p = rgb + ((size_t)row * w + col) * 3;
-            put_value(scale_color(p[0]));
-            separator();
-            put_value(scale_color(p[1]));
-            separator();
-            put_value(scale_color(p[2]));
-            if (col != w - 1) separator();
-        }
-        if (line_len != 0) ppm.push_back('\n');  // canvas.rs:90-93
-    }
-    char* out = (char*)std::malloc(ppm.size() + 1);
+    const size_t head_len = (size_t)snprintf(head, sizeof(head), "P3\n%u %u\n255\n", w, h);
+    // A 4096^2 frame is 175 MB of text -- 1.2 s on one core, a thousand renders.  A few threads measure their share of
+    // the rows, then write it straight into its place in the one output buffer (fresh pages are the other cost, so
+    // nothing is formatted into a scratch buffer and copied).
+    unsigned n_threads = std::thread::hardware_concurrency();
+    n_threads = n_threads == 0 ? 1 : (n_threads > 16 ? 16 : n_threads);
+    if ((uint64_t)w * h < (1u << 16)) n_threads = 1;
+    if (n_threads > h) n_threads = h ? h : 1;
+    auto first_row = [&](unsigned t) { return (uint32_t)((uint64_t)h * t / n_threads); };
+    auto on_all = [&](auto&& work) {
+        std::vector<std::thread> workers;
+        for (unsigned t = 1; t < n_threads; t++) workers.emplace_back(work, t);
+        work(0u);
+        for (auto& th : workers) th.join();
+    };
+    std::vector<size_t> len(n_threads, 0), at(n_threads, 0);
+    on_all([&](unsigned t) {
+        size_t n = 0;
+        for (uint32_t row = first_row(t); row < first_row(t + 1); row++)
+            n += (size_t)(ppm_format_row<false>(rgb + (size_t)row * w * 3, w, nullptr) - (char*)nullptr);
+        len[t] = n;
+    });
+    size_t total = head_len;
+    for (unsigned t = 0; t < n_threads; t++) at[t] = total, total += len[t];
+    char* out = (char*)std::malloc(total + 1);
     if (!out) return fail(RTC_ERR_INVALID_ARG, "rtc_to_ppm: out of memory");
-    std::memcpy(out, ppm.data(), ppm.size());
-    out[ppm.size()] = 0;
+    std::memcpy(out, head, head_len);
+    on_all([&](unsigned t) {
+        char* p = out + at[t];
+        for (uint32_t row = first_row(t); row < first_row(t + 1); row++) p = ppm_format_row<true>(rgb + (size_t)row * w * 3, w, p);
+    });
+    out[total] = 0;
     *out_text = out;
-    *out_len = ppm.size();
+    *out_len = total;
     return RTC_OK;
 }
 

@@ -151,7 +151,8 @@ def test_powf_restatement_equals_libm_powf():
 
 def test_to_ppm_matches_oracle_bytes():
     rng = np.random.default_rng(5)
-    for (w, h) in [(1, 1), (5, 3), (10, 2), (23, 7), (70, 3), (101, 4)]:
+    # the last three are large enough for the formatter to split the rows over threads (>= 2^16 pixels)
+    for (w, h) in [(1, 1), (5, 3), (10, 2), (23, 7), (70, 3), (101, 4), (700, 123), (65536, 1), (3, 30000)]:
         img = rng.uniform(-0.2, 1.3, (h, w, 3)).astype(f32)
         img[0, 0] = [np.nan, np.inf, -np.inf]
         assert P.Canvas(w, h, img).to_ppm() == O.to_ppm(img), (w, h)
