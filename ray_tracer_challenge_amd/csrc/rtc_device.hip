@@ -1058,7 +1058,7 @@ rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, 
     const uint32_t share_log2 = (c->spec_fn && c->spec_shares) ? choose_share_log2(c->hdr, rows) : 0u;  // only kernels compiled for it share lanes
     const uint32_t bw = 16u >> (share_log2 >> 1), bh = 16u >> ((share_log2 + 1u) >> 1);  // pixels per workgroup (2x2 wave tiles)
     dim3 grid((c->hdr.width + bw - 1) / bw, (rows + bh - 1) / bh), block(256);
-    const size_t n_blocks = (size_t)grid.x * grid.y;
+    const size_t n_blocks = (size_t)grid.x * grid.y * 4;  // partial counts: one per wave
     if (n_blocks > c->block_cap) {  // grow-only workspace (first call / larger image only)
         if (c->d_block_counts) HIP_TRY(hipFree(c->d_block_counts));
         c->d_block_counts = nullptr;

@@ -1938,7 +1938,7 @@ struct RenderArgs {
     SceneHdr hdr;
     SceneSoA soa;
     float* out;            // compact rows of this partition: [rows][width][3]
-    uint4* block_counts;   // one partial {rays, shaded hits, culled shadow rays, 0} per workgroup
+    uint4* block_counts;   // one partial {rays, shaded hits, culled shadow rays, 0} per wave (4 per workgroup)
     unsigned long long* total;  // {rays, shaded hits, culled}: zeroed here, accumulated by sum_counts_kernel
     uint32_t rows;         // rows in `out`
     uint32_t band_rows, n_parts, part;
@@ -1993,22 +1993,18 @@ DI void render_body(const RenderArgs& A) {
             dst[2] = col.z;
         }
     }
-    // work statistics: wave reduce, then one partial per workgroup
+    // work statistics: wave reduce, then one partial per wave
     uint32_t rays = cnt.rays, shaded = cnt.shaded & CNT_SHADED_MASK, culled = cnt.shaded >> CNT_CULLED_SHIFT;
     for (int off = 32; off > 0; off >>= 1) {
         rays += __shfl_down(rays, off, 64);
         shaded += __shfl_down(shaded, off, 64);
         culled += __shfl_down(culled, off, 64);
     }
-    __shared__ uint4 wave_counts[4];
-    if (lane == 0) wave_counts[wave] = make_uint4(rays, shaded, culled, 0u);
-    __syncthreads();
+    const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4u;
+    // one partial per WAVE and no workgroup barrier: a wave that is done leaves (where neighbouring tiles differ a lot in
+    // depth of recursion -- the edge of a glass ball -- the waiting waves were holding the slots of the next workgroup)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) A.total[threadIdx.x] = 0ull;  // for sum_counts_kernel's atomics
-    if (threadIdx.x == 0)
-        A.block_counts[blockIdx.y * gridDim.x + blockIdx.x] =
-            make_uint4(wave_counts[0].x + wave_counts[1].x + wave_counts[2].x + wave_counts[3].x,
-                       wave_counts[0].y + wave_counts[1].y + wave_counts[2].y + wave_counts[3].y,
-                       wave_counts[0].z + wave_counts[1].z + wave_counts[2].z + wave_counts[3].z, 0u);
+    if (lane == 0) A.block_counts[slot + wave] = make_uint4(rays, shaded, culled, 0u);
 }
 
 #ifdef RTC_SPEC_LIST
