@@ -535,6 +535,25 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     // GroupShapes: write the depth-first traversal out as an entry list (see SceneSoA::trav)
     if (scene->n_groups) {
         if (!scene->groups) return fail(RTC_ERR_INVALID_ARG, "scene.groups is NULL");
+        // SHAPE_LOOSE: leaves that some group around them does not (safely) contain -- see the flag
+        for (uint32_t g = 0; g < scene->n_groups; g++) {
+            const rtc_group& grp = scene->groups[g];
+            if ((uint64_t)grp.first_object + grp.n_objects > n) continue;  // reported below
+            for (uint32_t i = grp.first_object; i < grp.first_object + grp.n_objects; i++) {
+                double lo[3], hi[3];
+                bool inside = world_extent(scene->objects[i], lo, hi);
+                for (int a = 0; a < 3 && inside; a++) {
+                    const double tol = 1e-5 * (std::fabs(lo[a]) + std::fabs(hi[a]) + 1.0);
+                    inside = lo[a] >= (double)grp.bounds_min[a] - tol && hi[a] <= (double)grp.bounds_max[a] + tol;
+                }
+                if (!inside) {
+                    uint32_t bits;
+                    std::memcpy(&bits, &(*soa)[i].w, 4);
+                    bits |= SHAPE_LOOSE;
+                    std::memcpy(&(*soa)[i].w, &bits, 4);
+                }
+            }
+        }
         struct Open {
             uint32_t end;
             size_t entry;

@@ -558,6 +558,10 @@ enum : uint32_t {
     SHAPE_CASTS = 1u << 8,   // BaseShape.casts_shadow
     SHAPE_CLOSED = 1u << 9,  // Cylinder.closed
     SHAPE_DIAG = 1u << 10,   // t_inverse has no off-diagonal 3x3 terms (scale + translate only)
+    // The object sits in a GroupShape whose box does not contain it (group.rs:15 caches the box and never updates it, so a
+    // child added later can lie outside): rays that would hit it may be turned away at the group.  Shortcuts that
+    // ASSERT a hit on the object (light_cull_mask's `dark`) must stand down; those that only remove tests are unaffected.
+    SHAPE_LOOSE = 1u << 11,
 };
 
 // ---- scene specialisation (hiprtc compile only) --------------------------------------------------
@@ -1356,7 +1360,7 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p, bool& da
             // 1e3 of |b|), and it lies before the light because every sample is more than 2.2 radii beyond o along -o
             // while the sphere ends within 2.1.  So is_shadowed finds a hit below `distance`; the nearest hit may belong
             // to another object, but if that is a caster the answer is the same, and non-casters are dealt with below.
-            if (kind == RTC_SPHERE && (bits & SHAPE_CASTS) && c_own > 1e-4f && oo <= 1.21f && entering) dark = true;
+            if (kind == RTC_SPHERE && (bits & SHAPE_CASTS) && !(bits & SHAPE_LOOSE) && c_own > 1e-4f && oo <= 1.21f && entering) dark = true;
         }
         if (__all(cull)) mask |= 1u << i;
         else if (bits & SHAPE_CASTS) casters_left = true;

@@ -392,3 +392,31 @@ def test_a_stale_cached_box_hides_late_children_like_the_reference(many, monkeyp
         r.close()
         seen = Renderer(fresh, camera, device=0).render(3).cpu().numpy()
         assert (seen != img).any(axis=2).mean() > 0.02  # the late children really are hidden from most rays
+
+
+@pytest.mark.gpu
+def test_shortcuts_that_assert_a_hit_respect_a_stale_group_box():
+    """'Every sample is blocked by the sphere this point sits behind' (light_cull_mask's far-side shortcut) presumes the
+    rays reach the sphere.  A sphere added to a group after the group's box was cached lies outside that box, and the
+    reference turns its rays away at the group: points on its far side are LIT there, and must be here."""
+    light = ((-3.0, 6.0, -5.0), (1.0, 1.0, 1.0))
+
+    def build(api):
+        objs = _stale_box_objects(api, False)
+        lt = api.RectangleLight(np.array(light[1], dtype=f32), np.array(light[0] + (1.0,), dtype=f32), np.array((2, 0, 0, 0), dtype=f32), 4,
+                                np.array((0, 2, 0, 0), dtype=f32), 4, ("hashed", 4))
+        return api.World(objs, lt)
+
+    world, own = build(P), build(O)
+    late = world.objects[0].children[1]  # the sphere added after bounding_box() was cached
+    rng = np.random.default_rng(3)
+    d = rng.normal(size=(3000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    local = np.concatenate([d * (1.0 + 10.0 ** rng.uniform(-5, -1, (3000, 1))), np.ones((3000, 1))], axis=1)
+    pts = (np.asarray(late.transform, dtype=np.float64) @ local.T).T.astype(f32)
+    got = world.intensity_at(pts)
+    for i in range(len(pts)):
+        own.set_pixel(i)
+        exp = own.intensity_at(pts[i])
+        assert got[i] == exp, (pts[i], got[i], exp)
+    assert (got == 1.0).mean() > 0.5  # most points around the hidden sphere are lit, its own far side included
