@@ -362,6 +362,19 @@ class Pattern:
     def set_transformation(self, t):
         self.transform = np.asarray(t, dtype=f32)
 
+    def _uv_array(self, struct_type):
+        """The C array of this pattern's UV patterns.  The C struct returned by _c() -- and every copy of it, e.g. one per
+        leaf of a mesh whose triangles share this Pattern through Material.copy() -- BORROWS it, so it must outlive them
+        all: it is built once per state of the UV patterns and kept on the Pattern (replacing it on every _c() call freed
+        the array under the earlier copies)."""
+        key = tuple((type(u).__name__, tuple(sorted((k, id(v) if hasattr(v, "__dict__") or hasattr(v, "shape") else v)
+                                                      for k, v in vars(u).items() if not k.startswith("_")))) for u in self.uv)
+        cached = getattr(self, "_uv_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, (struct_type * len(self.uv))(*[u._c() for u in self.uv]), list(self.uv))
+            self._uv_cache = cached
+        return cached[1]
+
     def _c(self):
         p = _Pattern()
         p.kind = self.kind
@@ -369,9 +382,8 @@ class Pattern:
         p.b[:] = [f32(c) for c in self.b]
         p.transform[:] = [f32(v) for v in self.transform.reshape(-1)]
         if self.uv:
-            arr = (_UVPattern * len(self.uv))(*[u._c() for u in self.uv])
+            arr = self._uv_array(_UVPattern)
             p.uv_mapping, p.n_uv, p.uv = self.uv_mapping, len(self.uv), arr
-            self._keep = (arr, self.uv)  # borrowed by the C struct and its copies: lives as long as this Pattern
         return p
 
     def color_at_world(self, point):

@@ -205,13 +205,25 @@ class Pattern:
     def transformation_inverse(self):
         return np.array(list(self._c().inv), dtype=f32).reshape(4, 4)
 
+    def _uv_array(self, struct_type):
+        """The C array of this pattern's UV patterns.  The C struct returned by _c() -- and every copy of it, e.g. one per
+        leaf of a mesh whose triangles share this Pattern through Material.copy() -- BORROWS it, so it must outlive them
+        all: it is built once per state of the UV patterns and kept on the Pattern (replacing it on every _c() call freed
+        the array under the earlier copies)."""
+        key = tuple((type(u).__name__, tuple(sorted((k, id(v) if hasattr(v, "__dict__") or hasattr(v, "shape") else v)
+                                                      for k, v in vars(u).items() if not k.startswith("_")))) for u in self.uv)
+        cached = getattr(self, "_uv_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, (struct_type * len(self.uv))(*[u._c() for u in self.uv]), list(self.uv))
+            self._uv_cache = cached
+        return cached[1]
+
     def _c(self):
         p = L.rtc_pattern()
         a, b, t = _a(self.a, 3), _a(self.b, 3), _a(self.transform, 16)
         if self.uv:
-            arr = (L.rtc_uv_pattern * len(self.uv))(*[u._c() for u in self.uv])
+            arr = self._uv_array(L.rtc_uv_pattern)
             L.check(L.lib().rtc_texture_map_init(C.byref(p), int(self.uv_mapping), arr, len(self.uv), _p(t)))
-            self._keep = (arr, self.uv)  # borrowed by the C struct (and by every copy of it): lives as long as this Pattern
             return p
         L.check(L.lib().rtc_pattern_init(C.byref(p), self.kind, _p(a), _p(b), _p(t)))
         return p

@@ -535,7 +535,9 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     // GroupShapes: write the depth-first traversal out as an entry list (see SceneSoA::trav)
     if (scene->n_groups) {
         if (!scene->groups) return fail(RTC_ERR_INVALID_ARG, "scene.groups is NULL");
-        // SHAPE_LOOSE: leaves that some group around them does not (safely) contain -- see the flag
+        // SHAPE_LOOSE: leaves that some group around them does not (safely) contain -- see the flag.  Such a group must
+        // not be pruned by distance either (for_each_object assumes a group's hits lie inside its box): loose_group.
+        std::vector<char> loose_group(scene->n_groups, 0);
         for (uint32_t g = 0; g < scene->n_groups; g++) {
             const rtc_group& grp = scene->groups[g];
             if ((uint64_t)grp.first_object + grp.n_objects > n) continue;  // reported below
@@ -547,6 +549,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
                     inside = lo[a] >= (double)grp.bounds_min[a] - tol && hi[a] <= (double)grp.bounds_max[a] + tol;
                 }
                 if (!inside) {
+                    loose_group[g] = 1;
                     uint32_t bits;
                     std::memcpy(&bits, &(*soa)[i].w, 4);
                     bits |= SHAPE_LOOSE;
@@ -587,7 +590,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
                     big = (lo != lo || hi != hi) ? NAN : std::fmax(big, std::fmax(lo, hi));
                 }
                 trav.push_back(make_float4(g.bounds_min[0], g.bounds_min[1], g.bounds_min[2], 0.0f));
-                trav.push_back(make_float4(g.bounds_max[0], g.bounds_max[1], g.bounds_max[2], 1e-3f * big));
+                trav.push_back(make_float4(g.bounds_max[0], g.bounds_max[1], g.bounds_max[2], loose_group[gi] ? INFINITY : 1e-3f * big));
                 trav.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 any = true;
                 gi++;
