@@ -611,7 +611,8 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         // groups around it, which is all the recursive walk does (group.rs:115-133).  Same leaves in the same order.
         uint32_t n_gates = 0;
         for (uint32_t g = 0; g < scene->n_groups; g++) n_gates += scene->groups[g].n_objects != 0;
-        if (any && n <= 8 && n_gates <= RTC_MAX_GATES && env_flag("RTC_AMD_GATES", true)) {
+        // (render path only: the batched entry points run the any-count loop for flat worlds, which has no gates)
+        if (cam && any && n <= 8 && n_gates <= RTC_MAX_GATES && env_flag("RTC_AMD_GATES", true)) {
             uint32_t k = 0;
             for (uint32_t g = 0; g < scene->n_groups; g++) {
                 const rtc_group& grp = scene->groups[g];

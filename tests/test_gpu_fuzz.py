@@ -163,3 +163,38 @@ def test_random_worlds_match_the_oracle(seed, monkeypatch):
         H.assert_images_equal(img, exp, "seed %d (%s)" % (seed, r.kernel_name))
         assert r.stats()["rays"] == rays, (seed, r.kernel_name)
         r.close()
+
+
+@pytest.mark.parametrize("seed", [3, 9, 14, 21, 24, 33, 38, 47])
+def test_random_worlds_at_a_size_that_takes_the_default_fast_paths(seed):
+    """The same worlds at 640x420 (> 2^18 pixels) with nothing forced: whatever the library's own policies choose
+    -- scene-compiled kernels, lanes per pixel by frame size, ... -- must render the oracle's image."""
+    world, cam, depth = _world(seed, P)
+    own, _, _ = _world(seed, O)
+    camera = P.Camera(640, 420, cam[2], cam[3])
+    exp, rays = H.oracle_camera(camera).render(own, depth, threads=8)
+    r = Renderer(world, camera, device=0)
+    img = r.render(depth).cpu().numpy()
+    H.assert_images_equal(img, exp, "seed %d (%s)" % (seed, r.kernel_name))
+    assert r.stats()["rays"] == rays
+    r.close()
+
+
+@pytest.mark.parametrize("seed", range(0, 40, 2))
+def test_random_rays_through_the_batched_entry_points(seed):
+    """World::color_at for arbitrary rays (rtc_color_at: no camera, so no assumption about where rays start -- the
+    library's hierarchy stays off, triangle pre-culling only serves rays that start inside its ball)."""
+    world, _, _ = _world(seed, P)
+    own, _, _ = _world(seed, O)
+    rng = np.random.default_rng(seed)
+    n = 400
+    o = np.concatenate([rng.uniform(-9, 9, (n, 3)) * rng.choice([1.0, 1.0, 8.0], (n, 1)), np.ones((n, 1))], axis=1).astype(f32)
+    target = rng.uniform(-3, 3, (n, 3))
+    d = target - o[:, :3].astype(np.float64)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = np.concatenate([d, np.zeros((n, 1))], axis=1).astype(f32)
+    got = world.color_at(o, d, 3)
+    for i in range(n):
+        own.set_pixel(i)
+        exp = own.color_at(o[i], d[i], 3)
+        assert (got[i] == exp).all() or (np.isnan(got[i]) == np.isnan(exp)).all() and (got[i][~np.isnan(exp)] == exp[~np.isnan(exp)]).all(), (seed, i, o[i], d[i], got[i], exp)
