@@ -60,6 +60,8 @@ def _leaf(P, rng):
     kind = rng.choice(["sphere", "sphere", "cube", "cylinder", "cone", "triangle"])
     casts = bool(rng.random() < 0.85)
     m, t = _material(P, rng), _transform(P, rng)
+    if rng.random() < 0.04:  # a plane anywhere, also inside groups (whose boxes then hold infinities and NaNs)
+        return P.Plane(t, m, casts_shadow=casts)
     if kind == "sphere":
         return P.Sphere(t, m, casts_shadow=casts)
     if kind == "cube":
@@ -129,7 +131,7 @@ def _world(seed, P):
     if rng.random() < 0.5:
         light = P.PointLight(P.point(*[float(v) for v in rng.uniform(-6, 6, 3) + np.array([0, 7, -4])]), P.color(1, 1, 1))
     else:
-        jitter = ("hashed", seed) if rng.random() < 0.6 else ("constant", float(rng.choice([0.0, 0.5, 1.0])))
+        jitter = ("hashed", seed) if rng.random() < 0.6 else ("constant", float(rng.choice([0.0, 0.5, 1.0, 1.5, -0.25])))
         u = rng.normal(size=3)
         v = np.cross(u, rng.normal(size=3))
         light = P.RectangleLight(P.color(1.1, 1.0, 0.9), P.point(*[float(x) for x in rng.uniform(-3, 3, 3) + np.array([0, 6, -3])]),
