@@ -1274,11 +1274,12 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p, bool& da
     if (H.u_steps * H.v_steps < 8) return 0u;
     // unrolled kernels: all NOBJ records; any-count loops and tree walks: up to 32 objects (the mask's width)
     if (NOBJ <= 0 && H.n_objects > 31u) return 0u;
-    auto per_object = [&](uint32_t i) {
+    // casters first: when none of them is left the answer is known and the non-casters need not be looked at at all
+    auto per_object = [&](uint32_t i, bool casters) {
         const Obj ob = load_obj_static<NOBJ <= 0>(S, i);
         const uint32_t bits = ob.bits;
         const uint32_t kind = bits & SHAPE_KIND_MASK;
-        if (kind == SHAPE_NONE) return;
+        if (kind == SHAPE_NONE || ((bits & SHAPE_CASTS) != 0u) != casters) return;  // wave-uniform
         // Bounding sphere of the shape in its own space (centre = origin), inflated by 3 % (LIGHT_CULL_INFLATE2).  Every intersection
         // these kinds report lies on the shape.  (Not so for cones -- the near-parallel branch, cone.rs:99-107,
         // returns a root of the unbounded double cone without a range check -- nor for unbounded cylinders;
@@ -1367,15 +1368,23 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p, bool& da
     };
     if constexpr (NOBJ > 0) {
 #pragma unroll
-        for (uint32_t i = 0; i < (uint32_t)NOBJ; i++) per_object(i);
+        for (uint32_t i = 0; i < (uint32_t)NOBJ; i++) per_object(i, true);
     } else {
-        for (uint32_t i = 0; i < H.n_objects; i++) per_object(i);
+        for (uint32_t i = 0; i < H.n_objects; i++) per_object(i, true);
     }
     // no shadow caster can be reached from this shade point: every sample is lit whatever else is in the way
     // (world.rs:104-119 asks for the nearest hit to BE a caster), see intensity_at
     if (!casters_left) {
         mask |= LIGHT_CULL_ALL_CASTERS;
         return mask;  // (dark is false for every lane: the sphere it sits behind would have been kept)
+    }
+    if (H.all_cast == 0u) {
+        if constexpr (NOBJ > 0) {
+#pragma unroll
+            for (uint32_t i = 0; i < (uint32_t)NOBJ; i++) per_object(i, false);
+        } else {
+            for (uint32_t i = 0; i < H.n_objects; i++) per_object(i, false);
+        }
     }
     bool noncasters_left = false;  // wave-uniform
     // Objects that cast no shadow (the demo's lampshade around its area light) matter to a shadow ray only by being hit
