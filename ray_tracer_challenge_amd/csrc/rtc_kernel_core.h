@@ -1349,6 +1349,33 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p, bool& da
                 else outside = outside || (h > 0.0f && h * h > 1.01f * r2 * dot3(n, n));
             }
             cull = (boxy || oo > r2) && oo < 1e4f * r2 && narrow && outside;
+            if (boxy) {
+                // A shade point beyond one face of the box -- typically ON that face of the object itself -- whose every sample
+                // moves further out along that axis: the slab's parameter interval [(lo - o) / d, (hi - o) / d] is negative
+                // (or -inf for d = 0), so cube.rs:90-129 reports nothing, cylinder.rs' range checks o.y + t d.y against
+                // min_y / max_y fail for every t >= 0 and its caps lie at t < 0.  Likewise radially for a cylinder: with
+                // c = ox^2 + oz^2 - 1 > 0 and b = 2 (ox dx + oz dz) >= 0 the radius only grows with t, which rules out the
+                // wall and the caps' radius check.  Margins: 1e-5 on the position (over_point is 1.2e-3 / scale out),
+                // 1e-3 |e| on the direction component (its rounding is ~1e-7 |e|).  Sample directions are positive
+                // combinations of the corner directions, so the corner with the smallest component decides.
+                const V3 e0 = edge(0), e1 = edge(1), e2 = edge(2), e3 = edge(3);
+                const float tol = 1e-3f * sqrtf(fmaxf(fmaxf(dot3(e0, e0), dot3(e1, e1)), fmaxf(dot3(e2, e2), dot3(e3, e3))));
+                auto beyond = [&](float oa, float lo_a, float hi_a, float a0, float a1, float a2, float a3) {
+                    const float emin = fminf(fminf(a0, a1), fminf(a2, a3)), emax = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+                    const float m = 1e-5f * (fabsf(lo_a) + fabsf(hi_a) + 1.0f);
+                    return (oa > hi_a + m && emin >= tol) || (oa < lo_a - m && emax <= -tol);
+                };
+                const float ylo = kind == RTC_CYLINDER ? ob.min_y() : -1.0f, yhi = kind == RTC_CYLINDER ? ob.max_y() : 1.0f;
+                bool away = beyond(o.y, ylo, yhi, e0.y, e1.y, e2.y, e3.y);
+                if (kind == RTC_CUBE) {
+                    away = away || beyond(o.x, -1.0f, 1.0f, e0.x, e1.x, e2.x, e3.x) || beyond(o.z, -1.0f, 1.0f, e0.z, e1.z, e2.z, e3.z);
+                } else {
+                    const float rr = o.x * o.x + o.z * o.z, rtol = tol * sqrtf(rr);
+                    away = away || (rr - 1.0f > 1e-4f && o.x * e0.x + o.z * e0.z >= rtol && o.x * e1.x + o.z * e1.z >= rtol &&
+                                    o.x * e2.x + o.z * e2.z >= rtol && o.x * e3.x + o.z * e3.z >= rtol);
+                }
+                cull = cull || (away && oo < 1e4f * r2);
+            }
             // A shade point sitting just outside the unit sphere whose whole light pyramid points away from it: with
             // c = |o|^2 - 1 > 0 and b = 2 pd.o > 0 both roots (-b -+ sqrt(b^2 - 4ac)) / 2a are negative, and by more
             // than rounding can undo because 4ac / b^2 >= c / (1 + c) >= 8e-5 (c is the exact test's own value).

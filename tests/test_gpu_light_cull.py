@@ -204,3 +204,42 @@ def test_points_on_the_far_side_of_a_casting_sphere(jitter):
             exp = ow.intensity_at(pts[i])
             assert got[i] == exp, (jitter, k, pts[i], got[i], exp)
         assert (got == 0.0).mean() > 0.2 and (got == 1.0).mean() > 0.2
+
+
+@pytest.mark.parametrize("jitter", [("hashed", 12), ("constant", 0.0)])
+def test_points_all_around_cubes_and_cylinders(jitter):
+    """A cube or cylinder is left out for shade points beyond one of its faces (or radially outside) whose samples all move
+    further out -- in particular points on the object itself facing the light.  Points 1e-6 .. 0.3 units off every face,
+    wall and cap of rotated, squashed, mirrored cubes and open / closed cylinders, against the oracle."""
+    rng = np.random.default_rng(23)
+    light = P.RectangleLight(P.color(1, 1, 1), P.point(-2.0, 5.0, -3.0), P.vector(3, 0, 1), 4, P.vector(0, 2, 0), 3, jitter)
+    floor = P.Plane(P.translation(0.0, -4.0, 0.0), P.Material())
+    for k in range(8):
+        t = P.chain(P.translation(*rng.uniform(-1, 1, 3)), P.rotation_y(float(rng.uniform(-3, 3))), P.rotation_x(float(rng.uniform(-1, 1))),
+                    P.scaling(*[float(s) for s in rng.uniform(0.4, 1.5, 3) * rng.choice([1.0, 1.0, -1.0], 3)]))
+        n = 3000
+        h = 10.0 ** rng.uniform(-6, -0.5, n)
+        if k % 2 == 0:
+            shape = P.Cube(t, P.Material())
+            q = rng.uniform(-1, 1, (n, 3))
+            axis = rng.integers(0, 3, n)
+            side = rng.choice([-1.0, 1.0], n)
+            q[np.arange(n), axis] = side * (1.0 + h)
+        else:
+            lo, hi = float(rng.uniform(-2, -0.2)), float(rng.uniform(0.2, 2))
+            shape = P.Cylinder(t, P.Material(), minimum_y=lo, maximum_y=hi, closed=bool(k % 4 == 1))
+            ang = rng.uniform(0, 2 * np.pi, n)
+            rad = np.where(rng.random(n) < 0.6, 1.0 + h, rng.uniform(0, 1, n))           # wall, or over / under a cap
+            y = np.where(rad > 1.0, rng.uniform(lo, hi, n), np.where(rng.random(n) < 0.5, hi + h, lo - h))
+            q = np.stack([rad * np.cos(ang), y, rad * np.sin(ang)], axis=1)
+        local = np.concatenate([q, np.ones((n, 1))], axis=1)
+        pts = (np.asarray(t, dtype=np.float64) @ local.T).T.astype(f32)
+        objs = [shape, floor] + ([P.Sphere(P.chain(P.translation(0.0, 2.5, -1.0), P.scaling(0.5, 0.5, 0.5)), P.Material())] if k % 3 == 0 else [])
+        world = P.World(objs, light)
+        ow = H.oracle_world(world)
+        got = world.intensity_at(pts)
+        for i in range(n):
+            ow.set_pixel(i)
+            exp = ow.intensity_at(pts[i])
+            assert got[i] == exp, (jitter, k, pts[i], got[i], exp)
+        assert (got == 1.0).mean() > 0.03 and (got < 1.0).mean() > 0.03  # lit and shadowed points both occur
