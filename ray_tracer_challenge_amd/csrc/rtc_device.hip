@@ -548,6 +548,9 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
                     const double tol = 1e-5 * (std::fabs(lo[a]) + std::fabs(hi[a]) + 1.0);
                     inside = lo[a] >= (double)grp.bounds_min[a] - tol && hi[a] <= (double)grp.bounds_max[a] + tol;
                 }
+                // (a cone's near-parallel branch, cone.rs:99-107, reports roots of the UNBOUNDED double cone: hits outside
+                // the cone's own bounds, hence outside any group box built from them)
+                if (scene->objects[i].kind == RTC_CONE) loose_group[g] = 1;
                 if (!inside) {
                     loose_group[g] = 1;
                     uint32_t bits;

@@ -144,7 +144,9 @@ def _world(seed, P):
 
 
 # RTC_FUZZ_SEEDS=a:b widens the search (development); the default range is what the suite runs
-_SEEDS = range(*[int(v) for v in os.environ["RTC_FUZZ_SEEDS"].split(":")]) if os.environ.get("RTC_FUZZ_SEEDS") else range(60)
+# 2133: a cone's stray root (cone.rs:99-107) outside its group's box, which distance pruning used to skip
+_SEEDS = (range(*[int(v) for v in os.environ["RTC_FUZZ_SEEDS"].split(":")]) if os.environ.get("RTC_FUZZ_SEEDS")
+          else list(range(60)) + [2133])
 
 
 @pytest.mark.parametrize("seed", _SEEDS)
