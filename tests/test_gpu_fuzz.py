@@ -102,7 +102,9 @@ def _mesh(P, rng):
 
 def _world(seed, P):
     rng = np.random.default_rng(1000 + seed)
-    style = seed % 5  # 0: few flat objects; 1: many flat spheres / cubes; 2: small tree; 3: larger trees + mesh; 4: anything
+    # 0: few flat objects; 1: many flat spheres / cubes; 2: small tree; 3: larger trees + mesh; 4: anything;
+    # 5: big overlapping glass and mirrors close to the camera (nested refraction, deep recursion); 6: meshes
+    style = seed % 7 if seed >= 4000 else seed % 5
     objs = []
     if rng.random() < 0.7 and style != 1:
         objs.append(P.Plane(P.translation(0.0, float(rng.uniform(-3.5, -2.0)), 0.0), _material(P, rng)))
@@ -120,6 +122,19 @@ def _world(seed, P):
             else:
                 budget[0] -= 1
                 objs.append(_leaf(P, rng))
+    elif style == 5:
+        for _ in range(int(rng.integers(3, 9))):
+            t = P.chain(P.translation(*[float(v) for v in rng.uniform(-1.5, 1.5, 3)]), P.rotation_z(float(rng.uniform(-1, 1))),
+                        P.scaling(*[float(v) for v in rng.uniform(0.7, 2.0, 3)]))
+            u = rng.random()
+            m = P.Material(color=tuple(rng.uniform(0.0, 1.0, 3)), diffuse=float(rng.uniform(0.1, 0.6)), specular=0.8, shininess=120.0,
+                           reflective=float(rng.uniform(0.3, 1.0)) if u < 0.5 else 0.0, transparency=float(rng.uniform(0.5, 1.0)) if u > 0.3 else 0.0,
+                           refractive_index=float(rng.choice([1.0, 1.1, 1.5, 2.0])))
+            objs.append([P.Sphere, P.Sphere, P.Cube, P.Cylinder][int(rng.integers(0, 4))](t, m))
+    elif style == 6:
+        for _ in range(int(rng.integers(1, 4))):
+            objs.append(_mesh(P, rng))
+        objs += [_leaf(P, rng) for _ in range(int(rng.integers(0, 3)))]
     else:
         budget = [int(rng.integers(8, 20))]
         while budget[0] > 0:
@@ -146,7 +161,7 @@ def _world(seed, P):
 # RTC_FUZZ_SEEDS=a:b widens the search (development); the default range is what the suite runs
 # 2133: a cone's stray root (cone.rs:99-107) outside its group's box, which distance pruning used to skip
 _SEEDS = (range(*[int(v) for v in os.environ["RTC_FUZZ_SEEDS"].split(":")]) if os.environ.get("RTC_FUZZ_SEEDS")
-          else list(range(60)) + [2133])
+          else list(range(60)) + [2133] + list(range(4002, 4030, 7)) + list(range(4003, 4031, 7)))  # + nested glass, + meshes
 
 
 @pytest.mark.parametrize("seed", _SEEDS)
