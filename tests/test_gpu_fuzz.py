@@ -217,3 +217,32 @@ def test_random_rays_through_the_batched_entry_points(seed):
         own.set_pixel(i)
         exp = own.color_at(o[i], d[i], 3)
         assert (got[i] == exp).all() or (np.isnan(got[i]) == np.isnan(exp)).all() and (got[i][~np.isnan(exp)] == exp[~np.isnan(exp)]).all(), (seed, i, o[i], d[i], got[i], exp)
+
+
+@pytest.mark.parametrize("seed", [2, 5, 9, 13, 16, 4002, 4003])
+@pytest.mark.parametrize("specialise", ["0", "1"])
+def test_random_worlds_in_bands(seed, specialise, monkeypatch):
+    """The multi-GPU split on random worlds: 8-row bands dealt round-robin over 3 parts, each rendered on its own and laid
+    back into place, must be the whole frame -- pixel for pixel, ray for ray (the jitter key is the GLOBAL pixel index)."""
+    monkeypatch.setenv("RTC_AMD_SPECIALIZE", specialise)
+    world, cam, depth = _world(seed, P)
+    camera = P.Camera(*cam)
+    r = Renderer(world, camera, device=0)
+    whole = r.render(depth).cpu().numpy()
+    st = r.stats()
+    h, band, n = camera.height, 8, 3
+    frame = np.full_like(whole, np.nan)
+    rays = 0
+    for p in range(n):
+        part = r.partition(band, n, p)
+        rows = r.render(depth, part=part).cpu().numpy()
+        rays += r.stats()["rays"]
+        at = 0
+        for b in range(p, (h + band - 1) // band, n):
+            y0, y1 = b * band, min((b + 1) * band, h)
+            frame[y0:y1] = rows[at:at + y1 - y0]
+            at += y1 - y0
+        assert at == rows.shape[0]
+    H.assert_images_equal(frame, whole, "seed %d in bands" % seed)
+    assert rays == st["rays"]
+    r.close()
