@@ -528,6 +528,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         const float zero[4] = {0.0f, 0.0f, 0.0f, 1.0f};
         mat_vec4(cam->inv, zero, cam_origin);
         if (build_flat_bvh(scene, cam_origin, &trav)) {
+            hdr->internal_boxes = 1;
             hdr->n_trav = (uint32_t)(trav.size() / TRAV_STRIDE);
             soa->insert(soa->end(), trav.begin(), trav.end());
         }

@@ -496,6 +496,7 @@ struct SceneHdr {
     float tri_guard;  // TRI_GUARD (the boxes' padding is derived from it on the host)
     // Small trees in the unrolled kernels (rtc_device.hip flatten): group boxes as gates.  gate_box[g] = min.xyz, max.xyz;
     // bit g of gate_mask[i]: object i sits inside group g and is only intersected by rays that hit g's box
+    uint32_t internal_boxes;  // the traversal stream's boxes are all the library's own (build_flat_bvh): padded, not semantic
     uint32_t n_gates;
     float gate_box[8][6];
     uint32_t gate_mask[8];
@@ -924,7 +925,11 @@ DI WorldRay world_ray(const SceneHdr& H, V3 o, V3 d) {
     if constexpr (NOBJ < 0) {
         const V3 c = o - v3(H.cull_c[0], H.cull_c[1], H.cull_c[2]);
         const bool near = H.has_tbox != 0u && dot3(c, c) <= H.cull_r2;  // NaN: false
-        return {o, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), RTC_INF, d, near ? H.tri_guard * sqrtf(dot3(d, d)) : RTC_INF, 0u};
+        // ray.rs:16 keeps IEEE reciprocals, and a GroupShape's box must be tested with them; the library's own boxes are
+        // padded by 10 %, which a 1-ulp v_rcp_f32 cannot cross (three divisions are a quarter of a ray that hits nothing)
+        const V3 inv = H.internal_boxes ? v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z))
+                                        : v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        return {o, inv, RTC_INF, d, near ? H.tri_guard * sqrtf(dot3(d, d)) : RTC_INF, 0u};
     } else {
         WorldRay wr = {o, o, RTC_INF, o, RTC_INF, 0u};  // unused but for `closed`
         if (NOBJ > 0 && spec_has_gates(H.n_gates)) {
