@@ -631,6 +631,71 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
             soa->insert(soa->end(), trav.begin(), trav.end());
         }
     }
+    // scene_box (render_body's early-out for primary rays): the union of the top-level entries when all of them are
+    // bounded -- groups by their boxes (a ray that misses a group's box is turned away whatever is inside), leaves of the
+    // kinds whose hits lie within their bounds (not cones: stray roots; not triangles: ill-conditioned near their plane).
+    // Padding: a group's box only needs what the approximate test's rounding needs (the reference's own test of that box
+    // is exact about it): 1e-4 of the coordinates.  A leaf is padded by 10 % of its own half extent plus 0.6 % of the
+    // camera's distance to the farthest corner of the scene: a ray that misses passes the object at >= 6e-3 of its own
+    // length, where the sphere / cylinder quadratic (error ~ 8 eps (D/r)^2, i.e. a miss distance of 1.4e-3 D) and the
+    // slab tests report a miss with a margin of 4x and more.
+    if (cam && n > 0) {
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};  // union of the padded entries
+        double raw_lo[3] = {INFINITY, INFINITY, INFINITY}, raw_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        struct Entry {
+            double lo[3], hi[3];
+            bool group;
+        };
+        std::vector<Entry> entries;
+        bool bounded = true;
+        uint32_t i = 0, g = 0;
+        while (i < n && bounded) {
+            while (g < scene->n_groups && (scene->groups[g].n_objects == 0 || scene->groups[g].first_object < i)) g++;  // nested / empty
+            if (g < scene->n_groups && scene->groups[g].first_object == i) {
+                const rtc_group& grp = scene->groups[g];
+                Entry e;
+                e.group = true;
+                for (int a = 0; a < 3; a++) {
+                    bounded = bounded && std::isfinite(grp.bounds_min[a]) && std::isfinite(grp.bounds_max[a]);
+                    e.lo[a] = grp.bounds_min[a], e.hi[a] = grp.bounds_max[a];
+                }
+                entries.push_back(e);
+                i = grp.first_object + grp.n_objects;
+            } else {
+                const rtc_object& o = scene->objects[i];
+                Entry e;
+                e.group = false;
+                bounded = bounded && (o.kind == RTC_SPHERE || o.kind == RTC_CUBE || o.kind == RTC_CYLINDER) && world_extent(o, e.lo, e.hi);
+                entries.push_back(e);
+                i++;
+            }
+        }
+        if (bounded && env_flag("RTC_AMD_SCENE_BOX", true)) {
+            float org[4];
+            const float zero[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+            mat_vec4(cam->inv, zero, org);
+            for (const Entry& e : entries)
+                for (int a = 0; a < 3; a++) raw_lo[a] = std::fmin(raw_lo[a], e.lo[a]), raw_hi[a] = std::fmax(raw_hi[a], e.hi[a]);
+            double far2 = 0.0;
+            for (int a = 0; a < 3; a++) {
+                const double d = std::fmax(std::fabs(raw_lo[a] - org[a]), std::fabs(raw_hi[a] - org[a]));
+                far2 += d * d;
+            }
+            const double far = std::sqrt(far2);
+            for (const Entry& e : entries)
+                for (int a = 0; a < 3; a++) {
+                    const double pad = (e.group ? 0.0 : 0.05 * (e.hi[a] - e.lo[a]) + 6e-3 * far) + 1e-4 * (std::fabs(e.lo[a]) + std::fabs(e.hi[a]) + far);
+                    lo[a] = std::fmin(lo[a], e.lo[a] - pad), hi[a] = std::fmax(hi[a], e.hi[a] + pad);
+                }
+            bool ok = std::isfinite(far);
+            for (int a = 0; a < 3 && ok; a++) {
+                hdr->scene_box[a] = (float)lo[a];
+                hdr->scene_box[3 + a] = (float)hi[a];
+                ok = std::isfinite(hdr->scene_box[a]) && std::isfinite(hdr->scene_box[3 + a]);
+            }
+            hdr->has_scene_box = ok ? 1u : 0u;
+        }
+    }
     const rtc_light& l = *scene->light;
     hdr->light_kind = l.kind;
     for (int k = 0; k < 3; k++) {

@@ -496,6 +496,8 @@ struct SceneHdr {
     float tri_guard;  // TRI_GUARD (the boxes' padding is derived from it on the host)
     // Small trees in the unrolled kernels (rtc_device.hip flatten): group boxes as gates.  gate_box[g] = min.xyz, max.xyz;
     // bit g of gate_mask[i]: object i sits inside group g and is only intersected by rays that hit g's box
+    uint32_t has_scene_box;   // scene_box bounds everything a primary ray can hit (render_body)
+    float scene_box[6];       // min.xyz, max.xyz, padded
     uint32_t internal_boxes;  // the traversal stream's boxes are all the library's own (build_flat_bvh): padded, not semantic
     uint32_t n_gates;
     float gate_box[8][6];
@@ -2028,20 +2030,18 @@ DI void render_body(const RenderArgs& A) {
                         c[4] * world_x + c[5] * world_y + c[6] * -1.0f + c[7],
                         c[8] * world_x + c[9] * world_y + c[10] * -1.0f + c[11]};
             V3 origin = v3(H.cam_origin[0], H.cam_origin[1], H.cam_origin[2]);
+            // A box around everything a primary ray could hit (SceneHdr::scene_box, built and padded on the host when every
+            // top-level object is bounded): a ray that misses it -- tested with the unnormalised direction and approximate
+            // reciprocals, which move the ray by parts in 1e6 against a padding of 10 % of the box / 1 % of the camera's
+            // distance -- hits nothing, so color_at would return black after one counted ray.  Saves the exact square root
+            // and divisions of norm() and the walk on every such pixel (95 % of C5's).
             bool sees_nothing = false;
-            if constexpr (NOBJ < 0) {
-                // The library's own hierarchy (entry 0 is its root): a primary ray that misses the root's box -- padded by
-                // 10 %, tested here with the unnormalised direction and approximate reciprocals, which move the ray by
-                // parts in 1e6 -- hits no object, so color_at would return black after one counted ray.  Saves the exact
-                // square root and divisions of norm() on every such pixel (95 % of C5's).
-                if (H.internal_boxes) {
-                    const V3 du = pixel - origin;
-                    const V3 iu = v3(__builtin_amdgcn_rcpf(du.x), __builtin_amdgcn_rcpf(du.y), __builtin_amdgcn_rcpf(du.z));
-                    const ConstF4Ptr ep = (ConstF4Ptr)(unsigned long)A.soa.trav;
-                    const RawF4 r0 = ep[0], r1 = ep[1];
-                    float tmin;
-                    sees_nothing = !aabb_hit(origin, iu, make_float4(r0.x, r0.y, r0.z, 0.0f), make_float4(r1.x, r1.y, r1.z, 0.0f), tmin);
-                }
+            if (H.has_scene_box) {
+                const V3 du = pixel - origin;
+                const V3 iu = v3(__builtin_amdgcn_rcpf(du.x), __builtin_amdgcn_rcpf(du.y), __builtin_amdgcn_rcpf(du.z));
+                float tmin;
+                sees_nothing = !aabb_hit(origin, iu, make_float4(H.scene_box[0], H.scene_box[1], H.scene_box[2], 0.0f),
+                                         make_float4(H.scene_box[3], H.scene_box[4], H.scene_box[5], 0.0f), tmin);
             }
             if (sees_nothing) {
                 cnt.rays += cnt.lead();
