@@ -104,9 +104,11 @@ def _world(seed, P):
     rng = np.random.default_rng(1000 + seed)
     # 0: few flat objects; 1: many flat spheres / cubes; 2: small tree; 3: larger trees + mesh; 4: anything;
     # 5: big overlapping glass and mirrors close to the camera (nested refraction, deep recursion); 6: meshes
-    style = seed % 7 if seed >= 4000 else seed % 5
+    # 7 (seeds >= 9000): extreme sizes side by side -- specks of 0.02 next to boulders of 20, seen from far away: what
+    #    the conservative shortcuts' distance limits ("within 100 radii") and paddings are for
+    style = seed % 8 if seed >= 9000 else seed % 7 if seed >= 4000 else seed % 5
     objs = []
-    if rng.random() < 0.7 and style != 1:
+    if rng.random() < 0.7 and style not in (1, 7):
         objs.append(P.Plane(P.translation(0.0, float(rng.uniform(-3.5, -2.0)), 0.0), _material(P, rng)))
     if style == 0:
         objs += [_leaf(P, rng) for _ in range(int(rng.integers(1, 7)))]
@@ -131,6 +133,12 @@ def _world(seed, P):
                            reflective=float(rng.uniform(0.3, 1.0)) if u < 0.5 else 0.0, transparency=float(rng.uniform(0.5, 1.0)) if u > 0.3 else 0.0,
                            refractive_index=float(rng.choice([1.0, 1.1, 1.5, 2.0])))
             objs.append([P.Sphere, P.Sphere, P.Cube, P.Cylinder][int(rng.integers(0, 4))](t, m))
+    elif style == 7:
+        for _ in range(int(rng.integers(6, 30))):
+            r = float(10.0 ** rng.uniform(-1.7, 1.3))
+            sc = np.full(3, r) * (rng.uniform(0.5, 1.5, 3) if rng.random() < 0.5 else 1.0)
+            t = P.chain(P.translation(*[float(v) for v in rng.uniform(-25, 25, 3)]), P.scaling(*[float(v) for v in sc]))
+            objs.append((P.Sphere if rng.random() < 0.6 else P.Cube if rng.random() < 0.7 else P.Cylinder)(t, _material(P, rng)))
     elif style == 6:
         for _ in range(int(rng.integers(1, 4))):
             objs.append(_mesh(P, rng))
@@ -153,7 +161,8 @@ def _world(seed, P):
                                  P.vector(*[float(x) for x in u / np.linalg.norm(u) * rng.uniform(0.5, 3)]), int(rng.integers(2, 5)),
                                  P.vector(*[float(x) for x in v / np.linalg.norm(v) * rng.uniform(0.5, 3)]), int(rng.integers(2, 5)), jitter)
     w, h = int(rng.integers(40, 90)), int(rng.integers(30, 70))
-    camera = (w, h, float(rng.uniform(0.6, 1.3)), P.view_transform(P.point(*[float(x) for x in rng.uniform(-2, 2, 3) + np.array([0, 1.5, -9])]),
+    cam_z = -9.0 if style != 7 else float(-10.0 ** rng.uniform(1.0, 2.5))
+    camera = (w, h, float(rng.uniform(0.6, 1.3)), P.view_transform(P.point(*[float(x) for x in rng.uniform(-2, 2, 3) + np.array([0, 1.5, cam_z])]),
                                                                    P.point(0, 0, 0), P.vector(0, 1, 0)))
     return P.World(objs, light), camera, int(rng.integers(0, 6))
 
@@ -161,7 +170,7 @@ def _world(seed, P):
 # RTC_FUZZ_SEEDS=a:b widens the search (development); the default range is what the suite runs
 # 2133: a cone's stray root (cone.rs:99-107) outside its group's box, which distance pruning used to skip
 _SEEDS = (range(*[int(v) for v in os.environ["RTC_FUZZ_SEEDS"].split(":")]) if os.environ.get("RTC_FUZZ_SEEDS")
-          else list(range(60)) + [2133] + list(range(4002, 4030, 7)) + list(range(4003, 4031, 7)))  # + nested glass, + meshes
+          else list(range(60)) + [2133] + list(range(4002, 4030, 7)) + list(range(4003, 4031, 7)) + list(range(9007, 9040, 8)))  # + nested glass, + meshes, + extreme sizes
 
 
 @pytest.mark.parametrize("seed", _SEEDS)
