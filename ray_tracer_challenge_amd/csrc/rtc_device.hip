@@ -610,6 +610,10 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         }
         if (gi != scene->n_groups)
             return fail(RTC_ERR_INVALID_ARG, "group %u: groups must be listed in pre-order with first_object inside [0, n_objects)", gi);
+        // boxed triangle leaves that follow one another are pre-culled two at a time (for_each_object): mark the first of a pair
+        for (size_t e = 0; e + 1 < trav.size() / TRAV_STRIDE; e++)
+            if (trav[TRAV_STRIDE * e + 1].w == TRAV_BOXED_LEAF_TAG && trav[TRAV_STRIDE * (e + 1) + 1].w == TRAV_BOXED_LEAF_TAG)
+                trav[TRAV_STRIDE * e + 2].w = 1.0f;
         // A small tree (<= 8 leaves under <= 8 groups) keeps the unrolled flat kernels: every group becomes a GATE -- its box,
         // tested once per ray with the reference's own aabb test -- and a leaf is intersected only if the ray opens all the
         // groups around it, which is all the recursive walk does (group.rs:115-133).  Same leaves in the same order.

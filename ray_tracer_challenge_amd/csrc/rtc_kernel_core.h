@@ -531,7 +531,7 @@ struct SceneSoA {
     //          slack = 1e-3 * the box's largest |coordinate| (pruning margin, see for_each_object)
     //   leaf : { 0, 0, 0, object index }, { 0, 0, 0, -1 }, unused
     //   leaf, a triangle with a pre-culling box (tri_precull; world space, padded on the host -- rtc_device.hip triangle_box):
-    //          { box.min.xyz, object index }, { box.max.xyz, -2 }, { unit normal.xyz, 0 }
+    //          { box.min.xyz, object index }, { box.max.xyz, -2 }, { unit normal.xyz, 1 if the next entry is such a leaf too }
     const float4* __restrict__ trav;
     // Triangles (shape/triangle.rs:9-17), 3 records per object, read only for RTC_TRIANGLE objects:
     //   { p1.xyz, normal.x }, { e1.xyz, normal.y }, { e2.xyz, normal.z }
@@ -1018,6 +1018,17 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
                     if (!inside) resume = skip;
                 }
                 k = __any(inside) ? k + 1u : skip;
+            } else if (e1.w == TRAV_BOXED_LEAF_TAG && e2.w > 0.0f) {  // wave-uniform
+                // a boxed triangle followed by another one (e2.w, set on the host): both pre-culling tests at once.  In the
+                // long runs of such leaves the walk is one wave's chain of dependent instructions; two independent chains
+                // interleave.  Visiting order, and what each visit sees of the other's result (wr.limit), are unchanged.
+                const RawF4 q0 = ep[3], q1 = ep[4], q2 = ep[5];
+                const float4 f0 = make_float4(q0.x, q0.y, q0.z, q0.w), f1 = make_float4(q1.x, q1.y, q1.z, q1.w),
+                             f2 = make_float4(q2.x, q2.y, q2.z, q2.w);
+                const bool cull0 = tri_precull(wr, e0, e1, e2), cull1 = tri_precull(wr, f0, f1, f2);
+                if (active && !cull0) body(__float_as_uint(e0.w));
+                if (k + 1u >= resume && wr.limit > -RTC_INF && !cull1) body(__float_as_uint(f0.w));
+                k += 2u;
             } else {
                 bool visit = active;
                 if (e1.w == TRAV_BOXED_LEAF_TAG) visit = visit && !tri_precull(wr, e0, e1, e2);  // wave-uniform branch
