@@ -611,9 +611,12 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         if (gi != scene->n_groups)
             return fail(RTC_ERR_INVALID_ARG, "group %u: groups must be listed in pre-order with first_object inside [0, n_objects)", gi);
         // boxed triangle leaves that follow one another are pre-culled two at a time (for_each_object): mark the first of a pair
-        for (size_t e = 0; e + 1 < trav.size() / TRAV_STRIDE; e++)
-            if (trav[TRAV_STRIDE * e + 1].w == TRAV_BOXED_LEAF_TAG && trav[TRAV_STRIDE * (e + 1) + 1].w == TRAV_BOXED_LEAF_TAG)
-                trav[TRAV_STRIDE * e + 2].w = 1.0f;
+        for (size_t e = 0, ne = trav.size() / TRAV_STRIDE; e < ne; e++) {
+            if (trav[TRAV_STRIDE * e + 1].w != TRAV_BOXED_LEAF_TAG) continue;
+            int more = 0;  // boxed leaves right after this one, up to 3
+            while (more < 3 && e + more + 1 < ne && trav[TRAV_STRIDE * (e + more + 1) + 1].w == TRAV_BOXED_LEAF_TAG) more++;
+            trav[TRAV_STRIDE * e + 2].w = (float)more;
+        }
         // A small tree (<= 8 leaves under <= 8 groups) keeps the unrolled flat kernels: every group becomes a GATE -- its box,
         // tested once per ray with the reference's own aabb test -- and a leaf is intersected only if the ray opens all the
         // groups around it, which is all the recursive walk does (group.rs:115-133).  Same leaves in the same order.
@@ -1064,6 +1067,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
             std::vector<std::string> defs = {std::string("-DRTC_SPEC_LIST=") + b,
                                              uniform ? std::string("-DRTC_SPEC_UNIFORM_BITS=") + b : std::string("-DRTC_SPEC_RUNTIME_BITS=1"),
                                              "-DRTC_SPEC_NOBJ=-1", "-DRTC_SPEC_SIMPLE=0", "-DRTC_WAVES_PER_SIMD=" + tree_jit_waves(),
+                                             std::string("-DRTC_SPEC_TBOX=") + (hdr.has_tbox ? "1" : "0"),
                                              "-DRTC_SPEC_LIGHT_KIND=" + std::to_string(hdr.light_kind),
                                              "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
                                              std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};

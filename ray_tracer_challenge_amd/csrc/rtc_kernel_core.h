@@ -589,6 +589,11 @@ DI uint32_t spec_bits(uint32_t i, uint32_t) {
 DI int32_t spec_light_kind(int32_t) { return RTC_SPEC_LIGHT_KIND; }
 DI int32_t spec_jitter_mode(int32_t) { return RTC_SPEC_JITTER; }
 DI bool spec_has_patterns(uint32_t) { return RTC_SPEC_PATTERNS != 0; }
+#ifdef RTC_SPEC_TBOX
+DI bool spec_has_tbox(uint32_t) { return RTC_SPEC_TBOX != 0; }  // the scene has pre-culling boxes (tree walks)
+#else
+DI bool spec_has_tbox(uint32_t h) { return h != 0; }
+#endif
 #ifdef RTC_SPEC_GATES
 DI bool spec_has_gates(uint32_t) { return RTC_SPEC_GATES != 0; }
 #else
@@ -600,6 +605,7 @@ DI int32_t spec_light_kind(int32_t k) { return k; }
 DI int32_t spec_jitter_mode(int32_t m) { return m; }
 DI bool spec_has_patterns(uint32_t h) { return h != 0; }
 DI bool spec_has_gates(uint32_t n) { return n != 0; }
+DI bool spec_has_tbox(uint32_t h) { return h != 0; }
 #endif
 
 constexpr float PLANE_EPS = 1.1920929e-7f * 10000.0f;  // plane.rs:49  f32::EPSILON * 10000.0
@@ -1018,7 +1024,23 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
                     if (!inside) resume = skip;
                 }
                 k = __any(inside) ? k + 1u : skip;
-            } else if (e1.w == TRAV_BOXED_LEAF_TAG && e2.w > 0.0f) {  // wave-uniform
+            } else if (spec_has_tbox(H.has_tbox) && e1.w == TRAV_BOXED_LEAF_TAG && e2.w >= 3.0f) {  // wave-uniform: three more such leaves follow
+                float4 f[3][3];
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+#pragma unroll
+                    for (int r = 0; r < 3; r++) {
+                        const RawF4 q = ep[3 * (j + 1) + r];
+                        f[j][r] = make_float4(q.x, q.y, q.z, q.w);
+                    }
+                const bool c0 = tri_precull(wr, e0, e1, e2), c1 = tri_precull(wr, f[0][0], f[0][1], f[0][2]),
+                           c2 = tri_precull(wr, f[1][0], f[1][1], f[1][2]), c3 = tri_precull(wr, f[2][0], f[2][1], f[2][2]);
+                if (active && !c0) body(__float_as_uint(e0.w));
+                if (k + 1u >= resume && wr.limit > -RTC_INF && !c1) body(__float_as_uint(f[0][0].w));
+                if (k + 2u >= resume && wr.limit > -RTC_INF && !c2) body(__float_as_uint(f[1][0].w));
+                if (k + 3u >= resume && wr.limit > -RTC_INF && !c3) body(__float_as_uint(f[2][0].w));
+                k += 4u;
+            } else if (spec_has_tbox(H.has_tbox) && e1.w == TRAV_BOXED_LEAF_TAG && e2.w > 0.0f) {  // wave-uniform
                 // a boxed triangle followed by another one (e2.w, set on the host): both pre-culling tests at once.  In the
                 // long runs of such leaves the walk is one wave's chain of dependent instructions; two independent chains
                 // interleave.  Visiting order, and what each visit sees of the other's result (wr.limit), are unchanged.
@@ -1031,7 +1053,7 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
                 k += 2u;
             } else {
                 bool visit = active;
-                if (e1.w == TRAV_BOXED_LEAF_TAG) visit = visit && !tri_precull(wr, e0, e1, e2);  // wave-uniform branch
+                if (spec_has_tbox(H.has_tbox) && e1.w == TRAV_BOXED_LEAF_TAG) visit = visit && !tri_precull(wr, e0, e1, e2);  // wave-uniform branch
                 if (visit) body(__float_as_uint(e0.w));
                 k++;
             }
