@@ -433,6 +433,11 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     hdr->n_objects = n;
     const uint32_t np = padded_count(n);  // stride of each SoA array
     soa->assign((size_t)20 * np, make_float4(0, 0, 0, 0));
+    struct Extent {  // world_extent() of every object, computed once (a mesh leaf is asked for it by every group around it)
+        double lo[3], hi[3];
+        bool ok;
+    };
+    std::vector<Extent> extent(n);
     {
         uint32_t none = SHAPE_NONE;
         float none_f;
@@ -456,7 +461,10 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
             double lo[3], hi[3];  // bounding sphere: around the world-space box of the shape's own bounds
             float4 bs = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
             // (a cone's near-parallel branch, cone.rs:99-107, reports roots off the bounded cone: no sphere holds its hits)
-            if (o.kind != RTC_CONE && world_extent(o, lo, hi)) {
+            Extent& ex = extent[i];
+            ex.ok = world_extent(o, ex.lo, ex.hi);
+            for (int a = 0; a < 3; a++) lo[a] = ex.lo[a], hi[a] = ex.hi[a];
+            if (o.kind != RTC_CONE && ex.ok) {
                 double r2 = 0.0;
                 for (int a = 0; a < 3; a++) r2 += 0.25 * (hi[a] - lo[a]) * (hi[a] - lo[a]);
                 bs = make_float4((float)(0.5 * (lo[0] + hi[0])), (float)(0.5 * (lo[1] + hi[1])), (float)(0.5 * (lo[2] + hi[2])),
@@ -494,7 +502,8 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         for (uint32_t i = 0; i < n; i++) {
             any_triangle = any_triangle || scene->objects[i].kind == RTC_TRIANGLE;
             double olo[3], ohi[3];
-            if (world_extent(scene->objects[i], olo, ohi))
+            for (int a = 0; a < 3; a++) olo[a] = extent[i].lo[a], ohi[a] = extent[i].hi[a];
+            if (extent[i].ok)
                 for (int a = 0; a < 3; a++) lo[a] = std::fmin(lo[a], olo[a]), hi[a] = std::fmax(hi[a], ohi[a]);
         }
         if (cam) {
@@ -544,7 +553,8 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
             if ((uint64_t)grp.first_object + grp.n_objects > n) continue;  // reported below
             for (uint32_t i = grp.first_object; i < grp.first_object + grp.n_objects; i++) {
                 double lo[3], hi[3];
-                bool inside = world_extent(scene->objects[i], lo, hi);
+                bool inside = extent[i].ok;
+                for (int a = 0; a < 3; a++) lo[a] = extent[i].lo[a], hi[a] = extent[i].hi[a];
                 for (int a = 0; a < 3 && inside; a++) {
                     const double tol = 1e-5 * (std::fabs(lo[a]) + std::fabs(hi[a]) + 1.0);
                     inside = lo[a] >= (double)grp.bounds_min[a] - tol && hi[a] <= (double)grp.bounds_max[a] + tol;
