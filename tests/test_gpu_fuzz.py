@@ -164,13 +164,14 @@ def _world(seed, P):
     cam_z = -9.0 if style != 7 else float(-10.0 ** rng.uniform(1.0, 2.5))
     camera = (w, h, float(rng.uniform(0.6, 1.3)), P.view_transform(P.point(*[float(x) for x in rng.uniform(-2, 2, 3) + np.array([0, 1.5, cam_z])]),
                                                                    P.point(0, 0, 0), P.vector(0, 1, 0)))
-    return P.World(objs, light), camera, int(rng.integers(0, 6))
+    return P.World(objs, light), camera, int(rng.integers(0, 6)) if seed < 14000 else int(rng.integers(5, 9))  # up to RTC_MAX_DEPTH
 
 
 # RTC_FUZZ_SEEDS=a:b widens the search (development); the default range is what the suite runs
 # 2133: a cone's stray root (cone.rs:99-107) outside its group's box, which distance pruning used to skip
 _SEEDS = (range(*[int(v) for v in os.environ["RTC_FUZZ_SEEDS"].split(":")]) if os.environ.get("RTC_FUZZ_SEEDS")
-          else list(range(60)) + [2133] + list(range(4002, 4030, 7)) + list(range(4003, 4031, 7)) + list(range(9007, 9040, 8)))  # + nested glass, + meshes, + extreme sizes
+          else list(range(60)) + [2133] + list(range(4002, 4030, 7)) + list(range(4003, 4031, 7)) + list(range(9007, 9040, 8)) +  # + nested glass, + meshes, + extreme sizes
+             [14005, 14013, 14021, 14029])  # + recursion depth 5..8 on the glass-and-mirror style
 
 
 @pytest.mark.parametrize("seed", _SEEDS)
