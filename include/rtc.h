@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTC_ABI_VERSION 6
+#define RTC_ABI_VERSION 7
 /* maximum reflection_recursion_depth accepted (reference default: 5, constants.rs:4) */
 #define RTC_MAX_DEPTH 8
 
@@ -186,7 +186,25 @@ typedef struct rtc_stats {
     uint32_t rows;        /* rows written to the output buffer                                                 */
     uint64_t culled_shadow_rays; /* of `rays`: area-light shadow rays whose answer ("lit") followed from the
                                     conservative light-cone cull, i.e. that tested no object       */
+    uint32_t flags;       /* RTC_STATS_*                                                                       */
+    float gather_ms;      /* rtc_render_ex: wall time from the first render launch to the last row's arrival in `out`
+                             minus nothing -- i.e. the whole render + transport pipeline of the call (0 elsewhere)  */
 } rtc_stats;
+/* rtc_stats.flags: the scene's kernel is an ahead-of-time instantiation although the specialisation policy asked for a
+ * scene-compiled one (hiprtc failed; same image, several times slower on area-light scenes).  rtc_ctx_jit_status()
+ * holds the compiler's message. */
+#define RTC_STATS_JIT_FALLBACK 1u
+
+/* Options of rtc_render_ex (SURVEY.md 8(b) `opts`).  Zero-initialise for the defaults. */
+typedef struct rtc_opts {
+    const int32_t* devices; /* the GPUs to split the image over (64-row bands dealt round-robin, camera.rs:80-85 has no   */
+    uint32_t n_devices;     /* order dependence between pixels); NULL / 0: device 0.  A device may be listed twice.      */
+    uint32_t band_rows;     /* 0 -> 64 */
+    int32_t quantize;       /* 0: `out` receives width*height*3 f32 (the Canvas);  1: width*height*3 u8 -- every channel */
+                            /* through scale_color (canvas.rs:39-43), i.e. the numbers Canvas::to_ppm prints             */
+    int32_t out_on_device;  /* 0: `out` is host memory (pinned memory from rtc_host_alloc is written without staging);   */
+                            /* 1: `out` is device memory on devices[0]: peers' bands travel GPU-to-GPU (xGMI)            */
+} rtc_opts;
 
 typedef struct rtc_ctx rtc_ctx;
 
@@ -280,7 +298,26 @@ rtc_status rtc_scene_validate(const rtc_scene* scene, const rtc_camera* camera);
 rtc_status rtc_render(const rtc_scene* scene, const rtc_camera* camera, int32_t depth, int32_t device,
                       float* out_rgb, rtc_stats* stats);
 
-/* Persistent context: scene resident in HBM, output left on the device. */
+/* The same with options: several devices (the image's bands are dealt round-robin over opts->devices, each device
+ * renders its bands while the previous ones are on their way to `out`), bytes instead of floats, device-resident
+ * output.  Contexts, device buffers, pinned staging memory and compiled kernels are kept per device between calls
+ * (rtc_render_release drops them), so a second frame costs the kernel plus the transfer.  stats: rays / shaded hits /
+ * pixels summed over the devices, kernel_ms = the largest per-device sum of kernel times, gather_ms = wall time of
+ * the render + transfer pipeline.  rtc_render(scene, camera, depth, device, out, stats) is rtc_render_ex with
+ * opts = {devices = &device, n_devices = 1}. */
+rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32_t depth, const rtc_opts* opts,
+                         void* out, rtc_stats* stats);
+/* Frees everything rtc_render / rtc_render_ex keep between calls (all devices). */
+void rtc_render_release(void);
+/* Page-locked host memory (hipHostMalloc): an `out` buffer allocated here is filled by DMA straight from the device. */
+void* rtc_host_alloc(size_t bytes);
+void rtc_host_free(void* p);
+
+/* Persistent context: scene resident in HBM, output left on the device.
+ * Ordering contract: a context serves ONE stream at a time.  rtc_ctx_render is asynchronous; launches on the same
+ * stream queue up behind each other, but rendering from one context on two streams concurrently is a race on the
+ * context's counters.  rtc_ctx_set_scene waits for every launch the context has issued before it replaces the scene
+ * (it synchronises the device), so it may be called right after an asynchronous render. */
 rtc_status rtc_ctx_create(int32_t device, rtc_ctx** out);
 void rtc_ctx_destroy(rtc_ctx* ctx);
 /* Flattens the scene to structure-of-arrays records and uploads it. */
@@ -298,6 +335,11 @@ rtc_status rtc_ctx_stats(rtc_ctx* ctx, rtc_stats* out);
  * ("render_kernel<4,simple>") or a scene-specialised one compiled at rtc_ctx_set_scene
  * ("render_kernel_spec[...]"; env RTC_AMD_SPECIALIZE=0|1 overrides the size-based default). */
 const char* rtc_ctx_kernel_name(rtc_ctx* ctx);
+/* "" when the current scene's kernel is what the specialisation policy asked for; otherwise why it is not (the hiprtc
+ * failure), in which case rtc_stats.flags carries RTC_STATS_JIT_FALLBACK and a warning went to stderr once (silence:
+ * RTC_AMD_QUIET=1).  The kernel source is embedded in the library: no file beside librtc_amd.so is read at run time.
+ * Compiled kernels are cached in <library dir>/jit_cache, or RTC_AMD_JIT_CACHE=<dir> (0: memory only). */
+const char* rtc_ctx_jit_status(rtc_ctx* ctx);
 /* canvas.rs:39-43 scale_color on the device: n f32 channel values -> n bytes
  * ((c*255).min(255).max(0) as u8).  Both pointers are device pointers. */
 rtc_status rtc_ctx_quantize(rtc_ctx* ctx, const void* d_rgb, uint64_t n, void* d_out_u8, void* stream);

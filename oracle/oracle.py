@@ -508,7 +508,7 @@ def CubicMap(front, back, left, right, up, down, transform=None):
 
 
 class PpmParseError(ValueError):
-    VARIANTS = ("IoError", "IncorrectFormat", "ParseIntError", "MalformedDimensionHeader")
+    VARIANTS = ("IoError", "IncorrectFormat", "ParseIntError", "MalformedDimensionHeader", "PixelOutOfBounds (panic)")
 
     def __init__(self, code):
         super().__init__(self.VARIANTS[code - 1])

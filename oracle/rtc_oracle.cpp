@@ -656,9 +656,10 @@ Tuple normal_at(const Shape& s, Tuple world_point) {
 
 // ------------------------------------------------------------------- jitter
 // The reference draws from thread_rng() (rectangle_light.rs:46), which is
-// irreproducible.  Pinned replacement (specified in DESIGN.md, implemented
-// independently here and in the HIP kernel): a counter-based hash keyed by
-// (pixel, path code, cell, draw).
+// irreproducible.  Pinned replacement (specified in DESIGN.md,
+// implemented independently here and in the HIP kernel): a counter-based hash
+// keyed by (pixel, path code, cell, draw) -- one 32-bit mix per draw -- mapped
+// to the 23-bit grid of rand's OpenClosed01, ((h >> 9) + 1) * 2^-23 in (0, 1].
 inline uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7feb352du;
@@ -670,10 +671,9 @@ inline uint32_t mix32(uint32_t x) {
 inline uint32_t jitter_hash(uint32_t seed, uint32_t pixel, uint32_t path, uint32_t cell, uint32_t draw) {
     uint32_t a = mix32(pixel ^ seed);
     uint32_t b = mix32(a + path * 0x9E3779B9u);
-    uint32_t h = mix32(b + cell * 0x85EBCA6Bu);
-    return draw ? (h & 0xffffu) : (h >> 16);  // one hash per cell: draw 0 = high half, draw 1 = low half
+    return mix32(b + (2u * cell + draw) * 0x85EBCA6Bu);
 }
-inline float jitter_value(uint32_t h16) { return (float)(h16 + 1u) * 1.52587890625e-05f; }  // (0,1], 2^-16 steps
+inline float jitter_value(uint32_t h) { return (float)((h >> 9) + 1u) * 1.1920928955078125e-07f; }  // (0,1], 2^-23 steps
 
 struct Light {
     int kind;
@@ -1645,6 +1645,7 @@ int rtco_canvas_from_ppm(const char* text, uint64_t len, uint32_t* w, uint32_t* 
     if (!parse_uint(dims[0], &width) || !parse_uint(dims[1], &height)) return 3;
     if (!parse_uint(clean[2], &scale_u)) return 3;
     const float scale = (float)(uint32_t)scale_u;
+    if (width * height > 0x0fffffffull) return 5;  // test infrastructure: no multi-GB canvases
     std::vector<float> img((size_t)width * height * 3, 0.0f);
     std::vector<uint32_t> raw;
     size_t x = 0, y = 0, head = 0;
@@ -1657,10 +1658,9 @@ int rtco_canvas_from_ppm(const char* text, uint64_t len, uint32_t* w, uint32_t* 
         while (raw.size() - head >= 3) {
             float r = (float)raw[head] / scale, g = (float)raw[head + 1] / scale, b = (float)raw[head + 2] / scale;
             head += 3;
-            if (x < width && y < height) {
-                float* px = &img[(y * width + x) * 3];
-                px[0] = r, px[1] = g, px[2] = b;
-            }
+            if (!(x < width && y < height)) return 5;  // canvas.rs:27: write_pixel indexes data[y][x] and panics
+            float* px = &img[(y * width + x) * 3];
+            px[0] = r, px[1] = g, px[2] = b;
             x += 1;
             if (x >= width) {
                 x = 0;

@@ -78,7 +78,15 @@ class rtc_partition(C.Structure):
 class rtc_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("shaded_hits", C.c_uint64), ("pixels", C.c_uint64),
                 ("kernel_ms", C.c_float), ("launches", C.c_uint32), ("rows", C.c_uint32),
-                ("culled_shadow_rays", C.c_uint64)]
+                ("culled_shadow_rays", C.c_uint64), ("flags", C.c_uint32), ("gather_ms", C.c_float)]
+
+
+RTC_STATS_JIT_FALLBACK = 1
+
+
+class rtc_opts(C.Structure):
+    _fields_ = [("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_uint32), ("band_rows", C.c_uint32),
+                ("quantize", C.c_int32), ("out_on_device", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/rtc.h
@@ -124,6 +132,11 @@ SIGNATURES = {
     "rtc_ray_for_pixel": (None, [C.POINTER(rtc_camera), C.c_uint32, C.c_uint32, FP, FP]),
     "rtc_render": (C.c_int, [C.POINTER(rtc_scene), C.POINTER(rtc_camera), C.c_int32, C.c_int32, FP,
                              C.POINTER(rtc_stats)]),
+    "rtc_render_ex": (C.c_int, [C.POINTER(rtc_scene), C.POINTER(rtc_camera), C.c_int32, C.POINTER(rtc_opts), C.c_void_p,
+                                C.POINTER(rtc_stats)]),
+    "rtc_render_release": (None, []),
+    "rtc_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "rtc_host_free": (None, [C.c_void_p]),
     "rtc_scene_validate": (C.c_int, [C.POINTER(rtc_scene), C.POINTER(rtc_camera)]),
     "rtc_ctx_create": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)]),
     "rtc_ctx_destroy": (None, [C.c_void_p]),
@@ -132,6 +145,7 @@ SIGNATURES = {
     "rtc_ctx_render": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(rtc_partition), C.c_void_p, C.c_void_p]),
     "rtc_ctx_stats": (C.c_int, [C.c_void_p, C.POINTER(rtc_stats)]),
     "rtc_ctx_kernel_name": (C.c_char_p, [C.c_void_p]),
+    "rtc_ctx_jit_status": (C.c_char_p, [C.c_void_p]),
     "rtc_ctx_quantize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rtc_ppm_max_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32]),
     "rtc_ctx_to_ppm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,

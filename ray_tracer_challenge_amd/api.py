@@ -883,17 +883,26 @@ class Camera:
         L.lib().rtc_ray_for_pixel(C.byref(self._cam), int(x), int(y), _p(o), _p(d))
         return o, d
 
-    def render(self, world, reflection_recursion_depth, device=0):
-        """Camera::render (camera.rs:76-91) on the MI355X -> Canvas."""
-        img = np.zeros((self.height, self.width, 3), dtype=f32)
+    def render(self, world, reflection_recursion_depth, device=0, devices=None, quantize=False, band_rows=0, out=None):
+        """Camera::render (camera.rs:76-91) on the MI355X -> Canvas.
+
+        devices: the GPUs to split the image over (rtc_render_ex; default: [device]).  quantize: return the (h, w, 3) u8
+        array of scale_color'd channels (canvas.rs:39-43) instead of a Canvas.  out: a caller-provided array to fill."""
+        devs = [int(device)] if devices is None else [int(d) for d in devices]
+        dtype = np.uint8 if quantize else f32
+        img = np.zeros((self.height, self.width, 3), dtype=dtype) if out is None else out
+        assert img.dtype == dtype and img.shape == (self.height, self.width, 3) and img.flags["C_CONTIGUOUS"]
         stats = L.rtc_stats()
         cs = world._c()
-        L.check(L.lib().rtc_render(C.byref(cs.scene), C.byref(self._cam), int(reflection_recursion_depth), device,
-                                   _p(img), C.byref(stats)))
+        arr = (C.c_int32 * len(devs))(*devs)
+        opts = L.rtc_opts(arr, len(devs), int(band_rows), 1 if quantize else 0, 0)
+        L.check(L.lib().rtc_render_ex(C.byref(cs.scene), C.byref(self._cam), int(reflection_recursion_depth), C.byref(opts),
+                                      img.ctypes.data_as(C.c_void_p), C.byref(stats)))
         self.last_stats = {"rays": int(stats.rays), "shaded_hits": int(stats.shaded_hits),
                            "pixels": int(stats.pixels), "kernel_ms": float(stats.kernel_ms),
-                           "culled_shadow_rays": int(stats.culled_shadow_rays)}
-        return Canvas(self.width, self.height, img)
+                           "culled_shadow_rays": int(stats.culled_shadow_rays), "launches": int(stats.launches),
+                           "call_ms": float(stats.gather_ms), "flags": int(stats.flags)}
+        return img if quantize else Canvas(self.width, self.height, img)
 
 
 def powf(x, y, device=0):

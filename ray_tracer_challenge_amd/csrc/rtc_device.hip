@@ -771,6 +771,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     hdr->all_cast = 1;
     for (uint32_t i = 0; i < n; i++)
         if (!scene->objects[i].casts_shadow) hdr->all_cast = 0;
+    hdr->cull_flags = (env_flag("RTC_AMD_LIGHT_CULL", true) ? CULL_ENABLED : 0u) | (env_flag("RTC_AMD_DARK", true) ? CULL_DARK : 0u);
     hdr->uvrec_off = (uint32_t)soa->size();
     soa->insert(soa->end(), uvrec.begin(), uvrec.end());
     if (cam) {
@@ -812,9 +813,15 @@ struct rtc_ctx {
     bool spec_shares = false;         // spec_fn was compiled with -DRTC_SPEC_SHARE=1
     hipFunction_t spec_fn = nullptr;  // scene-specialised kernel (hiprtc), or null: ahead-of-time kernels
     std::string kernel_name;          // what rtc_ctx_render launches, for rtc_ctx_kernel_name()
+    std::string jit_note;             // why spec_fn is null although the policy wanted one (rtc_ctx_jit_status)
+    // the scene as last uploaded: an identical one (rtc_render_ex called again for the next frame) is not uploaded twice
+    std::vector<float4> soa_host;
+    std::vector<float> texels_host;
     uint4* d_block_counts = nullptr;
     size_t block_cap = 0;
-    unsigned long long* d_total = nullptr;  // {rays, shaded hits, culled shadow rays} of the last launch
+    // {rays, shaded hits, culled shadow rays} per counter slot: slot 0 = the last rtc_ctx_render launch; rtc_render_ex
+    // renders a frame in several launches (row chunks in flight while earlier ones travel) and gives each its own
+    unsigned long long* d_total = nullptr;
     // HIP-event pairs around the render kernel, one per launch since the last rtc_ctx_stats
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -877,6 +884,20 @@ int specialise_policy() {  // 0 never, 1 always, 2 auto
     return e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;
 }
 
+// The kernel source travels inside the library: rtc_kernel_core_embed.inc is rtc_kernel_core.h as a string literal,
+// written by ray_tracer_challenge_amd/build.py before every compile (under hiprtc the header needs no other file).  A
+// deployment is librtc_amd.so alone -- no csrc/ or include/ beside it.  RTC_AMD_JIT_SOURCE=<path> (development) reads
+// the header from disk instead, so a kernel experiment needs no rebuild of the library.
+const char k_core_src[] =
+#include "rtc_kernel_core_embed.inc"
+    ;
+
+std::string jit_cache_dir() {  // RTC_AMD_JIT_CACHE=<dir>, or 0 / off to keep compiled kernels in memory only; default <lib dir>/jit_cache
+    const char* e = std::getenv("RTC_AMD_JIT_CACHE");
+    if (e && *e) return (std::strcmp(e, "0") == 0 || std::strcmp(e, "off") == 0) ? std::string() : std::string(e);
+    return lib_dir() + "/jit_cache";
+}
+
 // Compiles (or fetches) the specialised kernel for `defines` on the current device.
 rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunction_t* out) {
     std::string key = std::to_string(device) + "|";
@@ -887,13 +908,13 @@ rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunct
         *out = it->second.fn;
         return RTC_OK;
     }
-    const std::string dir = lib_dir();
-    const std::string csrc = dir + "/csrc", inc = dir + "/../include";
-    std::string core;
-    if (!read_file(csrc + "/rtc_kernel_core.h", &core))
-        return fail(RTC_ERR_DEVICE, "scene specialisation: cannot read %s/rtc_kernel_core.h", csrc.c_str());
-    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
-                                     "-I" + csrc, "-I" + inc};
+    std::string core_file;
+    const char* core = k_core_src;
+    if (const char* src_path = std::getenv("RTC_AMD_JIT_SOURCE")) {
+        if (!read_file(src_path, &core_file)) return fail(RTC_ERR_DEVICE, "scene specialisation: cannot read RTC_AMD_JIT_SOURCE=%s", src_path);
+        core = core_file.c_str();
+    }
+    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
     for (const auto& d : defines) opts.push_back(d);
     // occupancy target of the specialised kernel: measured 4 -> 3.39, 5 -> 3.42, 6 -> 3.24, 7 -> 3.17, 8 -> 3.17 ms (C3) before
     // light-cone culling; with it (more state per shade point) 5 -> 0.98, 6 -> 0.97, 7 -> 0.95, 8 -> 1.02 ms (tools/ab_waves.sh)
@@ -905,17 +926,22 @@ rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunct
         std::string tok;
         while (ss >> tok) opts.push_back(tok);
     }
-    // disk cache keyed by the source text and every option
+    // disk cache keyed by the source text, every option, the compiler's version and the ABI the argument block follows
     std::string opt_text;
     for (const auto& o : opts) opt_text += o + "\n";
+    int rtc_major = 0, rtc_minor = 0;
+    (void)hiprtcVersion(&rtc_major, &rtc_minor);
+    opt_text += "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + " abi " + std::to_string(RTC_ABI_VERSION) +
+                " args " + std::to_string(sizeof(RenderArgs)) + "\n";
     char name[64];
     snprintf(name, sizeof(name), "spec_%016llx.hsaco", (unsigned long long)fnv1a(opt_text, fnv1a(core)));
-    const std::string cache_dir = dir + "/jit_cache", cache_path = cache_dir + "/" + name;
-    std::string code;
-    if (!read_file(cache_path, &code) || code.empty()) {
+    const std::string cache_dir = jit_cache_dir(), cache_path = cache_dir + "/" + name;
+    auto compile = [&](std::string* code) -> rtc_status {
         hiprtcProgram prog;
         const char* src = "#include \"rtc_kernel_core.h\"\n";
-        if (hiprtcCreateProgram(&prog, src, "rtc_scene_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        const char* headers[] = {core};
+        const char* header_names[] = {"rtc_kernel_core.h"};
+        if (hiprtcCreateProgram(&prog, src, "rtc_scene_spec.hip", 1, headers, header_names) != HIPRTC_SUCCESS)
             return fail(RTC_ERR_DEVICE, "hiprtcCreateProgram failed");
         std::vector<const char*> copts;
         for (const auto& o : opts) copts.push_back(o.c_str());
@@ -930,23 +956,45 @@ rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunct
         }
         size_t n = 0;
         hiprtcGetCodeSize(prog, &n);
-        code.resize(n);
-        hiprtcGetCode(prog, &code[0]);
+        code->resize(n);
+        hiprtcGetCode(prog, &(*code)[0]);
         hiprtcDestroyProgram(&prog);
-        // best effort: a read-only tree just means every process compiles for itself
-        std::string tmp = cache_path + "." + std::to_string((long)getpid());
-        if (::mkdir(cache_dir.c_str(), 0777) == 0 || errno == EEXIST) {
-            std::ofstream f(tmp, std::ios::binary);
-            if (f) {
-                f.write(code.data(), (std::streamsize)code.size());
-                f.close();
-                (void)std::rename(tmp.c_str(), cache_path.c_str());
+        // best effort: a read-only tree just means every process compiles for itself.  Only a completely written file
+        // is published (a short write -- disk full, quota -- would otherwise poison the cache for every later run).
+        if (!cache_dir.empty() && (::mkdir(cache_dir.c_str(), 0777) == 0 || errno == EEXIST)) {
+            const std::string tmp = cache_path + "." + std::to_string((long)getpid());
+            bool ok = false;
+            {
+                std::ofstream f(tmp, std::ios::binary);
+                if (f) {
+                    f.write(code->data(), (std::streamsize)code->size());
+                    f.close();
+                    ok = f.good();
+                }
             }
+            if (!ok || std::rename(tmp.c_str(), cache_path.c_str()) != 0) (void)::unlink(tmp.c_str());
         }
+        return RTC_OK;
+    };
+    std::string code;
+    const bool cached = !cache_dir.empty() && read_file(cache_path, &code) && !code.empty();
+    if (!cached) {
+        rtc_status st = compile(&code);
+        if (st != RTC_OK) return st;
     }
     JitModule m;
-    HIP_TRY(hipModuleLoadData(&m.mod, code.data()));
-    HIP_TRY(hipModuleGetFunction(&m.fn, m.mod, "render_kernel_spec"));
+    hipError_t le = hipModuleLoadData(&m.mod, code.data());
+    if (le == hipSuccess) le = hipModuleGetFunction(&m.fn, m.mod, "render_kernel_spec");
+    if (le != hipSuccess && cached) {
+        // a cached code object that does not load (truncated, or from another toolchain): drop it and compile once
+        (void)hipGetLastError();
+        (void)::unlink(cache_path.c_str());
+        rtc_status st = compile(&code);
+        if (st != RTC_OK) return st;
+        le = hipModuleLoadData(&m.mod, code.data());
+        if (le == hipSuccess) le = hipModuleGetFunction(&m.fn, m.mod, "render_kernel_spec");
+    }
+    if (le != hipSuccess) return fail(RTC_ERR_DEVICE, "scene specialisation: the compiled kernel does not load: %s", hipGetErrorString(le));
     g_jit_cache[key] = m;
     *out = m.fn;
     return RTC_OK;
@@ -994,8 +1042,8 @@ rtc_status rtc_ctx_create(int32_t device, rtc_ctx** out) {
     HIP_TRY(hipSetDevice(device));
     rtc_ctx* c = new rtc_ctx();
     c->device = device;
-    HIP_TRY(hipMalloc(&c->d_total, 3 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->d_total, 0, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&c->d_total, 3 * CTX_TOTAL_SLOTS * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_total, 0, 3 * CTX_TOTAL_SLOTS * sizeof(unsigned long long)));
     *out = c;
     return RTC_OK;
 }
@@ -1016,6 +1064,27 @@ void rtc_ctx_destroy(rtc_ctx* c) {
     delete c;
 }
 
+// The policy wanted a scene-compiled kernel and hiprtc did not deliver one.  RTC_AMD_SPECIALIZE=1: an error.  Default
+// policy: the ahead-of-time kernel renders the same image -- several times slower on area-light scenes -- so say so:
+// rtc_ctx_jit_status(), rtc_stats.flags, one line on stderr per process.
+static rtc_status jit_failed(rtc_ctx* c, int policy, rtc_status jst) {
+    c->spec_fn = nullptr;
+    c->spec_shares = false;
+    c->jit_note = rtc_last_error();
+    if (policy == 1) {
+        c->has_scene = false;
+        c->soa_host.clear();
+        return jst;
+    }
+    static bool warned = false;
+    if (!warned && !env_flag("RTC_AMD_QUIET", false)) {
+        warned = true;
+        std::fprintf(stderr, "librtc_amd: scene specialisation unavailable, rendering with the slower ahead-of-time kernel %s: %.300s\n",
+                     c->kernel_name.c_str(), c->jit_note.c_str());
+    }
+    return RTC_OK;
+}
+
 rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camera* camera) {
     if (!c) return fail(RTC_ERR_INVALID_ARG, "ctx is NULL");
     SceneHdr hdr;
@@ -1024,16 +1093,33 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     rtc_status st = flatten(scene, camera, &hdr, &soa, &texels);
     if (st != RTC_OK) return st;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->has_scene && std::memcmp(&hdr, &c->hdr, sizeof(hdr)) == 0 && soa.size() == c->soa_host.size() &&
+        texels.size() == c->texels_host.size() && std::memcmp(soa.data(), c->soa_host.data(), soa.size() * sizeof(float4)) == 0 &&
+        (texels.empty() || std::memcmp(texels.data(), c->texels_host.data(), texels.size() * sizeof(float)) == 0))
+        return RTC_OK;  // the very scene that is resident (records, camera, light, switches): nothing to replace
+    // Renders are asynchronous on caller streams (torch's are non-blocking: the null-stream copies below do not order
+    // against them), and a render still in flight reads the records and the counters this call replaces.  Wait for
+    // everything the context has launched before touching them.  (rtc.h: one stream at a time per context.)
+    HIP_TRY(hipDeviceSynchronize());
+    // until the new scene is fully resident the context has none: a failed allocation below must not leave a stale
+    // capacity beside a null pointer, nor a render path that believes the old scene is still there
+    c->has_scene = false;
+    c->spec_fn = nullptr;
+    c->jit_note.clear();
+    c->soa_host.clear();
+    c->texels_host.clear();
     if (texels.size() > c->texel_cap) {
-        if (c->d_texels) HIP_TRY(hipFree(c->d_texels));
+        if (c->d_texels) (void)hipFree(c->d_texels);
         c->d_texels = nullptr;
+        c->texel_cap = 0;
         HIP_TRY(hipMalloc(&c->d_texels, texels.size() * sizeof(float)));
         c->texel_cap = texels.size();
     }
     if (!texels.empty()) HIP_TRY(hipMemcpy(c->d_texels, texels.data(), texels.size() * sizeof(float), hipMemcpyHostToDevice));
     if (soa.size() > c->soa_cap) {
-        if (c->d_soa) HIP_TRY(hipFree(c->d_soa));
+        if (c->d_soa) (void)hipFree(c->d_soa);
         c->d_soa = nullptr;
+        c->soa_cap = 0;
         HIP_TRY(hipMalloc(&c->d_soa, soa.size() * sizeof(float4)));
         c->soa_cap = soa.size();
     }
@@ -1048,6 +1134,8 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         if (!(bits & SHAPE_DIAG) || kind == RTC_CYLINDER || kind == RTC_CONE || kind == RTC_TRIANGLE) c->simple = false;
     }
     c->has_scene = true;
+    c->soa_host = soa;
+    c->texels_host = texels;
     // which kernel will render this scene
     c->spec_fn = nullptr;
     // sample-parallel rendering (render_body): compiled in when this frame is small enough to want it
@@ -1084,9 +1172,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
             defs.push_back(share_def);
             rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
             if (jst != RTC_OK) {
-                if (policy == 1) return jst;
-                c->spec_fn = nullptr;
-                c->spec_shares = false;
+                if ((jst = jit_failed(c, policy, jst)) != RTC_OK) return jst;
             } else {
                 c->kernel_name = std::string("render_kernel_spec[") + how + (uniform ? std::string(";all ") + b : std::string()) +
                                  (hdr.has_patterns ? ";patterns" : "") + "]";
@@ -1114,10 +1200,9 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         defs.push_back(std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0"));
         defs.push_back(std::string("-DRTC_SPEC_GATES=") + (hdr.n_gates ? "1" : "0"));
         defs.push_back(share_def);
-            rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
+        rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
         if (jst != RTC_OK) {
-            if (policy == 1) return jst;  // explicitly requested: report
-            c->spec_fn = nullptr;         // auto: the ahead-of-time kernel computes the same image
+            if ((jst = jit_failed(c, policy, jst)) != RTC_OK) return jst;
         } else {
             c->kernel_name = "render_kernel_spec[" + list.substr(16) + (c->simple ? ";simple" : "") + (hdr.has_patterns ? ";patterns" : "") +
                              (hdr.n_gates ? ";gates" : "") + "]";
@@ -1144,9 +1229,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
             defs.push_back(share_def);
             rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
             if (jst != RTC_OK) {
-                if (policy == 1) return jst;
-                c->spec_fn = nullptr;
-                c->spec_shares = false;
+                if ((jst = jit_failed(c, policy, jst)) != RTC_OK) return jst;
             } else {
                 c->kernel_name = std::string("render_kernel_spec[all ") + b + (hdr.has_patterns ? ";patterns" : "") + "]";
             }
@@ -1155,9 +1238,15 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     return RTC_OK;
 }
 
-rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, void* d_out_rgb, void* stream_) {
-    if (!c || !d_out_rgb) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_render: null argument");
+}  // extern "C"
+
+// rtc_ctx_render with a counter slot of the caller's choosing (rtc_internal.h)
+rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* part, void* d_out_rgb, void* stream_, uint32_t slot) {
+    if (!c) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_render: null argument");
+    if (slot >= CTX_TOTAL_SLOTS) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_render: counter slot %u", slot);
     if (!c->has_scene || c->hdr.width == 0) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_render: no scene/camera set");
+    // a partition that owns no band (height < band_rows * n_parts) has nothing to write and may pass a null buffer
+    if (!d_out_rgb && partition_rows(c->hdr.height, part) != 0) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_render: null output buffer");
     if (depth < 0 || depth > RTC_MAX_DEPTH)
         return fail(RTC_ERR_INVALID_ARG, "depth %d outside [0, %d]", depth, RTC_MAX_DEPTH);
     Partition q = resolve(part);
@@ -1197,7 +1286,7 @@ rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, 
     a.soa = soa_view(c->d_soa, c->hdr, c->d_texels);
     a.out = (float*)d_out_rgb;
     a.block_counts = c->d_block_counts;
-    a.total = c->d_total;
+    a.total = c->d_total + 3 * (size_t)slot;
     a.rows = rows;
     a.band_rows = q.band_rows;
     a.n_parts = q.n_parts;
@@ -1229,10 +1318,42 @@ rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, 
     else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, 0, stream, a);
     HIP_TRY(hipEventRecord(ev.second, stream));
     hipLaunchKernelGGL(sum_counts_kernel, dim3((uint32_t)((n_blocks + SUM_COUNTS_SLICE - 1) / SUM_COUNTS_SLICE)), dim3(1024), 0, stream,
-                       c->d_block_counts, (uint32_t)n_blocks, c->d_total);
+                       c->d_block_counts, (uint32_t)n_blocks, c->d_total + 3 * (size_t)slot);
     HIP_TRY(hipGetLastError());
     c->rendered = true;
     return RTC_OK;
+}
+
+// After the caller has synchronised with every launch: counters summed over slots [0, n_slots), kernel_ms = the SUM
+// of the launches' HIP-event times since the last stats call (the launches of one frame run back to back).
+rtc_status rtc::ctx_collect(rtc_ctx* c, uint32_t n_slots, rtc_stats* out) {
+    std::memset(out, 0, sizeof(*out));
+    if (n_slots > CTX_TOTAL_SLOTS) n_slots = CTX_TOTAL_SLOTS;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<unsigned long long> total(3 * (size_t)n_slots, 0ull);
+    if (n_slots) HIP_TRY(hipMemcpy(total.data(), c->d_total, total.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (uint32_t s = 0; s < n_slots; s++) {
+        out->rays += total[3 * s];
+        out->shaded_hits += total[3 * s + 1];
+        out->culled_shadow_rays += total[3 * s + 2];
+    }
+    double sum_ms = 0.0;
+    for (size_t i = 0; i < c->events_used; i++) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->events[i].first, c->events[i].second));
+        sum_ms += ms;
+    }
+    out->kernel_ms = (float)sum_ms;
+    out->launches = (uint32_t)c->events_used;
+    out->flags = c->jit_note.empty() ? 0u : RTC_STATS_JIT_FALLBACK;
+    c->events_used = 0;
+    return RTC_OK;
+}
+
+extern "C" {
+
+rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, void* d_out_rgb, void* stream) {
+    return rtc::ctx_render_slot(c, depth, part, d_out_rgb, stream, 0u);
 }
 
 rtc_status rtc_ctx_stats(rtc_ctx* c, rtc_stats* out) {
@@ -1256,11 +1377,13 @@ rtc_status rtc_ctx_stats(rtc_ctx* c, rtc_stats* out) {
     out->culled_shadow_rays = total[2];
     out->launches = (uint32_t)c->events_used;
     out->kernel_ms = c->events_used ? (float)(sum_ms / (double)c->events_used) : 0.0f;
+    out->flags = c->jit_note.empty() ? 0u : RTC_STATS_JIT_FALLBACK;
     c->events_used = 0;
     return RTC_OK;
 }
 
 const char* rtc_ctx_kernel_name(rtc_ctx* c) { return c ? c->kernel_name.c_str() : ""; }
+const char* rtc_ctx_jit_status(rtc_ctx* c) { return c ? c->jit_note.c_str() : ""; }
 
 rtc_status rtc_ctx_quantize(rtc_ctx* c, const void* d_rgb, uint64_t n, void* d_out_u8, void* stream_) {
     if (!c || !d_rgb || !d_out_u8) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_quantize: null argument");
@@ -1316,40 +1439,6 @@ rtc_status rtc_ctx_to_ppm(rtc_ctx* c, const void* d_rgb, uint32_t width, uint32_
     HIP_TRY(hipStreamSynchronize(stream));  // `head` and `total` are host stack memory
     *out_len = total;
     return RTC_OK;
-}
-
-rtc_status rtc_render(const rtc_scene* scene, const rtc_camera* camera, int32_t depth, int32_t device, float* out_rgb,
-                      rtc_stats* stats) {
-    if (!out_rgb || !camera) return fail(RTC_ERR_INVALID_ARG, "rtc_render: null argument");
-    rtc_ctx* c = nullptr;
-    rtc_status st = rtc_ctx_create(device, &c);
-    if (st != RTC_OK) return st;
-    float* d_out = nullptr;
-    auto cleanup = [&]() {
-        if (d_out) (void)hipFree(d_out);
-        rtc_ctx_destroy(c);
-    };
-    st = rtc_ctx_set_scene(c, scene, camera);
-    if (st != RTC_OK) {
-        cleanup();
-        return st;
-    }
-    const size_t bytes = (size_t)camera->width * camera->height * 3 * sizeof(float);
-    hipError_t e = hipMalloc(&d_out, bytes);
-    if (e != hipSuccess) {
-        cleanup();
-        return fail(RTC_ERR_DEVICE, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    }
-    st = rtc_ctx_render(c, depth, nullptr, d_out, nullptr);
-    rtc_stats s;
-    if (st == RTC_OK) st = rtc_ctx_stats(c, &s);
-    if (st == RTC_OK) {
-        e = hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) st = fail(RTC_ERR_DEVICE, "hipMemcpy D2H failed: %s", hipGetErrorString(e));
-    }
-    if (st == RTC_OK && stats) *stats = s;
-    cleanup();
-    return st;
 }
 
 // ---- batched test/utility entry points (host buffers) ---------------------------

@@ -314,9 +314,14 @@ rtc_status rtc_canvas_from_ppm(const char* text, uint64_t len, uint32_t* width, 
     if (!parse_uint(dims[0].b, dims[0].e, &w) || !parse_uint(dims[1].b, dims[1].e, &h) || !parse_uint(lines[2].b, lines[2].e, &scale_u))
         return fail(RTC_ERR_INVALID_ARG, "ParseIntError: invalid digit found in string");
     const float scale = (float)(uint32_t)scale_u;
-    const size_t n = (size_t)w * (size_t)h * 3;
+    // the header comes from an untrusted file: w * h * 3 * sizeof(f32) must not wrap, and an image the library's own
+    // texel index (32 bits, pack_uv_pattern) cannot address is refused here rather than at rtc_ctx_set_scene
+    size_t n = 0, n_bytes = 0;
+    if (__builtin_mul_overflow((size_t)w, (size_t)h, &n) || n > 0xffffffffull || __builtin_mul_overflow(n, (size_t)3, &n) ||
+        __builtin_mul_overflow(n, sizeof(float), &n_bytes))
+        return fail(RTC_ERR_INVALID_ARG, "canvas of %llu x %llu pixels is too large", (unsigned long long)w, (unsigned long long)h);
     float* img = (float*)std::calloc(n ? n : 1, sizeof(float));
-    if (!img) return fail(RTC_ERR_INVALID_ARG, "out of memory");
+    if (!img) return fail(RTC_ERR_INVALID_ARG, "out of memory (%llu x %llu canvas)", (unsigned long long)w, (unsigned long long)h);
     uint32_t pending[3];
     int have = 0;
     size_t x = 0, y = 0;
@@ -330,10 +335,13 @@ rtc_status rtc_canvas_from_ppm(const char* text, uint64_t len, uint32_t* width, 
             pending[have++] = (uint32_t)v;
             if (have == 3) {
                 have = 0;
-                if (x < w && y < h) {
-                    float* px = img + (y * w + x) * 3;
-                    for (int k = 0; k < 3; k++) px[k] = (float)pending[k] / scale;
+                if (!(x < w && y < h)) {  // canvas.rs:27 write_pixel indexes data[y][x]: the reference panics here
+                    std::free(img);
+                    return fail(RTC_ERR_INVALID_ARG, "PixelOutOfBounds: more pixel data than the %llu x %llu header announces "
+                                "(the reference panics in Canvas::write_pixel)", (unsigned long long)w, (unsigned long long)h);
                 }
+                float* px = img + (y * w + x) * 3;
+                for (int k = 0; k < 3; k++) px[k] = (float)pending[k] / scale;
                 if (++x >= w) {
                     x = 0;
                     y++;

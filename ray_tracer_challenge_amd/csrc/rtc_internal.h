@@ -60,6 +60,12 @@ inline uint32_t partition_rows(uint32_t height, const rtc_partition* p) {
     return rows;
 }
 
+// Hooks of rtc_device.hip for rtc_render_ex (rtc_oneshot.hip): a frame rendered as several launches, each with a
+// counter slot of its own.  `stream`: a hipStream_t.
+constexpr uint32_t CTX_TOTAL_SLOTS = 64;
+rtc_status ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* part, void* d_out_rgb, void* stream, uint32_t slot);
+rtc_status ctx_collect(rtc_ctx* c, uint32_t n_slots, rtc_stats* out);
+
 }  // namespace rtc
 
 #endif

@@ -502,7 +502,13 @@ struct SceneHdr {
     uint32_t n_gates;
     float gate_box[8][6];
     uint32_t gate_mask[8];
+    // Light-cone culling switches (light_cull_mask), set by the host from RTC_AMD_LIGHT_CULL / RTC_AMD_DARK (default: both
+    // on): bit 0 -- cull at all; bit 1 -- the `dark` shortcut (every sample blocked on the far side of a casting sphere),
+    // the one decision that asserts hits instead of removing tests.  Off, every shadow ray is tested against every
+    // object: the image and the ray counts must not change (tests/test_gpu_light_cull.py, whole frames).
+    uint32_t cull_flags;
 };
+constexpr uint32_t CULL_ENABLED = 1u, CULL_DARK = 2u;
 constexpr uint32_t RTC_MAX_GATES = 8;
 
 // Structure-of-arrays scene records in HBM: 4 float4 of geometry (64 B) and
@@ -1309,6 +1315,7 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p, bool& da
     bool casters_left = false;  // wave-uniform
     // the samples stay inside the parallelogram only for jitter in [0, 1] (the hashed source draws from (0, 1])
     const bool hashed = spec_jitter_mode(H.jitter_mode) == RTC_JITTER_HASHED;
+    if (!(H.cull_flags & CULL_ENABLED)) return 0u;
     if (!hashed && !(H.jitter_const >= 0.0f && H.jitter_const <= 1.0f)) return 0u;
     // a decision costs about as much as four or five ray-object tests: not worth it for a handful of samples
     if (H.u_steps * H.v_steps < 8) return 0u;
@@ -1485,13 +1492,13 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p, bool& da
             for (uint32_t i = 0; i < H.n_objects; i++) reach(i, false);
         }
     }
-    if (noncasters_left) dark = false;  // a non-caster might be hit first
+    if (noncasters_left || !(H.cull_flags & CULL_DARK)) dark = false;  // a non-caster might be hit first
     return mask;
 }
 
-// Pinned jitter (DESIGN.md "Jitter"): counter-based hash keyed by
-// (pixel, path code, cell); one 32-bit hash per light cell, high half -> first
-// draw, low half -> second draw, each mapped to (0, 1] in 2^-16 steps.
+// Pinned jitter (DESIGN.md "Jitter"): counter-based hash keyed by (pixel, path code, cell, draw):
+// h = mix32(base + (2 cell + draw) * 0x85EBCA6B), one 32-bit mix per draw, mapped to the 23-bit grid of rand's
+// OpenClosed01 (rectangle_light.rs:46): ((h >> 9) + 1) * 2^-23 in (0, 1].
 DI uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7feb352du;
@@ -1504,7 +1511,12 @@ DI uint32_t jitter_base(uint32_t seed, uint32_t pixel, uint32_t path) {
     uint32_t a = mix32(pixel ^ seed);
     return mix32(a + path * 0x9E3779B9u);
 }
-DI float jitter_value(uint32_t h16) { return (float)(h16 + 1u) * 1.52587890625e-05f; }
+// ((h >> 9) + 1) * 2^-23 without the int -> float conversion: {0x7f, h} >> 9 is the float 1 + (h >> 9) 2^-23 in [1, 2),
+// and subtracting 1 - 2^-23 from it is exact (the difference, (k + 1) 2^-23 <= 1, is representable).  Two instructions;
+// the same bits as the plain formula, which is what the oracle evaluates.
+DI float jitter_value(uint32_t h) {
+    return __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, h, 9u)) - 0.99999988079071044921875f;
+}
 
 // Light::intensity_at: point_light.rs:28-34, rectangle_light.rs:60-66, 76-88
 template <int NOBJ, bool SIMPLE>
@@ -1546,11 +1558,10 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
         for (int v = 0; v < H.v_steps; v++) {
             for (int u = 0; u < H.u_steps; u++) {
                 float j1 = H.jitter_const, j2 = H.jitter_const;
-                if (hashed) {
-                    uint32_t h = mix32(key);
-                    key += 0x85EBCA6Bu;  // key = base + cell * 0x85EBCA6B, cell = v * u_steps + u
-                    j1 = jitter_value(h >> 16);
-                    j2 = jitter_value(h & 0xffffu);
+                if (hashed) {  // key = base + (2 cell + draw) * 0x85EBCA6B, cell = v * u_steps + u
+                    j1 = jitter_value(mix32(key));
+                    j2 = jitter_value(mix32(key + 0x85EBCA6Bu));
+                    key += 2u * 0x85EBCA6Bu;
                 }
                 // corner + u_vec * (u + jitter1) + v_vec * (v + jitter2)
                 V3 lp = corner + uvec * ((float)u + j1) + vvec * ((float)v + j2);
@@ -1566,14 +1577,13 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
     uint32_t cell = cnt.sub();
     int u = (int)cell, v = 0;
     while (u >= H.u_steps) u -= H.u_steps, v++;
-    key += cell * 0x85EBCA6Bu;  // key = base + cell * 0x85EBCA6B, cell = v * u_steps + u
+    key += 2u * cell * 0x85EBCA6Bu;  // key = base + (2 cell + draw) * 0x85EBCA6B, cell = v * u_steps + u
     for (; cell < cells; cell += stride) {
         float j1 = H.jitter_const, j2 = H.jitter_const;
         if (hashed) {
-            uint32_t h = mix32(key);
-            key += stride * 0x85EBCA6Bu;
-            j1 = jitter_value(h >> 16);
-            j2 = jitter_value(h & 0xffffu);
+            j1 = jitter_value(mix32(key));
+            j2 = jitter_value(mix32(key + 0x85EBCA6Bu));
+            key += 2u * stride * 0x85EBCA6Bu;
         }
         // corner + u_vec * (u + jitter1) + v_vec * (v + jitter2)
         V3 lp = corner + uvec * ((float)u + j1) + vvec * ((float)v + j2);

@@ -65,13 +65,18 @@ class Renderer:
     def kernel_name(self):
         return L.lib().rtc_ctx_kernel_name(self._ctx).decode()
 
+    @property
+    def jit_status(self):
+        """"" when the scene's kernel is what the specialisation policy asked for, else the reason (rtc_ctx_jit_status)."""
+        return L.lib().rtc_ctx_jit_status(self._ctx).decode(errors="replace")
+
     def stats(self):
         """Synchronises with the last render and returns its counters."""
         st = L.rtc_stats()
         L.check(L.lib().rtc_ctx_stats(self._ctx, C.byref(st)))
         return {"rays": int(st.rays), "shaded_hits": int(st.shaded_hits), "pixels": int(st.pixels),
                 "kernel_ms": float(st.kernel_ms), "launches": int(st.launches), "rows": int(st.rows),
-                "culled_shadow_rays": int(st.culled_shadow_rays)}
+                "culled_shadow_rays": int(st.culled_shadow_rays), "flags": int(st.flags)}
 
     def to_ppm(self, rgb, stream=None):
         """Canvas::to_ppm (canvas.rs:58-96) formatted on the device from an (h, w, 3) f32 tensor -> bytes."""

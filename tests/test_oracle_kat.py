@@ -337,8 +337,12 @@ def test_phong_lighting(kat):  # light/phong_lighting.rs:78-194, 238-271
 def test_hashed_jitter_is_in_open_closed_unit_interval():
     vals = [O.jitter_value(O.jitter_hash(0x5EED5EED, p, 1, c, d)) for p in range(50) for c in range(20) for d in (0, 1)]
     assert min(vals) > 0.0 and max(vals) <= 1.0
-    assert O.jitter_value(0xFFFF) == f32(1.0)
-    assert O.jitter_value(0) == f32(2.0 ** -16)
+    assert O.jitter_value(0xFFFFFFFF) == f32(1.0) and O.jitter_value(0xFFFFFE00) == f32(1.0)
+    assert O.jitter_value(0) == f32(2.0 ** -23) and O.jitter_value(0x1FF) == f32(2.0 ** -23)
+    assert O.jitter_value(0x200) == f32(2.0 ** -22)
+    # the two draws of a cell are separate hashes: (cell, 1) is keyed like no other (cell', 0)
+    h = {(c, d): O.jitter_hash(0x5EED5EED, 7, 1, c, d) for c in range(100) for d in (0, 1)}
+    assert len(set(h.values())) == 200
     assert abs(float(np.mean(vals)) - 0.5) < 0.02
 
 
