@@ -11,11 +11,16 @@ strong scaling: the job is one image whatever N is.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  value = rays traced by all ranks / wall time.
-`roofline` is the contractual HBM figure of SURVEY.md 8(d) (algorithmic bytes =
-rays x n_objects x 64 B + 48 B per shaded hit + 12 B per pixel) over the render
-kernel's mean HIP-event duration; `cpu_baseline` is the CPU oracle timed on a
-bounded row sample of the same workload on this box's host cores.
+Prints ONE JSON line (rank 0).  value = rays traced by all ranks / wall time (the reference's count: every
+World::intersect evaluation, including the area-light shadow rays the light-cone cull answers without an object test;
+`tested_rays_per_s` is the rate of the rays that were tested).  `roofline` names the roof that binds this kernel --
+FP32 VALU issue: VALU wave-instructions x 64 lanes per launch (PMC-measured, taken from the profiles/*_pmc.json whose
+kernel id and workload match the kernel that just ran, else null) / the launch's mean HIP-event duration, against
+256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 Tlane-op/s; `traffic` = PMC HBM bytes per launch from the same summary.
+`contract_hbm_figure` is the contractual number of SURVEY.md 8(d) (algorithmic bytes = rays x n_objects x 64 B + 48 B
+per shaded hit + 12 B per pixel over 8 TB/s): the scene is register-resident, so it is NOT physical traffic and
+exceeds 1.  `one_shot` times the drop-in seam itself (rtc_render_ex: one call, host buffer out).  `cpu_baseline` is
+the CPU oracle timed on a bounded row sample of the same workload on this box's host cores.
 """
 import argparse
 import json
@@ -28,6 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # 78.6: one non-FMA f32 lane-op per SIMD lane per cycle at the 2.4 GHz peak clock
 
 
 def parse():
@@ -39,6 +45,7 @@ def parse():
     ap.add_argument("--scene", default="soft_shadows", help="scene function in ray_tracer_challenge_amd.scenes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU oracle sample (0 = skip)")
     ap.add_argument("--no-verify", action="store_true", help="skip the sampled-row parity check before timing")
+    ap.add_argument("--no-one-shot", action="store_true", help="skip timing the one-call seam (rtc_render_ex)")
     ap.add_argument("--extra-parts", type=int, default=-1, help="N>1: parts rendered by rank 0 on top of its own in an "
                     "(N+E)-way band split; -1 = from the measured gather/render ratio, 0 = even split")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
@@ -250,14 +257,7 @@ def main():
         # roofline of the dominant kernel (render_kernel) on THIS rank: per-launch algorithmic bytes / mean duration
         algo_bytes = st["rays"] * n_obj * 64 + st["shaded_hits"] * 48 + st["pixels"] * 12
         achieved = algo_bytes / (st["kernel_ms"] * 1e-3) / 1e9 if st["kernel_ms"] > 0 else 0.0
-        traffic, tmeta = None, None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and world_size == 1 and args.size == 4096 and args.scene == "soft_shadows":
-            try:
-                tmeta = json.load(open(tpath))
-                traffic = tmeta.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic, tmeta = None, None
+        pmc = matching_pmc_summary(renderer.kernel_id, args.scene, camera.width, camera.height) if world_size == 1 else None
         verify = None
         if not args.no_verify:
             verify = verify_rows(image, world, camera, depth)
@@ -269,6 +269,7 @@ def main():
             "config": {"workload": "C3: soft_shadows demo scene (10x10 area light, 4 objects, depth 5), %dx%d, hashed "
                                    "jitter seed 0x5EED5EED" % (args.size, args.size) if args.scene == "soft_shadows"
                        else "%s %dx%d" % (args.scene, args.size, args.size),
+                       "workload_key": workload_key(args.scene, camera.width, camera.height),
                        "rays_per_frame": rays, "shaded_hits_per_frame": shaded, "pixels_per_frame": pixels,
                        # of rays_per_frame: area-light shadow rays whose answer followed from the conservative
                        # light-cone cull (no object test needed); they are counted because the reference casts them
@@ -276,17 +277,13 @@ def main():
                        "partition": "64-row bands round-robin over %d part(s)%s" % (
                            world_size + extra_parts, (", rank 0 renders %d of them; RCCL gather of f32 rows to rank 0"
                                                       % (extra_parts + 1)) if world_size > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": renderer.kernel_name, "kernel_ms": round(st["kernel_ms"], 4),
-                         "algorithmic_bytes": algo_bytes,
-                         "note": "contractual figure (SURVEY.md 8d): rays x n_objects x 64 B + 48 B/shaded hit + "
-                                 "12 B/pixel; the scene is SGPR/cache resident so physical HBM traffic is ~ the "
-                                 "canvas store and frac may exceed 1; the physical limiter is FP32 VALU issue"},
-            # the physical limiter is FP32 VALU issue: VALU lane-ops/s from the PMC-measured instruction count of
-            # this kernel (profiles/hbm_traffic.json, written by profiles/summarize.py) against one non-FMA f32 op
-            # per lane per cycle = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 Tops/s
-            "valu": valu_view(tmeta, st["kernel_ms"]),
+            "tested_rays_per_s": round((rays - culled) / (elapsed / args.steps), 1),
+            "roofline": valu_roofline(pmc, st["kernel_ms"], renderer),
+            "contract_hbm_figure": {"algorithmic_bytes": algo_bytes, "achieved_GBps": round(achieved, 2), "peak_GBps": HBM_PEAK_GBS,
+                                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                    "note": "SURVEY.md 8(d) contractual figure: rays x n_objects x 64 B + 48 B/shaded hit + 12 B/pixel "
+                                            "over the kernel time. NOT physical traffic (the scene is SGPR-resident and most object "
+                                            "tests are culled), so it exceeds the HBM peak; the roof that binds is in `roofline`"},
             "parity_check": verify,
         }
         if world_size > 1:
@@ -299,6 +296,11 @@ def main():
                                  "render_kernel_ms_max_over_ranks": round(float(kern.item()), 4),
                                  "gathered_bytes_per_step": int(camera.height * camera.width * 12 * (world_size - 1) // n_parts),
                                  "wire_format_gather": wire}
+        if world_size == 1 and not args.no_one_shot:
+            try:
+                line["one_shot"] = one_shot(world, camera, depth)
+            except Exception as exc:  # noqa: BLE001 -- informational: never costs the headline line
+                line["one_shot"] = {"error": repr(exc)[:300]}
         if args.cpu_seconds > 0 and world_size == 1:
             line["cpu_baseline"] = cpu_baseline(world, camera, depth, args.cpu_seconds)
         elif world_size > 1:
@@ -309,13 +311,82 @@ def main():
         dist.destroy_process_group()
 
 
-def valu_view(tmeta, kernel_ms):
-    if not tmeta or "valu_wave_insts_per_launch" not in tmeta or kernel_ms <= 0:
-        return None
-    lane_ops = tmeta["valu_wave_insts_per_launch"] * 64.0
+def workload_key(scene, width, height):
+    return "%s:%dx%d" % (scene, width, height)
+
+
+def matching_pmc_summary(kernel_id, scene, width, height):
+    """The committed rocprofv3 counter summary (profiles/*_pmc.json, written by profiles/summarize.py) that was
+    measured on THIS kernel (same code id) and THIS workload -- or None: counts are never quoted for another kernel."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            m = json.load(open(path))
+        except Exception:
+            continue
+        if m.get("kernel_id") == kernel_id and m.get("workload_key") == workload_key(scene, width, height):
+            best = (path, m)
+    return best
+
+
+def valu_roofline(pmc, kernel_ms, renderer):
+    out = {"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_TOPS, 1), "unit": "Tlane-op/s", "frac": None, "traffic": None,
+           "kernel": renderer.kernel_name, "kernel_id": renderer.kernel_id, "kernel_ms": round(kernel_ms, 4), "pmc_source": None}
+    if pmc is None or kernel_ms <= 0:
+        out["note"] = ("no profiles/*_pmc.json matches this kernel id and workload: instruction count and HBM traffic are not "
+                       "quoted from another kernel's profile (run profiles/run_profile.sh + summarize.py)")
+        return out
+    path, m = pmc
+    c = m["counters_mean_per_launch"]
+    lane_ops = c["SQ_INSTS_VALU"] * 64.0
     tops = lane_ops / (kernel_ms * 1e-3) / 1e12
-    return {"lane_ops_per_launch": lane_ops, "achieved_tops": round(tops, 2), "peak_tops": 78.6,
-            "frac": round(tops / 78.6, 3), "source": tmeta.get("source")}
+    out.update({"achieved": round(tops, 2), "frac": round(tops / VALU_PEAK_TOPS, 4), "traffic": m.get("hbm_bytes_per_launch"),
+                "valu_wave_insts_per_launch": c["SQ_INSTS_VALU"], "pmc_source": os.path.relpath(path, ROOT),
+                "profiled_kernel_ms": round(m.get("kernel_trace", {}).get("avg_ns", 0.0) / 1e6, 4),
+                "note": "FP32 VALU issue: PMC SQ_INSTS_VALU x 64 lanes per launch / this run's mean HIP-event kernel time, against "
+                        "256 CU x 4 SIMD x 32 lanes x 2.4 GHz; traffic = (2 FETCH_SIZE + WRITE_SIZE) x 1024 B per launch (separate "
+                        "--pmc passes), to be read against the %.0f MB f32 canvas store" % (renderer.width * renderer.height * 12 / 1e6)})
+    return out
+
+
+def one_shot(world, camera, depth):
+    """The drop-in seam as a caller meets it (camera.rs:76): ONE rtc_render_ex call, host buffer out -- scene check,
+    kernel launches, transfer.  Median wall ms of 5 calls after a warm-up call (which pays context, compile, allocation)."""
+    import numpy as np
+    import ray_tracer_challenge_amd as P
+    from ray_tracer_challenge_amd import _lib as L
+    import ctypes as C
+    res = {}
+    h, w = camera.height, camera.width
+
+    def timed(fn):
+        fn()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return round(sorted(ts)[2], 3)
+    buf = np.zeros((h, w, 3), dtype=np.float32)
+    res["f32_pageable_ms"] = timed(lambda: camera.render(world, depth, out=buf))
+    res["kernel_ms_in_call"] = round(camera.last_stats["kernel_ms"], 4)
+    buf8 = np.zeros((h, w, 3), dtype=np.uint8)
+    res["u8_pageable_ms"] = timed(lambda: camera.render(world, depth, quantize=True, out=buf8))
+    lib, cs = P.lib(), world._c()
+    p = lib.rtc_host_alloc(h * w * 12)
+    if p:
+        st = L.rtc_stats()
+        dev = (C.c_int32 * 1)(0)
+        for name, q in (("f32_pinned_ms", 0), ("u8_pinned_ms", 1)):
+            opts = L.rtc_opts(dev, 1, 0, q, 0)
+            res[name] = timed(lambda: L.check(lib.rtc_render_ex(C.byref(cs.scene), C.byref(camera._cam), depth, C.byref(opts),
+                                                                C.c_void_p(p), C.byref(st))))
+        lib.rtc_host_free(p)
+    res["note"] = ("rtc_render_ex, %dx%d, whole call; pageable: DMA into pinned staging + threaded copy into the caller's buffer; "
+                   "pinned: DMA straight into an rtc_host_alloc buffer" % (w, h))
+    lib.rtc_render_release()
+    return res
 
 
 def verify_rows(image, world, camera, depth):

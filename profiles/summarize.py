@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Turns a gpurun_out/prof_<tag>/ directory (profiles/run_profile.sh) into the committed summaries:
-   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 5`
-   profiles/<tag>_pmc.json           per-launch PMC means for render_kernel + derived figures
-   profiles/hbm_traffic.json         HBM bytes per launch (read by bench.py for roofline.traffic)
+   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 5 [...]`
+   profiles/<tag>_pmc.json           per-launch PMC means for render_kernel + derived figures, stamped with the
+                                     kernel id (rtc_ctx_kernel_id) and workload key bench.py printed in that very run:
+                                     bench.py quotes instruction counts / HBM traffic only from a summary whose stamp
+                                     matches the kernel it has just timed.
 HBM bytes follow MI355X_MICROARCH.md: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE under-reports
 wide reads by 2x on gfx950; WRITE_SIZE is taken as is (our stores are 4-byte, uncalibrated: see README)."""
 import collections
@@ -42,12 +44,25 @@ if "GRBM_GUI_ACTIVE" in m and "SQ_INSTS_VALU" in m:
                              if k in m},
     }
 if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
-    hbm = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
-    out["hbm_bytes_per_launch"] = hbm
-    json.dump({"workload": "C3 soft_shadows 4096x4096", "hbm_bytes_per_launch": hbm,
-               "fetch_size_kb": m["FETCH_SIZE"], "write_size_kb": m["WRITE_SIZE"], "source": "profiles/%s_pmc.json" % tag,
-               "valu_wave_insts_per_launch": m.get("SQ_INSTS_VALU"), "kernel": meta.get("kernel"),
-               "method": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes"},
-              open(os.path.join(here, "hbm_traffic.json"), "w"), indent=1)
+    out["hbm_bytes_per_launch"] = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
+    out["hbm_method"] = "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes"
+# the stamp: what bench.py said it ran, in the traced run and in every counter run (they must agree)
+stamps = set()
+for log in [os.path.join(src, "trace.log")] + glob.glob(os.path.join(src, "pmc_*.log")):
+    for line in open(log, errors="replace"):
+        if line.startswith("{") and '"roofline"' in line:
+            b = json.loads(line)
+            stamps.add((b["roofline"]["kernel_id"], b["config"]["workload_key"], b["roofline"]["kernel"]))
+            if log.endswith("trace.log"):
+                out["bench_line_of_the_traced_run"] = {k: b[k] for k in ("value", "unit", "ms_per_step", "mpixels_per_s") if k in b}
+                out["rays_per_frame"] = b["config"]["rays_per_frame"]
+                out["shadow_rays_resolved_by_light_cone_cull"] = b["config"]["shadow_rays_resolved_by_light_cone_cull"]
+assert len(stamps) == 1, "the profiled runs disagree about the kernel: %r" % (stamps,)
+out["kernel_id"], out["workload_key"], out["kernel_name"] = stamps.pop()
+if "derived" in out and out.get("rays_per_frame"):
+    tested = out["rays_per_frame"] - out["shadow_rays_resolved_by_light_cone_cull"]
+    out["derived"]["valu_lane_ops_per_ray"] = m["SQ_INSTS_VALU"] * 64.0 / out["rays_per_frame"]
+    out["derived"]["valu_lane_ops_per_tested_ray"] = m["SQ_INSTS_VALU"] * 64.0 / max(tested, 1)
+    out["derived"]["valu_issue_frac_of_78_6_Tlaneops"] = m["SQ_INSTS_VALU"] * 64.0 / (out["kernel_trace"]["avg_ns"] * 1e-9) / 78.6432e12
 json.dump(out, open(os.path.join(here, "%s_pmc.json" % tag), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -146,6 +146,7 @@ SIGNATURES = {
     "rtc_ctx_stats": (C.c_int, [C.c_void_p, C.POINTER(rtc_stats)]),
     "rtc_ctx_kernel_name": (C.c_char_p, [C.c_void_p]),
     "rtc_ctx_jit_status": (C.c_char_p, [C.c_void_p]),
+    "rtc_ctx_kernel_id": (C.c_char_p, [C.c_void_p]),
     "rtc_ctx_quantize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rtc_ppm_max_bytes": (C.c_uint64, [C.c_uint32, C.c_uint32]),
     "rtc_ctx_to_ppm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,

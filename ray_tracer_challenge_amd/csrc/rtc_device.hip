@@ -813,6 +813,7 @@ struct rtc_ctx {
     bool spec_shares = false;         // spec_fn was compiled with -DRTC_SPEC_SHARE=1
     hipFunction_t spec_fn = nullptr;  // scene-specialised kernel (hiprtc), or null: ahead-of-time kernels
     std::string kernel_name;          // what rtc_ctx_render launches, for rtc_ctx_kernel_name()
+    std::string kernel_id;            // rtc_ctx_kernel_id(): names the code object (source + options + compiler), not the scene
     std::string jit_note;             // why spec_fn is null although the policy wanted one (rtc_ctx_jit_status)
     // the scene as last uploaded: an identical one (rtc_render_ex called again for the next frame) is not uploaded twice
     std::vector<float4> soa_host;
@@ -844,9 +845,14 @@ struct rtc_ctx {
 // ============================================================================
 namespace {
 
+struct CacheHeader {
+    char magic[8];
+    uint64_t size, checksum;
+};
 struct JitModule {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
+    std::string id;  // "spec_<hash of source, options, compiler version>": names the code that runs (rtc_ctx_kernel_id)
 };
 std::mutex g_jit_mutex;
 std::map<std::string, JitModule> g_jit_cache;  // key: "<device>|<defines>"
@@ -899,13 +905,14 @@ std::string jit_cache_dir() {  // RTC_AMD_JIT_CACHE=<dir>, or 0 / off to keep co
 }
 
 // Compiles (or fetches) the specialised kernel for `defines` on the current device.
-rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunction_t* out) {
+rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunction_t* out, std::string* id) {
     std::string key = std::to_string(device) + "|";
     for (const auto& d : defines) key += d + " ";
     std::lock_guard<std::mutex> lock(g_jit_mutex);
     auto it = g_jit_cache.find(key);
     if (it != g_jit_cache.end()) {
         *out = it->second.fn;
+        *id = it->second.id;
         return RTC_OK;
     }
     std::string core_file;
@@ -967,6 +974,8 @@ rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunct
             {
                 std::ofstream f(tmp, std::ios::binary);
                 if (f) {
+                    const CacheHeader h = {{'R', 'T', 'C', 'J', 'I', 'T', '1', 0}, (uint64_t)code->size(), fnv1a(*code)};
+                    f.write((const char*)&h, sizeof(h));
                     f.write(code->data(), (std::streamsize)code->size());
                     f.close();
                     ok = f.good();
@@ -976,8 +985,16 @@ rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunct
         }
         return RTC_OK;
     };
+    // a cache entry is its header {magic, size, checksum} + the code object: a truncated or foreign file is ignored (the
+    // HIP runtime does not survive a damaged code object), and overwritten by the fresh compile
     std::string code;
-    const bool cached = !cache_dir.empty() && read_file(cache_path, &code) && !code.empty();
+    bool cached = false;
+    if (!cache_dir.empty() && read_file(cache_path, &code) && code.size() > sizeof(CacheHeader)) {
+        CacheHeader h;
+        std::memcpy(&h, code.data(), sizeof(h));
+        code.erase(0, sizeof(h));
+        cached = std::memcmp(h.magic, "RTCJIT1", 8) == 0 && h.size == code.size() && h.checksum == fnv1a(code);
+    }
     if (!cached) {
         rtc_status st = compile(&code);
         if (st != RTC_OK) return st;
@@ -995,9 +1012,18 @@ rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunct
         if (le == hipSuccess) le = hipModuleGetFunction(&m.fn, m.mod, "render_kernel_spec");
     }
     if (le != hipSuccess) return fail(RTC_ERR_DEVICE, "scene specialisation: the compiled kernel does not load: %s", hipGetErrorString(le));
+    m.id = std::string(name, std::strlen(name) - 6);  // without ".hsaco"
     g_jit_cache[key] = m;
     *out = m.fn;
+    *id = m.id;
     return RTC_OK;
+}
+
+// identifies the ahead-of-time kernels of this build: the source they were compiled from
+std::string aot_kernel_id() {
+    char b[40];
+    snprintf(b, sizeof(b), "aot_%016llx", (unsigned long long)fnv1a(k_core_src));
+    return b;
 }
 
 }  // namespace
@@ -1070,6 +1096,7 @@ void rtc_ctx_destroy(rtc_ctx* c) {
 static rtc_status jit_failed(rtc_ctx* c, int policy, rtc_status jst) {
     c->spec_fn = nullptr;
     c->spec_shares = false;
+    c->kernel_id = aot_kernel_id();
     c->jit_note = rtc_last_error();
     if (policy == 1) {
         c->has_scene = false;
@@ -1145,6 +1172,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     char nm[96];
     snprintf(nm, sizeof(nm), "render_kernel<%d,%s>", n <= 4 ? 4 : n <= 8 ? 8 : 0, (n <= 8 && c->simple) ? "simple" : "general");
     c->kernel_name = nm;
+    c->kernel_id = aot_kernel_id();
     if (hdr.n_trav) {  // a traversal stream (GroupShapes, or the library's own hierarchy): packet walk, compiled per scene like the flat kernels
         const std::string how = scene->n_groups ? "tree" : "tree,bvh";
         c->kernel_name = "render_kernel<" + how + ">";
@@ -1170,7 +1198,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
                                              "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
                                              std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
             defs.push_back(share_def);
-            rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
+            rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
             if (jst != RTC_OK) {
                 if ((jst = jit_failed(c, policy, jst)) != RTC_OK) return jst;
             } else {
@@ -1200,7 +1228,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         defs.push_back(std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0"));
         defs.push_back(std::string("-DRTC_SPEC_GATES=") + (hdr.n_gates ? "1" : "0"));
         defs.push_back(share_def);
-        rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
+        rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
         if (jst != RTC_OK) {
             if ((jst = jit_failed(c, policy, jst)) != RTC_OK) return jst;
         } else {
@@ -1227,7 +1255,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
                                              "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
                                              std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
             defs.push_back(share_def);
-            rtc_status jst = jit_get(c->device, defs, &c->spec_fn);
+            rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
             if (jst != RTC_OK) {
                 if ((jst = jit_failed(c, policy, jst)) != RTC_OK) return jst;
             } else {
@@ -1277,8 +1305,9 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     }
     c->last_rows = rows;
     c->last_pixels = traced_rows * (uint64_t)(c->hdr.width - 1);
-    if (rows == 0) {
-        c->rendered = false;
+    if (rows == 0) {  // nothing to launch: the slot's counters read zero
+        HIP_TRY(hipMemsetAsync(c->d_total + 3 * (size_t)slot, 0, 3 * sizeof(unsigned long long), stream));
+        if (slot == 0) c->rendered = false;
         return RTC_OK;
     }
     RenderArgs a;
@@ -1384,6 +1413,7 @@ rtc_status rtc_ctx_stats(rtc_ctx* c, rtc_stats* out) {
 
 const char* rtc_ctx_kernel_name(rtc_ctx* c) { return c ? c->kernel_name.c_str() : ""; }
 const char* rtc_ctx_jit_status(rtc_ctx* c) { return c ? c->jit_note.c_str() : ""; }
+const char* rtc_ctx_kernel_id(rtc_ctx* c) { return c ? c->kernel_id.c_str() : ""; }
 
 rtc_status rtc_ctx_quantize(rtc_ctx* c, const void* d_rgb, uint64_t n, void* d_out_u8, void* stream_) {
     if (!c || !d_rgb || !d_out_u8) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_quantize: null argument");

@@ -66,6 +66,11 @@ class Renderer:
         return L.lib().rtc_ctx_kernel_name(self._ctx).decode()
 
     @property
+    def kernel_id(self):
+        """Names the code object that renders the current scene (rtc_ctx_kernel_id)."""
+        return L.lib().rtc_ctx_kernel_id(self._ctx).decode()
+
+    @property
     def jit_status(self):
         """"" when the scene's kernel is what the specialisation policy asked for, else the reason (rtc_ctx_jit_status)."""
         return L.lib().rtc_ctx_jit_status(self._ctx).decode(errors="replace")

@@ -207,6 +207,14 @@ def test_library_alone_compiles_its_scene_kernels(tmp_path):
         path.write_bytes(data[: len(data) // 3])
     info2, img2, _, _ = _run_alone(tmp_path, {})
     assert info2["kernel"] == info["kernel"] and info2["flags"] == 0 and np.array_equal(img2, img)
+    for f in os.listdir(lib_dir / "jit_cache"):  # ... and so is one whose bytes were damaged in place
+        path = lib_dir / "jit_cache" / f
+        data = bytearray(path.read_bytes())
+        assert len(data) > 10000  # the truncated entry was replaced by a complete one
+        data[len(data) // 2] ^= 0xFF
+        path.write_bytes(bytes(data))
+    info2, img2, _, _ = _run_alone(tmp_path, {})
+    assert info2["kernel"] == info["kernel"] and info2["flags"] == 0 and np.array_equal(img2, img)
     # the cache directory can be moved or switched off
     other = tmp_path / "elsewhere"
     info3, img3, _, _ = _run_alone(tmp_path, {"RTC_AMD_JIT_CACHE": str(other)})
@@ -215,7 +223,7 @@ def test_library_alone_compiles_its_scene_kernels(tmp_path):
 
 @gpu
 def test_failed_scene_compile_is_reported_not_hidden(tmp_path):
-    bad = {"RTC_AMD_JIT_FLAGS": "-Duint32_t=this_does_not_compile", "RTC_AMD_JIT_CACHE": "0"}
+    bad = {"RTC_AMD_JIT_FLAGS": "-Dnamespace=:", "RTC_AMD_JIT_CACHE": "0"}   # `: rtc {` does not compile
     info, img, stderr, _ = _run_alone(tmp_path, bad)
     assert info["kernel"].startswith("render_kernel<"), info            # the ahead-of-time kernel ...
     assert info["flags"] & L.RTC_STATS_JIT_FALLBACK and "failed to compile" in info["jit_status"]   # ... and it says so

@@ -3,7 +3,7 @@
 OUT=gpurun_out/${1:-pmc}; shift
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-verify $@"
+BENCH="python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-verify --no-one-shot $@"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/a -- $BENCH > $OUT/a.log 2>&1
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SMEM SQ_WAIT_INST_LDS --output-format csv -d $OUT/b -- $BENCH > $OUT/b.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/c -- $BENCH > $OUT/c.log 2>&1

@@ -2,7 +2,7 @@
 # quick HBM-side traffic probe of bench.py's render kernel: bash tools/traffic.sh <outdir>
 OUT=gpurun_out/${1:-traffic}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-verify"
+BENCH="python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-verify --no-one-shot"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/f -- $BENCH > $OUT/f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w -- $BENCH > $OUT/w.log 2>&1
 python3 - <<PY
