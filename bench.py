@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=4096, help="image edge in pixels (metric config: 4096)")
+    ap.add_argument("--height", type=int, default=0, help="image height if not square (profiling other scenes: 1000x400 demos)")
     ap.add_argument("--scene", default="soft_shadows", help="scene function in ray_tracer_challenge_amd.scenes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU oracle sample (0 = skip)")
     ap.add_argument("--no-verify", action="store_true", help="skip the sampled-row parity check before timing")
@@ -118,7 +119,7 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    world, camera, depth = getattr(scenes, args.scene)(args.size, args.size)
+    world, camera, depth = getattr(scenes, args.scene)(args.size, args.height or args.size)
     renderers = {}  # one context per part this rank renders: each keeps the counters and event timings of its own launches
 
     def renderer_for(p):
@@ -268,7 +269,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C3: soft_shadows demo scene (10x10 area light, 4 objects, depth 5), %dx%d, hashed "
                                    "jitter seed 0x5EED5EED" % (args.size, args.size) if args.scene == "soft_shadows"
-                       else "%s %dx%d" % (args.scene, args.size, args.size),
+                       else "%s %dx%d" % (args.scene, camera.width, camera.height),
                        "workload_key": workload_key(args.scene, camera.width, camera.height),
                        "rays_per_frame": rays, "shaded_hits_per_frame": shaded, "pixels_per_frame": pixels,
                        # of rays_per_frame: area-light shadow rays whose answer followed from the conservative
