@@ -1168,6 +1168,24 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     // sample-parallel rendering (render_body): compiled in when this frame is small enough to want it
     c->spec_shares = choose_share_log2(hdr, hdr.height) != 0u;
     const std::string share_def = std::string("-DRTC_SPEC_SHARE=") + (c->spec_shares ? "1" : "0");
+    // Recursion facts (rtc_kernel_core.h FrameStack): does any material reflect / transmit at all, and how many levels of
+    // the recursion stack the kernel keeps in registers.  Register levels pay where a shade point is cheap (a point
+    // light: frames are then the kernel's memory traffic) and cost occupancy where it is not (an area light's sample
+    // loop): default 5 (the reference's depth, constants.rs:4) for point lights, 0 otherwise; RTC_AMD_REG_LEVELS overrides.
+    bool any_refl = false, any_refr = false;
+    for (uint32_t i = 0; i < hdr.n_objects; i++) {
+        any_refl = any_refl || !(scene->objects[i].material.reflective == 0.0f);
+        any_refr = any_refr || !(scene->objects[i].material.transparency == 0.0f);
+    }
+    int reg_levels = (hdr.light_kind == RTC_LIGHT_POINT && (any_refl || any_refr)) ? 5 : 0;
+    if (const char* e = std::getenv("RTC_AMD_REG_LEVELS"))
+        if (e[0] >= '0' && e[0] <= '8' && !e[1]) reg_levels = e[0] - '0';
+    if (!any_refl && !any_refr) reg_levels = 0;
+    std::vector<std::string> recursion_defs = {std::string("-DRTC_SPEC_ANY_REFL=") + (any_refl ? "1" : "0"),
+                                               std::string("-DRTC_SPEC_ANY_REFR=") + (any_refr ? "1" : "0"),
+                                               "-DRTC_SPEC_REG_LEVELS=" + std::to_string(reg_levels)};
+    // register levels need the registers: 13 dwords per level on top of the ~70 the kernel works in
+    const char* reg_waves = reg_levels == 0 ? nullptr : reg_levels <= 3 ? "-DRTC_WAVES_PER_SIMD=4" : "-DRTC_WAVES_PER_SIMD=3";
     const uint32_t n = hdr.n_objects;
     char nm[96];
     snprintf(nm, sizeof(nm), "render_kernel<%d,%s>", n <= 4 ? 4 : n <= 8 ? 8 : 0, (n <= 8 && c->simple) ? "simple" : "general");
@@ -1192,12 +1210,14 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
             snprintf(b, sizeof(b), "0x%x", first);
             std::vector<std::string> defs = {std::string("-DRTC_SPEC_LIST=") + b,
                                              uniform ? std::string("-DRTC_SPEC_UNIFORM_BITS=") + b : std::string("-DRTC_SPEC_RUNTIME_BITS=1"),
-                                             "-DRTC_SPEC_NOBJ=-1", "-DRTC_SPEC_SIMPLE=0", "-DRTC_WAVES_PER_SIMD=" + tree_jit_waves(),
+                                             "-DRTC_SPEC_NOBJ=-1", "-DRTC_SPEC_SIMPLE=0",
+                                             reg_waves ? std::string(reg_waves) : "-DRTC_WAVES_PER_SIMD=" + tree_jit_waves(),
                                              std::string("-DRTC_SPEC_TBOX=") + (hdr.has_tbox ? "1" : "0"),
                                              "-DRTC_SPEC_LIGHT_KIND=" + std::to_string(hdr.light_kind),
                                              "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
                                              std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
             defs.push_back(share_def);
+            defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
             rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
             if (jst != RTC_OK) {
                 if ((jst = jit_failed(c, policy, jst)) != RTC_OK) return jst;
@@ -1228,6 +1248,8 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         defs.push_back(std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0"));
         defs.push_back(std::string("-DRTC_SPEC_GATES=") + (hdr.n_gates ? "1" : "0"));
         defs.push_back(share_def);
+        defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
+        if (reg_waves) defs.push_back(reg_waves);
         rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
         if (jst != RTC_OK) {
             if ((jst = jit_failed(c, policy, jst)) != RTC_OK) return jst;
@@ -1255,6 +1277,8 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
                                              "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
                                              std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
             defs.push_back(share_def);
+            if (reg_waves) defs.push_back(reg_waves);
+            defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
             rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
             if (jst != RTC_OK) {
                 if ((jst = jit_failed(c, policy, jst)) != RTC_OK) return jst;

@@ -1844,7 +1844,7 @@ struct LaneStash {
 
 // One suspended shade_hit (world.rs:62-86) waiting for a child colour.
 // Split in two so that the common frame -- a mirror-like hit waiting for its reflection only -- moves 6 dwords
-// through scratch instead of 13: the refraction half is written and read only when there is a refraction child.
+// instead of 13: the refraction half is written and read only when there is a refraction child.
 struct Frame {
     V3 acc;       // surface colour, later surface + reflected[*R]
     float reflective, R;
@@ -1856,6 +1856,84 @@ struct FrameRefr {
 };
 enum { F_WAIT_REFR = 1, F_HAS_REFR = 2, F_SCHLICK = 4 };
 
+// Scene facts a scene-compiled kernel knows (hiprtc, -DRTC_SPEC_ANY_REFL / _ANY_REFR / _REG_LEVELS): whether any material
+// reflects / transmits at all -- a scene without either has no recursion and carries no frame code, a mirror-only scene
+// no refraction half -- and how many levels of the recursion stack live in REGISTERS.
+#if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_ANY_REFL)
+constexpr bool ANY_REFL = RTC_SPEC_ANY_REFL != 0, ANY_REFR = RTC_SPEC_ANY_REFR != 0;
+#else
+constexpr bool ANY_REFL = true, ANY_REFR = true;
+#endif
+#if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_REG_LEVELS)
+constexpr int STACK_REG_LEVELS = RTC_SPEC_REG_LEVELS;
+#else
+constexpr int STACK_REG_LEVELS = 0;
+#endif
+static_assert(STACK_REG_LEVELS >= 0 && STACK_REG_LEVELS <= RTC_MAX_DEPTH, "RTC_SPEC_REG_LEVELS");
+
+// The post-order stack of color_at: one Frame (+ FrameRefr) per suspended shade_hit, at most `depth` of them.
+// A per-lane array indexed by a per-lane stack pointer lives in scratch memory: every push and pop is a round trip
+// through the vector memory path, and with a quarter of a million waves each owning 28 KB of it the lines do not stay
+// in L2 -- on the glass-and-mirror scene (BASELINE C4) that was 2.5 GB of L2<->fabric traffic per 0.2 GB frame with 63 %
+// of the wave-cycles spent waiting.  So the first STACK_REG_LEVELS levels are kept in registers instead: level u is
+// the struct `reg[u]`, only ever indexed with constants, and a push / pop visits the levels some lane of the wave is
+// at (wave-uniform test per level, then a per-lane select) -- typically one or two.  Deeper levels (depth > levels, or
+// a kernel compiled without register levels) use the scratch arrays as before.  Which of the two holds a frame
+// changes nothing about the values stored: the image cannot differ (tests/test_gpu_parity.py, every level count).
+// (Two objects, because the compiler only turns a local aggregate into registers when EVERY access to it has a
+// constant offset: the dynamically indexed scratch levels must not share an allocation with the register levels.)
+struct FrameRegs {
+    static constexpr int R = STACK_REG_LEVELS;
+    Frame f[R > 0 ? R : 1];
+    FrameRefr r[R > 0 ? R : 1];
+};
+struct FrameMem {
+    static constexpr int M = RTC_MAX_DEPTH - STACK_REG_LEVELS;
+    Frame f[M > 0 ? M : 1];
+    FrameRefr r[M > 0 ? M : 1];
+};
+struct FrameStack {
+    static constexpr int R = FrameRegs::R, M = FrameMem::M;
+    FrameRegs& reg;
+    FrameMem& mem;
+    DI void put(int sp, const Frame& f) const {
+#pragma unroll
+        for (int u = 0; u < R; u++)
+            if (__any(sp == u)) {  // wave-uniform: some lane is at this level
+                if (sp == u) reg.f[u] = f;
+            }
+        if (M > 0 && sp >= R) mem.f[sp - R] = f;
+    }
+    DI void put_refr(int sp, const FrameRefr& f) const {
+#pragma unroll
+        for (int u = 0; u < R; u++)
+            if (__any(sp == u)) {
+                if (sp == u) reg.r[u] = f;
+            }
+        if (M > 0 && sp >= R) mem.r[sp - R] = f;
+    }
+    DI Frame get(int sp) const {
+        Frame f = {v3(0.0f, 0.0f, 0.0f), 0.0f, 0.0f, 0u};
+#pragma unroll
+        for (int u = 0; u < R; u++)
+            if (__any(sp == u)) {
+                if (sp == u) f = reg.f[u];
+            }
+        if (M > 0 && sp >= R) f = mem.f[sp - R];
+        return f;
+    }
+    DI FrameRefr get_refr(int sp) const {
+        FrameRefr f = {v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 0.0f), 0.0f};
+#pragma unroll
+        for (int u = 0; u < R; u++)
+            if (__any(sp == u)) {
+                if (sp == u) f = reg.r[u];
+            }
+        if (M > 0 && sp >= R) f = mem.r[sp - R];
+        return f;
+    }
+};
+
 // World::color_at (world.rs:88-101) with reflected_color / refracted_color
 // recursion (world.rs:121-162) unrolled into an explicit post-order stack.
 // `path` is the jitter path code: 1 at the root, 2p for the reflection child
@@ -1863,8 +1941,9 @@ enum { F_WAIT_REFR = 1, F_HAS_REFR = 2, F_SCHLICK = 4 };
 template <int NOBJ, bool SIMPLE>
 DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint32_t pixel, Counters& cnt,
                const LaneStash stash) {
-    Frame stack[RTC_MAX_DEPTH];
-    FrameRefr stack_refr[RTC_MAX_DEPTH];
+    FrameRegs stack_regs;
+    FrameMem stack_mem;
+    const FrameStack stack = {stack_regs, stack_mem};
     int sp = 0;
     int rem = depth;
     uint32_t path = 1;
@@ -1937,12 +2016,12 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
             }
             V3 surface = phong(H, material_color, ma, mb, over_point, eye, n, li);
 
-            bool has_refl = !(reflective == 0.0f || rem < 1);  // world.rs:126
+            bool has_refl = ANY_REFL && !(reflective == 0.0f || rem < 1);  // world.rs:126
             bool has_refr = false;
-            bool use_schlick = reflective > 0.0f && transparency > 0.0f;  // world.rs:80
+            bool use_schlick = ANY_REFL && ANY_REFR && reflective > 0.0f && transparency > 0.0f;  // world.rs:80
             float R = 0.0f;
             V3 rdir = v3(0.0f, 0.0f, 0.0f);
-            if (transparency != 0.0f) {
+            if (ANY_REFR && transparency != 0.0f) {
                 float n1, n2;
                 refraction_indices<NOBJ>(H, S, o, d, ob, n1, n2);
                 if (use_schlick) R = schlick(eye, n, n1, n2);
@@ -1970,7 +2049,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                     fr.ro = under_point;
                     fr.rd = rdir;
                     fr.transparency = transparency;
-                    stack_refr[sp] = fr;
+                    stack.put_refr(sp, fr);
                 }
                 if (has_refl) {
                     f.acc = surface;
@@ -1985,7 +2064,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                     d = rdir;
                     path = path * 2u + 1u;
                 }
-                stack[sp++] = f;
+                stack.put(sp++, f);
                 rem--;
                 descend = true;
             }
@@ -1994,17 +2073,19 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
         // ---------------- return `ret` to the suspended callers
         for (;;) {
             if (sp == 0) return ret;
-            Frame& f = stack[sp - 1];
+            Frame f = stack.get(sp - 1);
             rem++;
             path >>= 1;
             if (!(f.flags & F_WAIT_REFR)) {
                 V3 reflected = ret * f.reflective;  // world.rs:131
                 V3 partial = (f.flags & F_SCHLICK) ? f.acc + reflected * f.R : f.acc + reflected;
-                if (f.flags & F_HAS_REFR) {
+                if (ANY_REFR && (f.flags & F_HAS_REFR)) {
                     f.acc = partial;
                     f.flags |= F_WAIT_REFR;
-                    o = stack_refr[sp - 1].ro;
-                    d = stack_refr[sp - 1].rd;
+                    stack.put(sp - 1, f);
+                    const FrameRefr fr = stack.get_refr(sp - 1);
+                    o = fr.ro;
+                    d = fr.rd;
                     rem--;
                     path = path * 2u + 1u;
                     break;
@@ -2013,7 +2094,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                 ret = (f.flags & F_SCHLICK) ? partial + black * (1.0f - f.R) : partial + black;
                 sp--;
             } else {
-                V3 refracted = ret * stack_refr[sp - 1].transparency;  // world.rs:159-160
+                V3 refracted = ret * stack.get_refr(sp - 1).transparency;  // world.rs:159-160
                 ret = (f.flags & F_SCHLICK) ? f.acc + refracted * (1.0f - f.R) : f.acc + refracted;
                 sp--;
             }
