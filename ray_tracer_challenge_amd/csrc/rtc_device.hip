@@ -246,13 +246,18 @@ static std::string tree_jit_waves() {
     return (e && *e >= '1' && *e <= '8' && !e[1]) ? std::string(e) : std::string("6");
 }
 
-// Lanes per pixel (RenderArgs::share_log2): only an area light has work to share; more lanes per pixel while the frame
-// would otherwise be fewer than ~4 waves per SIMD.  RTC_AMD_SHARE_LOG2=0..3 overrides.
+// Lanes per pixel (RenderArgs::share_log2).  Two kinds of work can be shared between the lanes of a pixel: an area light's
+// cells (intensity_at), while the frame would otherwise be fewer than ~4 waves per SIMD; and, in a tree walk, the long
+// runs of leaves a divided mesh leaves at every level (for_each_leaf_shared) -- there a frame's time is that of its
+// slowest wave, whatever the frame's size.  RTC_AMD_SHARE_LOG2=0..3 overrides.
 static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows) {
-    if (hdr.light_kind != RTC_LIGHT_RECT || hdr.u_steps * hdr.v_steps < 8) return 0u;
+    const bool area = hdr.light_kind == RTC_LIGHT_RECT && hdr.u_steps * hdr.v_steps >= 8;
+    const bool runs = hdr.n_trav != 0u && hdr.max_leaf_run >= 16u && !area;
+    if (!area && !runs) return 0u;
     if (const char* e = std::getenv("RTC_AMD_SHARE_LOG2"))
         if (e[0] >= '0' && e[0] <= '3' && !e[1]) return (uint32_t)(e[0] - '0');
     const uint64_t waves = ((uint64_t)hdr.width * rows + 63) / 64;
+    if (runs) return 3u;
     uint32_t s = 0;
     while (s < 3u && (waves << s) < 24576u) s++;
     return s;
@@ -347,6 +352,23 @@ static bool build_flat_bvh(const rtc_scene* scene, const float cam_origin[4], st
     };
     Rec::go(order, 0, n, box, trav, +as_f);
     return true;
+}
+
+// Every leaf entry learns how many consecutive leaf entries start with it (kernel: trav_run / trav_more share e2.w, which
+// holds `more` -- 0..3 -- on entry); returns the longest run.
+static uint32_t mark_leaf_runs(std::vector<float4>* trav) {
+    uint32_t longest = 0, run = 0;
+    for (size_t e = trav->size() / TRAV_STRIDE; e-- > 0;) {
+        if (!((*trav)[TRAV_STRIDE * e + 1].w < 0.0f)) {  // a group
+            run = 0;
+            continue;
+        }
+        run = std::min(run + 1u, 1u << 20);
+        longest = std::max(longest, run);
+        float& w = (*trav)[TRAV_STRIDE * e + 2].w;
+        w = (float)(4u * run + ((uint32_t)w & 3u));
+    }
+    return longest;
 }
 
 // TextureMap / CubicMap: the pattern's second record points at its UV patterns, which are appended to `uvrec`.
@@ -537,6 +559,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         const float zero[4] = {0.0f, 0.0f, 0.0f, 1.0f};
         mat_vec4(cam->inv, zero, cam_origin);
         if (build_flat_bvh(scene, cam_origin, &trav)) {
+            hdr->max_leaf_run = mark_leaf_runs(&trav);
             hdr->internal_boxes = 1;
             hdr->n_trav = (uint32_t)(trav.size() / TRAV_STRIDE);
             soa->insert(soa->end(), trav.begin(), trav.end());
@@ -627,6 +650,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
             while (more < 3 && e + more + 1 < ne && trav[TRAV_STRIDE * (e + more + 1) + 1].w == TRAV_BOXED_LEAF_TAG) more++;
             trav[TRAV_STRIDE * e + 2].w = (float)more;
         }
+        hdr->max_leaf_run = mark_leaf_runs(&trav);
         // A small tree (<= 8 leaves under <= 8 groups) keeps the unrolled flat kernels: every group becomes a GATE -- its box,
         // tested once per ray with the reference's own aabb test -- and a leaf is intersected only if the ray opens all the
         // groups around it, which is all the recursive walk does (group.rs:115-133).  Same leaves in the same order.
@@ -1168,22 +1192,27 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     // sample-parallel rendering (render_body): compiled in when this frame is small enough to want it
     c->spec_shares = choose_share_log2(hdr, hdr.height) != 0u;
     const std::string share_def = std::string("-DRTC_SPEC_SHARE=") + (c->spec_shares ? "1" : "0");
-    // Recursion facts (rtc_kernel_core.h FrameStack): does any material reflect / transmit at all, and how many levels of
-    // the recursion stack the kernel keeps in registers.  Register levels pay where a shade point is cheap (a point
-    // light: frames are then the kernel's memory traffic) and cost occupancy where it is not (an area light's sample
-    // loop): default 5 (the reference's depth, constants.rs:4) for point lights, 0 otherwise; RTC_AMD_REG_LEVELS overrides.
-    bool any_refl = false, any_refr = false;
+    // Material facts (rtc_kernel_core.h): does any material reflect / transmit at all (a scene without either carries no
+    // recursion code), does any need powf for a highlight, and how many levels of the recursion stack the kernel keeps in
+    // registers (FrameStack).  Register levels were built to take the 2.5 GB of frame traffic out of the glass-and-mirror
+    // scene and do (scratch 448 -> 184 B per lane), but the frame gets only 2.5 % faster at 4 waves per SIMD and every
+    // other scene slower (tools/ab_env.py): the traffic was not what the waves wait for.  Default 0;
+    // RTC_AMD_REG_LEVELS=1..8 keeps the experiment reproducible.
+    bool any_refl = false, any_refr = false, any_specular = false;
     for (uint32_t i = 0; i < hdr.n_objects; i++) {
-        any_refl = any_refl || !(scene->objects[i].material.reflective == 0.0f);
-        any_refr = any_refr || !(scene->objects[i].material.transparency == 0.0f);
+        const rtc_material& m = scene->objects[i].material;
+        any_refl = any_refl || !(m.reflective == 0.0f);
+        any_refr = any_refr || !(m.transparency == 0.0f);
+        any_specular = any_specular || !(m.specular == 0.0f && m.shininess >= 0.0f && m.shininess <= 1e6f);  // phong: needs powf
     }
-    int reg_levels = (hdr.light_kind == RTC_LIGHT_POINT && (any_refl || any_refr)) ? 5 : 0;
+    int reg_levels = 0;
     if (const char* e = std::getenv("RTC_AMD_REG_LEVELS"))
         if (e[0] >= '0' && e[0] <= '8' && !e[1]) reg_levels = e[0] - '0';
     if (!any_refl && !any_refr) reg_levels = 0;
     std::vector<std::string> recursion_defs = {std::string("-DRTC_SPEC_ANY_REFL=") + (any_refl ? "1" : "0"),
                                                std::string("-DRTC_SPEC_ANY_REFR=") + (any_refr ? "1" : "0"),
-                                               "-DRTC_SPEC_REG_LEVELS=" + std::to_string(reg_levels)};
+                                               "-DRTC_SPEC_REG_LEVELS=" + std::to_string(reg_levels),
+                                               std::string("-DRTC_SPEC_ANY_SPECULAR=") + (any_specular ? "1" : "0")};
     // register levels need the registers: 13 dwords per level on top of the ~70 the kernel works in
     const char* reg_waves = reg_levels == 0 ? nullptr : reg_levels <= 3 ? "-DRTC_WAVES_PER_SIMD=4" : "-DRTC_WAVES_PER_SIMD=3";
     const uint32_t n = hdr.n_objects;

@@ -507,6 +507,7 @@ struct SceneHdr {
     // the one decision that asserts hits instead of removing tests.  Off, every shadow ray is tested against every
     // object: the image and the ray counts must not change (tests/test_gpu_light_cull.py, whole frames).
     uint32_t cull_flags;
+    uint32_t max_leaf_run;  // the longest run of consecutive leaf entries in SceneSoA::trav (host: lanes per pixel, for_each_leaf_shared)
 };
 constexpr uint32_t CULL_ENABLED = 1u, CULL_DARK = 2u;
 constexpr uint32_t RTC_MAX_GATES = 8;
@@ -614,6 +615,27 @@ DI bool spec_has_gates(uint32_t n) { return n != 0; }
 DI bool spec_has_tbox(uint32_t h) { return h != 0; }
 #endif
 
+// Scene facts a scene-compiled kernel knows (hiprtc, -DRTC_SPEC_ANY_REFL / _ANY_REFR / _REG_LEVELS): whether any material
+// reflects / transmits at all -- a scene without either has no recursion and carries no frame code, a mirror-only scene
+// no refraction half -- and how many levels of the recursion stack live in REGISTERS.
+#if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_ANY_REFL)
+constexpr bool ANY_REFL = RTC_SPEC_ANY_REFL != 0, ANY_REFR = RTC_SPEC_ANY_REFR != 0;
+#else
+constexpr bool ANY_REFL = true, ANY_REFR = true;
+#endif
+// ... and whether any material has a specular highlight that needs powf (phong)
+#if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_ANY_SPECULAR)
+constexpr bool ANY_SPECULAR = RTC_SPEC_ANY_SPECULAR != 0;
+#else
+constexpr bool ANY_SPECULAR = true;
+#endif
+#if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_REG_LEVELS)
+constexpr int STACK_REG_LEVELS = RTC_SPEC_REG_LEVELS;
+#else
+constexpr int STACK_REG_LEVELS = 0;
+#endif
+static_assert(STACK_REG_LEVELS >= 0 && STACK_REG_LEVELS <= RTC_MAX_DEPTH, "RTC_SPEC_REG_LEVELS");
+
 constexpr float PLANE_EPS = 1.1920929e-7f * 10000.0f;  // plane.rs:49  f32::EPSILON * 10000.0
 constexpr float SELF_EPS = 1.1920929e-7f * 10000.0f;   // world.rs:210
 constexpr float CLOSE_TO_ZERO = 0.000001f;             // cylinder.rs:82
@@ -716,7 +738,8 @@ DI float quadratic_c(uint32_t kind, V3 o) {
 DI V3 cross3(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 
 // `tri` / `i`: the triangle records and this object's index (wave-uniform); only read for RTC_TRIANGLE.
-template <bool HITS_ONLY, class F>
+// LANE_IDX: `i` differs from lane to lane (the leaf-sharing tree walk): the triangle records come through vector loads.
+template <bool HITS_ONLY, bool LANE_IDX = false, class F>
 DI void local_intersect_c(uint32_t bits, float min_y, float max_y, const float4* __restrict__ tri, uint32_t i, V3 o, V3 d,
                           float c, F&& f) {
     const uint32_t kind = bits & SHAPE_KIND_MASK;
@@ -800,7 +823,8 @@ DI void local_intersect_c(uint32_t bits, float min_y, float max_y, const float4*
             if ((cx * cx + cz * cz) <= 1.0f + CLOSE_TO_ZERO) f(t);
         }
     } else if (kind == RTC_TRIANGLE) {  // triangle.rs:45-68 (Moeller-Trumbore as written there)
-        const float4 t0 = load_uniform(tri, 3u * i), t1 = load_uniform(tri, 3u * i + 1u), t2 = load_uniform(tri, 3u * i + 2u);
+        const float4 t0 = LANE_IDX ? tri[3u * i] : load_uniform(tri, 3u * i), t1 = LANE_IDX ? tri[3u * i + 1u] : load_uniform(tri, 3u * i + 1u),
+                     t2 = LANE_IDX ? tri[3u * i + 2u] : load_uniform(tri, 3u * i + 2u);
         const V3 p1 = v3(t0.x, t0.y, t0.z), e1 = v3(t1.x, t1.y, t1.z), e2 = v3(t2.x, t2.y, t2.z);
         V3 dir_cross_e2 = cross3(d, e2);
         float determinant = dot3(e1, dir_cross_e2);
@@ -849,9 +873,9 @@ DI void local_intersect_c(uint32_t bits, float min_y, float max_y, const float4*
     }
 }
 
-template <bool HITS_ONLY, class F>
+template <bool HITS_ONLY, bool LANE_IDX = false, class F>
 DI void local_intersect(uint32_t bits, float min_y, float max_y, const float4* __restrict__ tri, uint32_t i, V3 o, V3 d, F&& f) {
-    local_intersect_c<HITS_ONLY>(bits, min_y, max_y, tri, i, o, d, quadratic_c(bits & SHAPE_KIND_MASK, o), f);
+    local_intersect_c<HITS_ONLY, LANE_IDX>(bits, min_y, max_y, tri, i, o, d, quadratic_c(bits & SHAPE_KIND_MASK, o), f);
 }
 
 // local_norm_at (sphere.rs:71-73, plane.rs:57-59, cube.rs:66-80, cylinder.rs:62-72, cone.rs:60-73)
@@ -996,6 +1020,61 @@ DI bool tri_precull(const WorldRay& wr, float4 b0, float4 b1, float4 b2) {
     return lo > hi;
 }
 
+template <bool B>
+struct BoolConstant {
+    static constexpr bool value = B;
+};
+// e2.w of a leaf entry, written by the host: (consecutive leaf entries from this one on, itself included) * 4 + (boxed
+// triangle leaves right after this one, at most 3) -- small whole numbers, exact as floats
+DI uint32_t trav_more(float w) { return (uint32_t)w & 3u; }
+DI uint32_t trav_run(float w) { return (uint32_t)w >> 2; }
+
+// The tree walk of a kernel whose pixels are traced by 2^s adjacent lanes each (Counters::SHARE_LANES), for a ray that
+// all of a pixel's lanes share -- the pixel's primary and secondary rays, a point light's shadow ray.  One lane per
+// pixel walks a mesh as ONE chain of dependent tests: the reference's divide() keeps every child that straddles the
+// split plane in the parent group (group.rs:46-73), a ring of dozens to hundreds of direct triangle children at every
+// level, and a frame's time is that of its slowest wave -- here_be_dragons at 1000 x 400 kept 3 % of the chip busy.
+// Here the lanes of a pixel SPLIT every run of consecutive leaves between them: lane `sub` takes the run's entries
+// sub, sub + 2^s, ...  (fetched per lane: vector loads), group entries are tested by all of them alike, and after
+// each run `after_run()` lets the caller pool what the lanes found (nearest_hit: the minimum over the pixel's lanes
+// becomes every lane's pruning limit).  Each leaf is still visited exactly once per pixel, by exactly one lane; what
+// the callers compute from the visits is order-independent in the tree kernels (ties go by object index), so the
+// split cannot change an answer.
+template <class F, class G>
+DI void for_each_leaf_shared(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, const Counters& cnt, F&& body, G&& after_run) {
+    uint32_t resume = 0;  // this lane ignores entries below `resume`
+    const uint32_t stride = 1u << cnt.share_log2(), sub = cnt.sub();
+    for (uint32_t k = 0; k < H.n_trav;) {
+        const ConstF4Ptr ep = ((ConstF4Ptr)(unsigned long)S.trav) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(TRAV_STRIDE * k));
+        const RawF4 r0 = ep[0], r1 = ep[1];
+        const bool active = k >= resume && wr.limit > -RTC_INF;
+        if (!(r1.w < 0.0f)) {  // a group (see for_each_object): every lane of the pixel takes the same decision
+            const uint32_t skip = __float_as_uint(r0.w);
+            bool inside = false;
+            if (active) {
+                float tmin;
+                inside = aabb_hit(wr.o, wr.inv, make_float4(r0.x, r0.y, r0.z, r0.w), make_float4(r1.x, r1.y, r1.z, r1.w), tmin);
+                if (inside && tmin > wr.limit + (r1.w + 1e-4f * fabsf(wr.limit))) inside = false;
+                if (!inside) resume = skip;
+            }
+            k = __any(inside) ? k + 1u : skip;
+        } else {
+            const uint32_t run = trav_run(ep[2].w);  // wave-uniform, >= 1
+            if (__any(active)) {
+                for (uint32_t m = sub; active && m < run; m += stride) {
+                    const float4* ent = S.trav + (size_t)TRAV_STRIDE * (k + m);  // this lane's own entry
+                    const float4 b0 = ent[0], b1 = ent[1];
+                    bool visit = true;
+                    if (spec_has_tbox(H.has_tbox) && b1.w == TRAV_BOXED_LEAF_TAG) visit = !tri_precull(wr, b0, b1, ent[2]);
+                    if (visit) body(__float_as_uint(b0.w));
+                }
+                after_run();
+            }
+            k += run;
+        }
+    }
+}
+
 // Applies `body(i)` to every object the reference's World::intersect would reach.  NOBJ > 0: the scene has at
 // most NOBJ objects and the loop is fully unrolled (record loads become loop-invariant SGPR values, per-object
 // state can live in registers); NOBJ == 0: any count; NOBJ < 0: the world contains GroupShapes -- the depth-first
@@ -1030,7 +1109,7 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
                     if (!inside) resume = skip;
                 }
                 k = __any(inside) ? k + 1u : skip;
-            } else if (spec_has_tbox(H.has_tbox) && e1.w == TRAV_BOXED_LEAF_TAG && e2.w >= 3.0f) {  // wave-uniform: three more such leaves follow
+            } else if (spec_has_tbox(H.has_tbox) && e1.w == TRAV_BOXED_LEAF_TAG && trav_more(e2.w) >= 3u) {  // wave-uniform: three more such leaves follow
                 float4 f[3][3];
 #pragma unroll
                 for (int j = 0; j < 3; j++)
@@ -1046,7 +1125,7 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
                 if (k + 2u >= resume && wr.limit > -RTC_INF && !c2) body(__float_as_uint(f[1][0].w));
                 if (k + 3u >= resume && wr.limit > -RTC_INF && !c3) body(__float_as_uint(f[2][0].w));
                 k += 4u;
-            } else if (spec_has_tbox(H.has_tbox) && e1.w == TRAV_BOXED_LEAF_TAG && e2.w > 0.0f) {  // wave-uniform
+            } else if (spec_has_tbox(H.has_tbox) && e1.w == TRAV_BOXED_LEAF_TAG && trav_more(e2.w) > 0u) {  // wave-uniform
                 // a boxed triangle followed by another one (e2.w, set on the host): both pre-culling tests at once.  In the
                 // long runs of such leaves the walk is one wave's chain of dependent instructions; two independent chains
                 // interleave.  Visiting order, and what each visit sees of the other's result (wr.limit), are unchanged.
@@ -1104,12 +1183,45 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
 // Tree walks only: `t_max` -- hits beyond it do not matter to the caller (a shadow ray's distance to the light);
 // `any_hit` -- the caller only asks whether there is a hit below t_max (a shadow ray in a world where every object
 // casts shadows: the nearest hit is then a caster whichever it is), so a lane stops at its first such hit.
-template <int NOBJ>
-DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, float t_max = RTC_INF, bool any_hit = false,
+// SHARED (tree kernels compiled for several lanes per pixel): every lane of the pixel traces this very ray; they split
+// the leaves between them (for_each_leaf_shared) and pool their nearest hits, so that all of them return the pixel's.
+template <int NOBJ, bool SHARED = false>
+DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, const Counters& cnt, float t_max = RTC_INF, bool any_hit = false,
                    uint32_t skip = 0u) {
     Hit best = {0.0f, -1};
     WorldRay wr = world_ray<NOBJ>(H, o, d);
     wr.limit = t_max;
+    if constexpr (NOBJ < 0 && SHARED && Counters::SHARE_LANES) {
+        for_each_leaf_shared(
+            H, S, wr, cnt,
+            [&](uint32_t i) {
+                if (i < 32u && ((skip >> i) & 1u)) return;  // light-cone culled for this shade point
+                Obj ob = load_obj(S, i);                    // per-lane index: vector loads
+                ob.bits = spec_bits(i, ob.bits);
+                V3 po = obj_point(ob, o);
+                V3 pd = obj_vector(ob, d);
+                local_intersect<true, true>(ob.bits, ob.min_y(), ob.max_y(), S.tri, i, po, pd, [&](float t) {
+                    const bool better = best.obj < 0 || t < best.t || (t == best.t && (int)i < best.obj);
+                    if (t >= 0.0f && better) {
+                        best.t = t;
+                        best.obj = (int)i;
+                        wr.limit = (any_hit && t < t_max) ? -RTC_INF : fminf(wr.limit, t);
+                    }
+                });
+            },
+            [&]() {  // the minimum over the pixel's lanes, in the order the reference's stable sort gives: (t, object index)
+                for (uint32_t m = 1u; m < (1u << cnt.share_log2()); m <<= 1) {
+                    const float ot = __shfl_xor(best.t, (int)m, 64);
+                    const int oo = __shfl_xor(best.obj, (int)m, 64);
+                    if (oo >= 0 && (best.obj < 0 || ot < best.t || (ot == best.t && oo < best.obj))) {
+                        best.t = ot;
+                        best.obj = oo;
+                    }
+                }
+                if (best.obj >= 0) wr.limit = (any_hit && best.t < t_max) ? -RTC_INF : fminf(wr.limit, best.t);
+            });
+        return best;
+    }
     for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) {
         if (i < 32u && ((skip >> i) & 1u)) return;  // light-cone culled for this shade point (wave-uniform)
         Obj ob = load_obj_static<NOBJ <= 0>(S, i);
@@ -1132,13 +1244,14 @@ DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, float t_max
 }
 
 // world.rs:104-119
-template <int NOBJ>
+// SHARED: see nearest_hit (the ray is counted once per pixel)
+template <int NOBJ, bool SHARED = false>
 DI bool is_shadowed(const SceneHdr& H, const SceneSoA& S, V3 light_position, V3 p, Counters& cnt, uint32_t skip = 0u) {
     V3 v = light_position - p;
     float distance = mag3(v);
     V3 direction = norm3(v);
-    cnt.rays++;
-    Hit h = nearest_hit<NOBJ>(H, S, p, direction, distance, H.all_cast != 0u, skip);
+    cnt.rays += SHARED ? cnt.lead() : 1u;
+    Hit h = nearest_hit<NOBJ, SHARED>(H, S, p, direction, cnt, distance, H.all_cast != 0u, skip);
     if (h.obj < 0) return false;
     bool casts = (__float_as_uint(S.geo[h.obj].w) & SHAPE_CASTS) != 0;
     return casts && h.t < distance;
@@ -1522,7 +1635,7 @@ DI float jitter_value(uint32_t h) {
 template <int NOBJ, bool SIMPLE>
 DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel, uint32_t path, Counters& cnt) {
     if (spec_light_kind(H.light_kind) == RTC_LIGHT_POINT) {
-        return is_shadowed<NOBJ>(H, S, v3(H.lpos[0], H.lpos[1], H.lpos[2]), p, cnt) ? 0.0f : 1.0f;
+        return is_shadowed<NOBJ, true>(H, S, v3(H.lpos[0], H.lpos[1], H.lpos[2]), p, cnt) ? 0.0f : 1.0f;
     }
     const V3 corner = v3(H.corner[0], H.corner[1], H.corner[2]);
     const V3 uvec = v3(H.uvec[0], H.uvec[1], H.uvec[2]);
@@ -1746,7 +1859,14 @@ DI V3 phong(const SceneHdr& H, V3 material_color, float4 ma, float4 mb, V3 p, V3
         V3 surface_reflection = reflect3(-to_light, n);
         float reflection_eye_cosine = dot3(surface_reflection, eye);
         if (!(reflection_eye_cosine <= 0.0f)) {
-            float factor = rtc_powf_dev(reflection_eye_cosine, mb.z);
+            // A material without a highlight (specular == 0: every object of the soft_shadows demo, the floor of most
+            // scenes): `light.intensity() * 0 * factor` is the zero `intensity * 0` again for any finite positive factor,
+            // and powf(c, s) is one for c in (0, 1 + 1e-6] -- a cosine of two unit vectors -- and 0 <= s <= 1e6.  The
+            // power (some 25 f64 operations) is then not evaluated; a scene-compiled kernel of a world without any
+            // highlight does not contain it at all.
+            const bool no_highlight = !ANY_SPECULAR || (mb.y == 0.0f && mb.z >= 0.0f && mb.z <= 1e6f);
+            float factor = 1.0f;
+            if (ANY_SPECULAR && !no_highlight) factor = rtc_powf_dev(reflection_eye_cosine, mb.z);
             specular = li * mb.y * factor;
         }
     }
@@ -1761,20 +1881,38 @@ DI V3 phong(const SceneHdr& H, V3 material_color, float4 ma, float4 mb, V3 p, V3
 // of its largest negative t (ties between objects: object order).  So the
 // "innermost container" is the odd-parity object with the largest
 // (t_max_negative, index); toggling the hit object then gives n2.
+// (Tree kernels with several lanes per pixel: the lanes split the leaves -- for_each_leaf_shared -- and merge their two
+// best containers at the end; an object is examined by exactly one lane, so the merged lists hold no duplicates.)
 template <int NOBJ>
-DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int hit_obj, float& n1, float& n2) {
+DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int hit_obj, float& n1, float& n2, const Counters& cnt) {
     WorldRay wr = world_ray<NOBJ>(H, o, d);
     wr.limit = 0.0f;             // only intersections behind the origin (t < 0) matter here
     float t1 = 0.0f, t2 = 0.0f;  // best and runner-up container keys
     int c1 = -1, c2 = -1;
     bool hit_inside = false;
-    for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) {
-        Obj ob = load_obj_static<NOBJ <= 0>(S, i);
+    // the later object (in list order) wins ties: it sorts after.  Flat loops visit in list order; tree walks
+    // compare indices explicitly (see nearest_hit).
+    auto after = [&](float ta, int ia, float tb, int ib) {  // does (ta, ia) sort after (tb, ib)?
+        if constexpr (NOBJ < 0) return ta > tb || (ta == tb && ia > ib);
+        else return ta >= tb;
+    };
+    auto offer = [&](float t, int c) {  // a container candidate
+        if (c1 < 0 || after(t, c, t1, c1)) {
+            t2 = t1;
+            c2 = c1;
+            t1 = t;
+            c1 = c;
+        } else if (c2 < 0 || after(t, c, t2, c2)) {
+            t2 = t;
+            c2 = c;
+        }
+    };
+    auto per_object = [&](uint32_t i, const Obj& ob, auto lane_idx) {
         V3 po = obj_point(ob, o);
         V3 pd = obj_vector(ob, d);
         int negatives = 0;
         float tmax = 0.0f;
-        local_intersect<false>(ob.bits, ob.min_y(), ob.max_y(), S.tri, i, po, pd, [&](float t) {
+        local_intersect<false, decltype(lane_idx)::value>(ob.bits, ob.min_y(), ob.max_y(), S.tri, i, po, pd, [&](float t) {
             if (t < 0.0f) {
                 if (negatives == 0 || t > tmax) tmax = t;
                 negatives++;
@@ -1782,23 +1920,30 @@ DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int
         });
         if (negatives & 1) {
             if ((int)i == hit_obj) hit_inside = true;
-            // the later object (in list order) wins ties: it sorts after.  Flat loops visit in list order; tree walks
-            // compare indices explicitly (see nearest_hit).
-            auto after = [&](float ta, int ia, float tb, int ib) {  // does (ta, ia) sort after (tb, ib)?
-                if constexpr (NOBJ < 0) return ta > tb || (ta == tb && ia > ib);
-                else return ta >= tb;
-            };
-            if (c1 < 0 || after(tmax, (int)i, t1, c1)) {
-                t2 = t1;
-                c2 = c1;
-                t1 = tmax;
-                c1 = (int)i;
-            } else if (c2 < 0 || after(tmax, (int)i, t2, c2)) {
-                t2 = tmax;
-                c2 = (int)i;
-            }
+            offer(tmax, (int)i);
         }
-    });
+    };
+    using LaneIdx = BoolConstant<true>;
+    using UniformIdx = BoolConstant<false>;
+    if constexpr (NOBJ < 0 && Counters::SHARE_LANES) {
+        for_each_leaf_shared(
+            H, S, wr, cnt,
+            [&](uint32_t i) {
+                Obj ob = load_obj(S, i);
+                ob.bits = spec_bits(i, ob.bits);
+                per_object(i, ob, LaneIdx());
+            },
+            [&]() {});
+        for (uint32_t m = 1u; m < (1u << cnt.share_log2()); m <<= 1) {
+            const float pt1 = __shfl_xor(t1, (int)m, 64), pt2 = __shfl_xor(t2, (int)m, 64);
+            const int pc1 = __shfl_xor(c1, (int)m, 64), pc2 = __shfl_xor(c2, (int)m, 64);
+            if (pc1 >= 0) offer(pt1, pc1);
+            if (pc2 >= 0) offer(pt2, pc2);
+            hit_inside = hit_inside || (__shfl_xor((int)hit_inside, (int)m, 64) != 0);
+        }
+    } else {
+        for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) { per_object(i, load_obj_static<NOBJ <= 0>(S, i), UniformIdx()); });
+    }
     const float vacuum = 1.0f;  // REFRACTION_VACCUM, constants.rs:6
     n1 = c1 >= 0 ? S.mat_c[c1].y : vacuum;
     if (!hit_inside) {
@@ -1855,21 +2000,6 @@ struct FrameRefr {
     float transparency;
 };
 enum { F_WAIT_REFR = 1, F_HAS_REFR = 2, F_SCHLICK = 4 };
-
-// Scene facts a scene-compiled kernel knows (hiprtc, -DRTC_SPEC_ANY_REFL / _ANY_REFR / _REG_LEVELS): whether any material
-// reflects / transmits at all -- a scene without either has no recursion and carries no frame code, a mirror-only scene
-// no refraction half -- and how many levels of the recursion stack live in REGISTERS.
-#if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_ANY_REFL)
-constexpr bool ANY_REFL = RTC_SPEC_ANY_REFL != 0, ANY_REFR = RTC_SPEC_ANY_REFR != 0;
-#else
-constexpr bool ANY_REFL = true, ANY_REFR = true;
-#endif
-#if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_REG_LEVELS)
-constexpr int STACK_REG_LEVELS = RTC_SPEC_REG_LEVELS;
-#else
-constexpr int STACK_REG_LEVELS = 0;
-#endif
-static_assert(STACK_REG_LEVELS >= 0 && STACK_REG_LEVELS <= RTC_MAX_DEPTH, "RTC_SPEC_REG_LEVELS");
 
 // The post-order stack of color_at: one Frame (+ FrameRefr) per suspended shade_hit, at most `depth` of them.
 // A per-lane array indexed by a per-lane stack pointer lives in scratch memory: every push and pop is a round trip
@@ -1951,7 +2081,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
     for (;;) {
         // ---------------- color_at(ray(o, d), rem)
         cnt.rays += cnt.lead();
-        Hit h = nearest_hit<NOBJ>(H, S, o, d);
+        Hit h = nearest_hit<NOBJ, true>(H, S, o, d, cnt);
         bool descend = false;
         ret = v3(0.0f, 0.0f, 0.0f);
         if (h.obj >= 0) {
@@ -2023,7 +2153,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
             V3 rdir = v3(0.0f, 0.0f, 0.0f);
             if (ANY_REFR && transparency != 0.0f) {
                 float n1, n2;
-                refraction_indices<NOBJ>(H, S, o, d, ob, n1, n2);
+                refraction_indices<NOBJ>(H, S, o, d, ob, n1, n2, cnt);
                 if (use_schlick) R = schlick(eye, n, n1, n2);
                 if (rem != 0) {  // refracted_color, world.rs:140-161
                     float n_ratio = n1 / n2;
