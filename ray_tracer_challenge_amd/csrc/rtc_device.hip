@@ -354,15 +354,25 @@ static bool build_flat_bvh(const rtc_scene* scene, const float cam_origin[4], st
     return true;
 }
 
-// Every leaf entry learns how many consecutive leaf entries start with it (kernel: trav_run / trav_more share e2.w, which
-// holds `more` -- 0..3 -- on entry); returns the longest run.
+// Every leaf entry learns how many consecutive leaf entries OF THE SAME GROUP start with it (kernel: trav_run / trav_more
+// share e2.w, which holds `more` -- 0..3 -- on entry); returns the longest run.  A run ends where a group ends: the
+// leaves after a nested group's last child belong to rays that may not have entered that group at all.
 static uint32_t mark_leaf_runs(std::vector<float4>* trav) {
+    const size_t ne = trav->size() / TRAV_STRIDE;
+    std::vector<char> ends_subtree(ne + 1, 0);  // [e]: some group's subtree ends right before entry e
+    for (size_t e = 0; e < ne; e++)
+        if (!((*trav)[TRAV_STRIDE * e + 1].w < 0.0f)) {
+            uint32_t skip;
+            std::memcpy(&skip, &(*trav)[TRAV_STRIDE * e].w, 4);
+            if (skip <= ne) ends_subtree[skip] = 1;
+        }
     uint32_t longest = 0, run = 0;
-    for (size_t e = trav->size() / TRAV_STRIDE; e-- > 0;) {
+    for (size_t e = ne; e-- > 0;) {
         if (!((*trav)[TRAV_STRIDE * e + 1].w < 0.0f)) {  // a group
             run = 0;
             continue;
         }
+        if (ends_subtree[e + 1]) run = 0;
         run = std::min(run + 1u, 1u << 20);
         longest = std::max(longest, run);
         float& w = (*trav)[TRAV_STRIDE * e + 2].w;
