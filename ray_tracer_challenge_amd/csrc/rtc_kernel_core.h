@@ -1020,6 +1020,21 @@ DI bool tri_precull(const WorldRay& wr, float4 b0, float4 b1, float4 b2) {
     return lo > hi;
 }
 
+#ifdef RTC_NO_SHARED_WALK  // development: a pixel's lanes all walk every leaf, as before for_each_leaf_shared existed
+constexpr bool SHARED_WALK = false;
+#else
+constexpr bool SHARED_WALK = true;
+#endif
+#ifdef RTC_NO_SHARED_HIT
+constexpr bool SHARED_WALK_HIT = false;
+#else
+constexpr bool SHARED_WALK_HIT = true;
+#endif
+#ifdef RTC_NO_SHARED_N12
+constexpr bool SHARED_WALK_N12 = false;
+#else
+constexpr bool SHARED_WALK_N12 = true;
+#endif
 template <bool B>
 struct BoolConstant {
     static constexpr bool value = B;
@@ -1191,7 +1206,7 @@ DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, const Count
     Hit best = {0.0f, -1};
     WorldRay wr = world_ray<NOBJ>(H, o, d);
     wr.limit = t_max;
-    if constexpr (NOBJ < 0 && SHARED && Counters::SHARE_LANES) {
+    if constexpr (NOBJ < 0 && SHARED && Counters::SHARE_LANES && SHARED_WALK && SHARED_WALK_HIT) {
         for_each_leaf_shared(
             H, S, wr, cnt,
             [&](uint32_t i) {
@@ -1925,7 +1940,7 @@ DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int
     };
     using LaneIdx = BoolConstant<true>;
     using UniformIdx = BoolConstant<false>;
-    if constexpr (NOBJ < 0 && Counters::SHARE_LANES) {
+    if constexpr (NOBJ < 0 && Counters::SHARE_LANES && SHARED_WALK && SHARED_WALK_N12) {
         for_each_leaf_shared(
             H, S, wr, cnt,
             [&](uint32_t i) {
@@ -1939,7 +1954,8 @@ DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int
             const int pc1 = __shfl_xor(c1, (int)m, 64), pc2 = __shfl_xor(c2, (int)m, 64);
             if (pc1 >= 0) offer(pt1, pc1);
             if (pc2 >= 0) offer(pt2, pc2);
-            hit_inside = hit_inside || (__shfl_xor((int)hit_inside, (int)m, 64) != 0);
+            const int partner_inside = __shfl_xor((int)hit_inside, (int)m, 64);  // (every lane must take part: no short circuit)
+            hit_inside = hit_inside || partner_inside != 0;
         }
     } else {
         for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) { per_object(i, load_obj_static<NOBJ <= 0>(S, i), UniformIdx()); });
