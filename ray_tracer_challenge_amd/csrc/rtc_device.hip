@@ -453,8 +453,10 @@ static rtc_status pack_uv_pattern(const rtc_uv_pattern& u, std::vector<float4>* 
     return RTC_OK;
 }
 
+// `heavy_boxes` (optional): world-space boxes, 6 floats each, of the top-level GroupShapes that hold long runs of leaves
+// (divided meshes) -- where a frame's slow waves are (rtc_ctx_render: block list).
 static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHdr* hdr, std::vector<float4>* soa,
-                          std::vector<float>* texels) {
+                          std::vector<float>* texels, std::vector<float>* heavy_boxes = nullptr) {
     std::vector<float4> uvrec;
     std::vector<std::pair<const float*, size_t>> seen_images;
     if (!scene) return fail(RTC_ERR_INVALID_ARG, "scene is NULL");
@@ -610,6 +612,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         };
         std::vector<float4> trav;
         std::vector<Open> open;
+        std::vector<std::pair<size_t, uint32_t>> top_level;  // (entry, group) of the groups directly under the world
         uint32_t gi = 0;
         bool any = false;
         auto as_f = [](uint32_t u) {
@@ -630,6 +633,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
                 if (end > n || (!open.empty() && end > open.back().end))
                     return fail(RTC_ERR_INVALID_ARG, "group %u: objects [%u, %u) do not nest inside the enclosing group / the world",
                                 gi, g.first_object, (unsigned)end);
+                if (open.empty()) top_level.push_back({trav.size() / TRAV_STRIDE, gi});
                 open.push_back({(uint32_t)end, trav.size() / TRAV_STRIDE});
                 float big = 0.0f;  // pruning slack: 1e-3 of the largest |coordinate| (NaN-propagating on purpose)
                 for (int a = 0; a < 3; a++) {
@@ -661,6 +665,18 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
             trav[TRAV_STRIDE * e + 2].w = (float)more;
         }
         hdr->max_leaf_run = mark_leaf_runs(&trav);
+        if (heavy_boxes)
+            for (const auto& tl : top_level) {
+                uint32_t skip, longest = 0;
+                std::memcpy(&skip, &trav[TRAV_STRIDE * tl.first].w, 4);
+                for (size_t e = tl.first + 1; e < skip && e < trav.size() / TRAV_STRIDE; e++)
+                    if (trav[TRAV_STRIDE * e + 1].w < 0.0f) longest = std::max(longest, (uint32_t)trav[TRAV_STRIDE * e + 2].w >> 2);
+                if (longest >= 16u) {
+                    const rtc_group& g = scene->groups[tl.second];
+                    for (int a = 0; a < 3; a++) heavy_boxes->push_back(g.bounds_min[a]);
+                    for (int a = 0; a < 3; a++) heavy_boxes->push_back(g.bounds_max[a]);
+                }
+            }
         // A small tree (<= 8 leaves under <= 8 groups) keeps the unrolled flat kernels: every group becomes a GATE -- its box,
         // tested once per ray with the reference's own aabb test -- and a leaf is intersected only if the ray opens all the
         // groups around it, which is all the recursive walk does (group.rs:115-133).  Same leaves in the same order.
@@ -830,6 +846,10 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
 
 using namespace rtc;
 
+struct rtc_ctx_tiles {
+    const uint8_t* bits;
+    uint32_t w, h;
+};
 struct rtc_ctx {
     int device = 0;
     SceneHdr hdr;
@@ -847,6 +867,15 @@ struct rtc_ctx {
     bool spec_shares = false;         // spec_fn was compiled with -DRTC_SPEC_SHARE=1
     hipFunction_t spec_fn = nullptr;  // scene-specialised kernel (hiprtc), or null: ahead-of-time kernels
     std::string kernel_name;          // what rtc_ctx_render launches, for rtc_ctx_kernel_name()
+    // Block list of the current scene (RenderArgs::tiles): which 16 x 16 pixel tiles of the image a mesh projects to
+    // (row-major bitmap, empty: no block list), and the list last built -- for the partition it was built for
+    std::vector<uint8_t> heavy_tiles;
+    uint32_t heavy_w = 0, heavy_h = 0;
+    std::vector<uint32_t> blocks_host;
+    uint32_t* d_blocks = nullptr;
+    size_t blocks_cap = 0;
+    uint32_t blocks_for[3] = {0u, 0u, 0u};  // band_rows, n_parts, part
+    bool blocks_valid = false;
     std::string kernel_id;            // rtc_ctx_kernel_id(): names the code object (source + options + compiler), not the scene
     std::string jit_note;             // why spec_fn is null although the policy wanted one (rtc_ctx_jit_status)
     // the scene as last uploaded: an identical one (rtc_render_ex called again for the next frame) is not uploaded twice
@@ -1117,11 +1146,72 @@ void rtc_ctx_destroy(rtc_ctx* c) {
     if (c->d_total) (void)hipFree(c->d_total);
     if (c->d_ppm_rows) (void)hipFree(c->d_ppm_rows);
     if (c->d_ppm_bits) (void)hipFree(c->d_ppm_bits);
+    if (c->d_blocks) (void)hipFree(c->d_blocks);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
     delete c;
+}
+
+// Which 16 x 16 pixel tiles do the boxes of the mesh-holding groups project to?  ray_for_pixel (camera.rs:60-74) sends
+// pixel (px, py) through the camera-space point (half_width - (px + 0.5) s, half_height - (py + 0.5) s, -1); a world
+// point maps to camera space through the inverse of Camera.transform_inverse.  Performance only -- which blocks start
+// first and with how many lanes per pixel -- so generous padding and "everything" when a box reaches behind the camera.
+static void project_heavy_boxes(const std::vector<float>& boxes, const rtc_camera* cam, std::vector<uint8_t>* tiles, uint32_t* tw, uint32_t* th) {
+    tiles->clear();
+    *tw = *th = 0;
+    if (boxes.empty() || !cam || !env_flag("RTC_AMD_BLOCK_LIST", true)) return;
+    float view[16];
+    inverse4(cam->inv, view);
+    const uint32_t w = (cam->width + 15u) / 16u, h = (cam->height + 15u) / 16u;
+    tiles->assign((size_t)w * h, 0);
+    *tw = w;
+    *th = h;
+    for (size_t b = 0; b + 5 < boxes.size(); b += 6) {
+        double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+        bool everything = false;
+        for (int k = 0; k < 8 && !everything; k++) {
+            const float p[4] = {boxes[b + ((k & 1) ? 3 : 0)], boxes[b + ((k & 2) ? 4 : 1)], boxes[b + ((k & 4) ? 5 : 2)], 1.0f};
+            float q[4];
+            mat_vec4(view, p, q);
+            if (!(q[2] < -1e-4f) || !std::isfinite(q[0]) || !std::isfinite(q[1]) || !std::isfinite(q[2])) {
+                everything = true;
+                break;
+            }
+            const double px = ((double)cam->half_width - (double)q[0] / -(double)q[2]) / cam->pixel_size - 0.5;
+            const double py = ((double)cam->half_height - (double)q[1] / -(double)q[2]) / cam->pixel_size - 0.5;
+            x0 = std::fmin(x0, px), x1 = std::fmax(x1, px), y0 = std::fmin(y0, py), y1 = std::fmax(y1, py);
+        }
+        if (everything) x0 = y0 = -1e9, x1 = y1 = 1e9;
+        const long tx0 = std::max(0L, (long)std::floor((x0 - 8.0) / 16.0)), tx1 = std::min((long)w - 1, (long)std::floor((x1 + 8.0) / 16.0));
+        const long ty0 = std::max(0L, (long)std::floor((y0 - 8.0) / 16.0)), ty1 = std::min((long)h - 1, (long)std::floor((y1 + 8.0) / 16.0));
+        for (long ty = ty0; ty <= ty1; ty++)
+            for (long tx = tx0; tx <= tx1; tx++) (*tiles)[(size_t)ty * w + tx] = 1;
+    }
+}
+
+// The block list of one partition (RenderArgs::tiles): the 16 x 16 tiles of the partition's compact rows, those a mesh
+// projects to first and cut into eight 8 x 4 blocks of 8 lanes per pixel, the others after them, whole, one lane per pixel.
+static void build_block_list(const rtc_ctx_tiles& T, uint32_t width, uint32_t height, uint32_t rows, const Partition& q, std::vector<uint32_t>* out) {
+    out->clear();
+    std::vector<uint32_t> light;
+    for (uint32_t yl0 = 0; yl0 < rows; yl0 += 16u) {
+        const uint32_t band = yl0 / q.band_rows;
+        const uint32_t y = (band * q.n_parts + q.part) * q.band_rows + (yl0 - band * q.band_rows);  // global row of the tile's first row
+        for (uint32_t x0 = 0; x0 < width; x0 += 16u) {
+            const uint32_t ty = std::min(y / 16u, T.h - 1u), tx = std::min(x0 / 16u, T.w - 1u);
+            if (T.bits[(size_t)ty * T.w + tx]) {
+                for (uint32_t dy = 0; dy < 16u && yl0 + dy < rows; dy += 4u)
+                    for (uint32_t dx = 0; dx < 16u && x0 + dx < width; dx += 8u)
+                        out->push_back(3u << 30 | ((x0 + dx) / 4u) << 16 | ((yl0 + dy) / 4u));
+            } else {
+                light.push_back(0u << 30 | (x0 / 4u) << 16 | (yl0 / 4u));
+            }
+        }
+    }
+    (void)height;
+    out->insert(out->end(), light.begin(), light.end());
 }
 
 // The policy wanted a scene-compiled kernel and hiprtc did not deliver one.  RTC_AMD_SPECIALIZE=1: an error.  Default
@@ -1151,7 +1241,8 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     SceneHdr hdr;
     std::vector<float4> soa;
     std::vector<float> texels;
-    rtc_status st = flatten(scene, camera, &hdr, &soa, &texels);
+    std::vector<float> heavy_boxes;
+    rtc_status st = flatten(scene, camera, &hdr, &soa, &texels, &heavy_boxes);
     if (st != RTC_OK) return st;
     HIP_TRY(hipSetDevice(c->device));
     if (c->has_scene && std::memcmp(&hdr, &c->hdr, sizeof(hdr)) == 0 && soa.size() == c->soa_host.size() &&
@@ -1197,6 +1288,8 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     c->has_scene = true;
     c->soa_host = soa;
     c->texels_host = texels;
+    c->blocks_valid = false;
+    project_heavy_boxes(heavy_boxes, camera, &c->heavy_tiles, &c->heavy_w, &c->heavy_h);
     // which kernel will render this scene
     c->spec_fn = nullptr;
     // sample-parallel rendering (render_body): compiled in when this frame is small enough to want it
@@ -1348,6 +1441,30 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     const uint32_t share_log2 = (c->spec_fn && c->spec_shares) ? choose_share_log2(c->hdr, rows) : 0u;  // only kernels compiled for it share lanes
     const uint32_t bw = 16u >> (share_log2 >> 1), bh = 16u >> ((share_log2 + 1u) >> 1);  // pixels per workgroup (2x2 wave tiles)
     dim3 grid((c->hdr.width + bw - 1) / bw, (rows + bh - 1) / bh), block(256);
+    // Tree worlds with meshes: a block list instead of the regular grid -- the tiles a mesh projects to first, eight
+    // lanes per pixel there and one elsewhere (build_block_list).  Not when RTC_AMD_SHARE_LOG2 pins one value for all.
+    const uint32_t* d_tiles = nullptr;
+    if (share_log2 != 0u && !c->heavy_tiles.empty() && c->hdr.light_kind == RTC_LIGHT_POINT && !std::getenv("RTC_AMD_SHARE_LOG2") &&
+        c->hdr.width <= 65532u && rows <= 262140u && rows > 0u) {
+        if (!c->blocks_valid || c->blocks_for[0] != q.band_rows || c->blocks_for[1] != q.n_parts || c->blocks_for[2] != q.part) {
+            const rtc_ctx_tiles T = {c->heavy_tiles.data(), c->heavy_w, c->heavy_h};
+            // the previous list may still be read by a launch in flight
+            HIP_TRY(hipDeviceSynchronize());
+            build_block_list(T, c->hdr.width, c->hdr.height, rows, q, &c->blocks_host);
+            if (c->blocks_host.size() > c->blocks_cap) {
+                if (c->d_blocks) (void)hipFree(c->d_blocks);
+                c->d_blocks = nullptr;
+                c->blocks_cap = 0;
+                HIP_TRY(hipMalloc(&c->d_blocks, c->blocks_host.size() * sizeof(uint32_t)));
+                c->blocks_cap = c->blocks_host.size();
+            }
+            HIP_TRY(hipMemcpy(c->d_blocks, c->blocks_host.data(), c->blocks_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            c->blocks_for[0] = q.band_rows, c->blocks_for[1] = q.n_parts, c->blocks_for[2] = q.part;
+            c->blocks_valid = true;
+        }
+        d_tiles = c->d_blocks;
+        grid = dim3((uint32_t)c->blocks_host.size(), 1);
+    }
     const size_t n_blocks = (size_t)grid.x * grid.y * 4;  // partial counts: one per wave
     if (n_blocks > c->block_cap) {  // grow-only workspace (first call / larger image only)
         if (c->d_block_counts) HIP_TRY(hipFree(c->d_block_counts));
@@ -1385,6 +1502,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     a.part = q.part;
     a.depth = depth;
     a.share_log2 = share_log2;
+    a.tiles = d_tiles;
     if (c->events_used == c->events.size()) {
         if (c->events.size() >= 4096) {
             c->events_used = 0;  // nobody is reading the timings: recycle

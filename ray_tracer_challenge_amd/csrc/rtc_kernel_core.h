@@ -2261,6 +2261,12 @@ struct RenderArgs {
     uint32_t band_rows, n_parts, part;
     int32_t depth;
     uint32_t share_log2;   // 2^share_log2 lanes per pixel (see Counters): > 0 only for area lights on small images
+    // Block list (kernels compiled for lane sharing; tree worlds with long leaf runs): workgroup b renders the block
+    // tiles[b] = s << 30 | (x0 / 4) << 16 | (y0 / 4) -- pixel origin (x0, local row y0) and ITS OWN lanes-per-pixel 2^s --
+    // instead of block (blockIdx.x, blockIdx.y) of a regular grid.  The host lists the blocks of image regions a mesh
+    // projects to first and with 8 lanes per pixel, the rest after them with one (rtc_device.hip build_block_list):
+    // such a frame's time is that of its slowest waves, so those start first and are cut into eight.  nullptr: regular grid.
+    const uint32_t* tiles;
 };
 
 // Camera::render (camera.rs:76-91): one lane per pixel, 8x8 pixel tile per
@@ -2276,10 +2282,20 @@ DI void render_body(const RenderArgs& A) {
     // each working through 64 pixels x 100 shadow rays, leaves most of the chip idle for the length of one wave.
     // With 2^s lanes per pixel a wave takes a tile of 64 >> s pixels (8x8, 8x4, 4x4, 4x2) and every lane a 2^-s share of
     // each shade point's light cells; all other work is replicated across a pixel's lanes (same inputs, same bits).
-    const uint32_t sl = Counters::SHARE_LANES ? A.share_log2 : 0u, q = lane >> sl;  // q: the pixel's slot in the wave's tile
+    uint32_t sl = Counters::SHARE_LANES ? A.share_log2 : 0u, bx0, by0;  // lanes per pixel (log2) and pixel origin of this workgroup's block
+    if (Counters::SHARE_LANES && A.tiles != nullptr) {
+        const uint32_t t = A.tiles[blockIdx.x];  // wave-uniform
+        sl = t >> 30;
+        bx0 = ((t >> 16) & 0x3fffu) << 2;
+        by0 = (t & 0xffffu) << 2;
+    } else {
+        bx0 = blockIdx.x << (4u - (sl >> 1));
+        by0 = blockIdx.y << (4u - ((sl + 1u) >> 1));
+    }
+    const uint32_t q = lane >> sl;  // q: the pixel's slot in the wave's tile
     const uint32_t tw_log2 = 3u - (sl >> 1), th_log2 = 3u - ((sl + 1u) >> 1);
-    const uint32_t x = ((blockIdx.x * 2u + (wave & 1u)) << tw_log2) + (q & ((1u << tw_log2) - 1u));
-    const uint32_t yl = ((blockIdx.y * 2u + (wave >> 1)) << th_log2) + (q >> tw_log2);
+    const uint32_t x = bx0 + ((wave & 1u) << tw_log2) + (q & ((1u << tw_log2) - 1u));
+    const uint32_t yl = by0 + ((wave >> 1) << th_log2) + (q >> tw_log2);
     Counters cnt = {0u, 0u, sl};
     __shared__ float stash_lds[STASH_SLOTS * 256];
     const LaneStash stash = {stash_lds + threadIdx.x, 256u};
