@@ -354,10 +354,13 @@ static bool build_flat_bvh(const rtc_scene* scene, const float cam_origin[4], st
     return true;
 }
 
-// Every leaf entry learns how many consecutive leaf entries OF THE SAME GROUP start with it (kernel: trav_run / trav_more
-// share e2.w, which holds `more` -- 0..3 -- on entry); returns the longest run.  A run ends where a group ends: the
-// leaves after a nested group's last child belong to rays that may not have entered that group at all.
-static uint32_t mark_leaf_runs(std::vector<float4>* trav) {
+// Every leaf entry learns how many consecutive leaf entries OF THE SAME GROUP start with it, and whether those are a MESH
+// run -- boxed triangle leaves of consecutive object indices that all share one inverse transform and one kind / flags
+// word, which is what the children of a parsed, transformed, divided mesh are (group.rs:39-44 bakes the group's transform
+// into every child) -- see the kernel's trav_run / trav_mesh_run / trav_more, which share e2.w (it holds `more`, 0..3,
+// on entry).  A run ends where a group ends: the leaves after a nested group's last child belong to rays that may not
+// have entered that group at all.  Returns the longest run.
+static uint32_t mark_leaf_runs(std::vector<float4>* trav, const rtc_scene* scene) {
     const size_t ne = trav->size() / TRAV_STRIDE;
     std::vector<char> ends_subtree(ne + 1, 0);  // [e]: some group's subtree ends right before entry e
     for (size_t e = 0; e < ne; e++)
@@ -366,17 +369,32 @@ static uint32_t mark_leaf_runs(std::vector<float4>* trav) {
             std::memcpy(&skip, &(*trav)[TRAV_STRIDE * e].w, 4);
             if (skip <= ne) ends_subtree[skip] = 1;
         }
+    auto object_of = [&](size_t e) {
+        uint32_t idx;
+        std::memcpy(&idx, &(*trav)[TRAV_STRIDE * e].w, 4);
+        return idx;
+    };
+    auto same_mesh = [&](size_t a, size_t b) {  // entry b continues the mesh run of entry a
+        const uint32_t ia = object_of(a), ib = object_of(b);
+        if (ib != ia + 1u || ib >= scene->n_objects) return false;
+        const rtc_object &oa = scene->objects[ia], &ob = scene->objects[ib];
+        return oa.kind == ob.kind && (oa.casts_shadow != 0) == (ob.casts_shadow != 0) && std::memcmp(oa.inv, ob.inv, sizeof(oa.inv)) == 0;
+    };
     uint32_t longest = 0, run = 0;
+    bool mesh = false;
     for (size_t e = ne; e-- > 0;) {
         if (!((*trav)[TRAV_STRIDE * e + 1].w < 0.0f)) {  // a group
             run = 0;
             continue;
         }
         if (ends_subtree[e + 1]) run = 0;
+        const bool boxed_tri = (*trav)[TRAV_STRIDE * e + 1].w == TRAV_BOXED_LEAF_TAG && object_of(e) < scene->n_objects &&
+                               scene->objects[object_of(e)].kind == RTC_TRIANGLE;
+        mesh = boxed_tri && (run == 0 || (mesh && same_mesh(e, e + 1)));
         run = std::min(run + 1u, 1u << 20);
         longest = std::max(longest, run);
         float& w = (*trav)[TRAV_STRIDE * e + 2].w;
-        w = (float)(4u * run + ((uint32_t)w & 3u));
+        w = (float)(8u * run + (mesh ? 4u : 0u) + ((uint32_t)w & 3u));
     }
     return longest;
 }
@@ -571,7 +589,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         const float zero[4] = {0.0f, 0.0f, 0.0f, 1.0f};
         mat_vec4(cam->inv, zero, cam_origin);
         if (build_flat_bvh(scene, cam_origin, &trav)) {
-            hdr->max_leaf_run = mark_leaf_runs(&trav);
+            hdr->max_leaf_run = mark_leaf_runs(&trav, scene);
             hdr->internal_boxes = 1;
             hdr->n_trav = (uint32_t)(trav.size() / TRAV_STRIDE);
             soa->insert(soa->end(), trav.begin(), trav.end());
@@ -664,13 +682,13 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
             while (more < 3 && e + more + 1 < ne && trav[TRAV_STRIDE * (e + more + 1) + 1].w == TRAV_BOXED_LEAF_TAG) more++;
             trav[TRAV_STRIDE * e + 2].w = (float)more;
         }
-        hdr->max_leaf_run = mark_leaf_runs(&trav);
+        hdr->max_leaf_run = mark_leaf_runs(&trav, scene);
         if (heavy_boxes)
             for (const auto& tl : top_level) {
                 uint32_t skip, longest = 0;
                 std::memcpy(&skip, &trav[TRAV_STRIDE * tl.first].w, 4);
                 for (size_t e = tl.first + 1; e < skip && e < trav.size() / TRAV_STRIDE; e++)
-                    if (trav[TRAV_STRIDE * e + 1].w < 0.0f) longest = std::max(longest, (uint32_t)trav[TRAV_STRIDE * e + 2].w >> 2);
+                    if (trav[TRAV_STRIDE * e + 1].w < 0.0f) longest = std::max(longest, (uint32_t)trav[TRAV_STRIDE * e + 2].w >> 3);
                 if (longest >= 16u) {
                     const rtc_group& g = scene->groups[tl.second];
                     for (int a = 0; a < 3; a++) heavy_boxes->push_back(g.bounds_min[a]);
@@ -1196,15 +1214,19 @@ static void project_heavy_boxes(const std::vector<float>& boxes, const rtc_camer
 static void build_block_list(const rtc_ctx_tiles& T, uint32_t width, uint32_t height, uint32_t rows, const Partition& q, std::vector<uint32_t>* out) {
     out->clear();
     std::vector<uint32_t> light;
+    uint32_t hs = 3u;  // lanes per pixel (log2) in the mesh tiles; RTC_AMD_BLOCK_S=0..3: development
+    if (const char* e = std::getenv("RTC_AMD_BLOCK_S"))
+        if (e[0] >= '0' && e[0] <= '3' && !e[1]) hs = (uint32_t)(e[0] - '0');
+    const uint32_t hbw = 16u >> (hs >> 1), hbh = 16u >> ((hs + 1u) >> 1);
     for (uint32_t yl0 = 0; yl0 < rows; yl0 += 16u) {
         const uint32_t band = yl0 / q.band_rows;
         const uint32_t y = (band * q.n_parts + q.part) * q.band_rows + (yl0 - band * q.band_rows);  // global row of the tile's first row
         for (uint32_t x0 = 0; x0 < width; x0 += 16u) {
             const uint32_t ty = std::min(y / 16u, T.h - 1u), tx = std::min(x0 / 16u, T.w - 1u);
             if (T.bits[(size_t)ty * T.w + tx]) {
-                for (uint32_t dy = 0; dy < 16u && yl0 + dy < rows; dy += 4u)
-                    for (uint32_t dx = 0; dx < 16u && x0 + dx < width; dx += 8u)
-                        out->push_back(3u << 30 | ((x0 + dx) / 4u) << 16 | ((yl0 + dy) / 4u));
+                for (uint32_t dy = 0; dy < 16u && yl0 + dy < rows; dy += hbh)
+                    for (uint32_t dx = 0; dx < 16u && x0 + dx < width; dx += hbw)
+                        out->push_back(hs << 30 | ((x0 + dx) / 4u) << 16 | ((yl0 + dy) / 4u));
             } else {
                 light.push_back(0u << 30 | (x0 / 4u) << 16 | (yl0 / 4u));
             }
@@ -1444,7 +1466,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     // Tree worlds with meshes: a block list instead of the regular grid -- the tiles a mesh projects to first, eight
     // lanes per pixel there and one elsewhere (build_block_list).  Not when RTC_AMD_SHARE_LOG2 pins one value for all.
     const uint32_t* d_tiles = nullptr;
-    if (share_log2 != 0u && !c->heavy_tiles.empty() && c->hdr.light_kind == RTC_LIGHT_POINT && !std::getenv("RTC_AMD_SHARE_LOG2") &&
+    if (c->spec_fn && c->spec_shares && !c->heavy_tiles.empty() && c->hdr.light_kind == RTC_LIGHT_POINT && !std::getenv("RTC_AMD_SHARE_LOG2") &&
         c->hdr.width <= 65532u && rows <= 262140u && rows > 0u) {
         if (!c->blocks_valid || c->blocks_for[0] != q.band_rows || c->blocks_for[1] != q.n_parts || c->blocks_for[2] != q.part) {
             const rtc_ctx_tiles T = {c->heavy_tiles.data(), c->heavy_w, c->heavy_h};

@@ -737,6 +737,24 @@ DI float quadratic_c(uint32_t kind, V3 o) {
 // tuple.rs:47-55
 DI V3 cross3(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 
+// triangle.rs:45-68 (Moeller-Trumbore as written there); t0..t2: the object's three `tri` records
+template <class F>
+DI void triangle_intersect(float4 t0, float4 t1, float4 t2, V3 o, V3 d, F&& f) {
+    const V3 p1 = v3(t0.x, t0.y, t0.z), e1 = v3(t1.x, t1.y, t1.z), e2 = v3(t2.x, t2.y, t2.z);
+    V3 dir_cross_e2 = cross3(d, e2);
+    float determinant = dot3(e1, dir_cross_e2);
+    if (!(fabsf(determinant) < 0.0000001f)) {
+        float fi = 1.0f / determinant;
+        V3 p1_to_origin = o - p1;
+        float u = fi * dot3(p1_to_origin, dir_cross_e2);
+        if (!(u < 0.0f || u > 1.0f)) {
+            V3 origin_cross_e1 = cross3(p1_to_origin, e1);
+            float v = fi * dot3(d, origin_cross_e1);
+            if (!(v < 0.0f || (u + v) > 1.0f)) f(fi * dot3(e2, origin_cross_e1));
+        }
+    }
+}
+
 // `tri` / `i`: the triangle records and this object's index (wave-uniform); only read for RTC_TRIANGLE.
 // LANE_IDX: `i` differs from lane to lane (the leaf-sharing tree walk): the triangle records come through vector loads.
 template <bool HITS_ONLY, bool LANE_IDX = false, class F>
@@ -822,22 +840,10 @@ DI void local_intersect_c(uint32_t bits, float min_y, float max_y, const float4*
             cz = o.z + t * d.z;
             if ((cx * cx + cz * cz) <= 1.0f + CLOSE_TO_ZERO) f(t);
         }
-    } else if (kind == RTC_TRIANGLE) {  // triangle.rs:45-68 (Moeller-Trumbore as written there)
+    } else if (kind == RTC_TRIANGLE) {
         const float4 t0 = LANE_IDX ? tri[3u * i] : load_uniform(tri, 3u * i), t1 = LANE_IDX ? tri[3u * i + 1u] : load_uniform(tri, 3u * i + 1u),
                      t2 = LANE_IDX ? tri[3u * i + 2u] : load_uniform(tri, 3u * i + 2u);
-        const V3 p1 = v3(t0.x, t0.y, t0.z), e1 = v3(t1.x, t1.y, t1.z), e2 = v3(t2.x, t2.y, t2.z);
-        V3 dir_cross_e2 = cross3(d, e2);
-        float determinant = dot3(e1, dir_cross_e2);
-        if (!(fabsf(determinant) < 0.0000001f)) {
-            float fi = 1.0f / determinant;
-            V3 p1_to_origin = o - p1;
-            float u = fi * dot3(p1_to_origin, dir_cross_e2);
-            if (!(u < 0.0f || u > 1.0f)) {
-                V3 origin_cross_e1 = cross3(p1_to_origin, e1);
-                float v = fi * dot3(d, origin_cross_e1);
-                if (!(v < 0.0f || (u + v) > 1.0f)) f(fi * dot3(e2, origin_cross_e1));
-            }
-        }
+        triangle_intersect(t0, t1, t2, o, d, f);
     } else if (kind == RTC_CONE) {  // cone.rs:52-57: sides (:89-141), then -- always -- caps (:156-175)
         float two_a = 2.0f * (d.x * d.x - d.y * d.y + d.z * d.z);
         float b = 2.0f * (o.x * d.x - o.y * d.y + o.z * d.z);
@@ -1039,10 +1045,13 @@ template <bool B>
 struct BoolConstant {
     static constexpr bool value = B;
 };
-// e2.w of a leaf entry, written by the host: (consecutive leaf entries from this one on, itself included) * 4 + (boxed
-// triangle leaves right after this one, at most 3) -- small whole numbers, exact as floats
+// e2.w of a leaf entry, written by the host (mark_leaf_runs): (consecutive leaf entries of the same group from this one
+// on, itself included) * 8 + (4 if they are a MESH run: boxed triangles of consecutive object indices that all share one
+// transform and one kind / flags word) + (boxed triangle leaves right after this one, at most 3) -- a small whole number,
+// exact as a float
 DI uint32_t trav_more(float w) { return (uint32_t)w & 3u; }
-DI uint32_t trav_run(float w) { return (uint32_t)w >> 2; }
+DI uint32_t trav_run(float w) { return (uint32_t)w >> 3; }
+DI bool trav_mesh_run(float w) { return ((uint32_t)w & 4u) != 0u; }
 
 // The tree walk of a kernel whose pixels are traced by 2^s adjacent lanes each (Counters::SHARE_LANES), for a ray that
 // all of a pixel's lanes share -- the pixel's primary and secondary rays, a point light's shadow ray.  One lane per
@@ -1055,8 +1064,13 @@ DI uint32_t trav_run(float w) { return (uint32_t)w >> 2; }
 // becomes every lane's pruning limit).  Each leaf is still visited exactly once per pixel, by exactly one lane; what
 // the callers compute from the visits is order-independent in the tree kernels (ties go by object index), so the
 // split cannot change an answer.
-template <class F, class G>
-DI void for_each_leaf_shared(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, const Counters& cnt, F&& body, G&& after_run) {
+// `on_tri(i, t)`: a triangle of a mesh run has its one intersection at distance t (what body(i) would have found).  The
+// triangles of a parsed mesh share their group's baked transform (group.rs:39-44), so the ray is taken into their object
+// space once per run -- the same operations on the same matrix as per leaf, hence the same bits -- from records that
+// arrive through scalar loads; per leaf a lane then needs its own entry (box + normal, for tri_precull) and, for the few
+// leaves that pass, the three triangle records.  The next entry is fetched while the current one is being tested.
+template <class F, class T, class G>
+DI void for_each_leaf_shared(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, const Counters& cnt, F&& body, T&& on_tri, G&& after_run) {
     uint32_t resume = 0;  // this lane ignores entries below `resume`
     const uint32_t stride = 1u << cnt.share_log2(), sub = cnt.sub();
     for (uint32_t k = 0; k < H.n_trav;) {
@@ -1074,14 +1088,36 @@ DI void for_each_leaf_shared(const SceneHdr& H, const SceneSoA& S, WorldRay& wr,
             }
             k = __any(inside) ? k + 1u : skip;
         } else {
-            const uint32_t run = trav_run(ep[2].w);  // wave-uniform, >= 1
+            const float w = ep[2].w;
+            const uint32_t run = trav_run(w);  // wave-uniform, >= 1
             if (__any(active)) {
-                for (uint32_t m = sub; active && m < run; m += stride) {
-                    const float4* ent = S.trav + (size_t)TRAV_STRIDE * (k + m);  // this lane's own entry
-                    const float4 b0 = ent[0], b1 = ent[1];
-                    bool visit = true;
-                    if (spec_has_tbox(H.has_tbox) && b1.w == TRAV_BOXED_LEAF_TAG) visit = !tri_precull(wr, b0, b1, ent[2]);
-                    if (visit) body(__float_as_uint(b0.w));
+                const float4* ent = S.trav + (size_t)TRAV_STRIDE * k;
+                if (spec_has_tbox(H.has_tbox) && trav_mesh_run(w)) {  // wave-uniform
+                    const uint32_t obj0 = __float_as_uint(r0.w);  // entry k + m is object obj0 + m
+                    const Obj ob = load_obj_static<true>(S, obj0);
+                    const V3 po = obj_point(ob, wr.o), pd = obj_vector(ob, wr.d);
+                    uint32_t m = sub;
+                    float4 b0 = ent[0], b1 = ent[1], b2 = ent[2];
+                    if (active && m < run) b0 = ent[TRAV_STRIDE * m], b1 = ent[TRAV_STRIDE * m + 1u], b2 = ent[TRAV_STRIDE * m + 2u];
+                    while (active && m < run) {
+                        const uint32_t mn = m + stride;
+                        float4 n0 = b0, n1 = b1, n2 = b2;
+                        if (mn < run) n0 = ent[TRAV_STRIDE * mn], n1 = ent[TRAV_STRIDE * mn + 1u], n2 = ent[TRAV_STRIDE * mn + 2u];
+                        if (!tri_precull(wr, b0, b1, b2)) {
+                            const uint32_t i = obj0 + m;
+                            const float4* tr = S.tri + (size_t)3u * i;
+                            triangle_intersect(tr[0], tr[1], tr[2], po, pd, [&](float t) { on_tri(i, t); });
+                        }
+                        b0 = n0, b1 = n1, b2 = n2;
+                        m = mn;
+                    }
+                } else {
+                    for (uint32_t m = sub; active && m < run; m += stride) {
+                        const float4 b0 = ent[TRAV_STRIDE * m], b1 = ent[TRAV_STRIDE * m + 1u];  // this lane's own entry
+                        bool visit = true;
+                        if (spec_has_tbox(H.has_tbox) && b1.w == TRAV_BOXED_LEAF_TAG) visit = !tri_precull(wr, b0, b1, ent[TRAV_STRIDE * m + 2u]);
+                        if (visit) body(__float_as_uint(b0.w));
+                    }
                 }
                 after_run();
             }
@@ -1206,7 +1242,18 @@ DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, const Count
     Hit best = {0.0f, -1};
     WorldRay wr = world_ray<NOBJ>(H, o, d);
     wr.limit = t_max;
-    if constexpr (NOBJ < 0 && SHARED && Counters::SHARE_LANES && SHARED_WALK && SHARED_WALK_HIT) {
+    // (a block of one lane per pixel -- RenderArgs::tiles mixes both kinds in one launch -- keeps the packet walk below,
+    // whose records arrive through scalar loads: wave-uniform choice)
+    if constexpr (NOBJ < 0 && SHARED && Counters::SHARE_LANES && SHARED_WALK && SHARED_WALK_HIT)
+      if (cnt.share_log2() != 0u) {
+        auto offer = [&](uint32_t i, float t) {
+            const bool better = best.obj < 0 || t < best.t || (t == best.t && (int)i < best.obj);
+            if (t >= 0.0f && better) {
+                best.t = t;
+                best.obj = (int)i;
+                wr.limit = (any_hit && t < t_max) ? -RTC_INF : fminf(wr.limit, t);
+            }
+        };
         for_each_leaf_shared(
             H, S, wr, cnt,
             [&](uint32_t i) {
@@ -1215,14 +1262,11 @@ DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, const Count
                 ob.bits = spec_bits(i, ob.bits);
                 V3 po = obj_point(ob, o);
                 V3 pd = obj_vector(ob, d);
-                local_intersect<true, true>(ob.bits, ob.min_y(), ob.max_y(), S.tri, i, po, pd, [&](float t) {
-                    const bool better = best.obj < 0 || t < best.t || (t == best.t && (int)i < best.obj);
-                    if (t >= 0.0f && better) {
-                        best.t = t;
-                        best.obj = (int)i;
-                        wr.limit = (any_hit && t < t_max) ? -RTC_INF : fminf(wr.limit, t);
-                    }
-                });
+                local_intersect<true, true>(ob.bits, ob.min_y(), ob.max_y(), S.tri, i, po, pd, [&](float t) { offer(i, t); });
+            },
+            [&](uint32_t i, float t) {
+                if (i < 32u && ((skip >> i) & 1u)) return;
+                offer(i, t);
             },
             [&]() {  // the minimum over the pixel's lanes, in the order the reference's stable sort gives: (t, object index)
                 for (uint32_t m = 1u; m < (1u << cnt.share_log2()); m <<= 1) {
@@ -1940,13 +1984,22 @@ DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int
     };
     using LaneIdx = BoolConstant<true>;
     using UniformIdx = BoolConstant<false>;
-    if constexpr (NOBJ < 0 && Counters::SHARE_LANES && SHARED_WALK && SHARED_WALK_N12) {
+    bool walked = false;
+    if constexpr (NOBJ < 0 && Counters::SHARE_LANES && SHARED_WALK && SHARED_WALK_N12)
+      if (cnt.share_log2() != 0u) {
+        walked = true;
         for_each_leaf_shared(
             H, S, wr, cnt,
             [&](uint32_t i) {
                 Obj ob = load_obj(S, i);
                 ob.bits = spec_bits(i, ob.bits);
                 per_object(i, ob, LaneIdx());
+            },
+            [&](uint32_t i, float t) {  // a triangle has one intersection: behind the origin it is an odd count
+                if (t < 0.0f) {
+                    if ((int)i == hit_obj) hit_inside = true;
+                    offer(t, (int)i);
+                }
             },
             [&]() {});
         for (uint32_t m = 1u; m < (1u << cnt.share_log2()); m <<= 1) {
@@ -1957,9 +2010,8 @@ DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int
             const int partner_inside = __shfl_xor((int)hit_inside, (int)m, 64);  // (every lane must take part: no short circuit)
             hit_inside = hit_inside || partner_inside != 0;
         }
-    } else {
-        for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) { per_object(i, load_obj_static<NOBJ <= 0>(S, i), UniformIdx()); });
-    }
+      }
+    if (!walked) for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) { per_object(i, load_obj_static<NOBJ <= 0>(S, i), UniformIdx()); });
     const float vacuum = 1.0f;  // REFRACTION_VACCUM, constants.rs:6
     n1 = c1 >= 0 ? S.mat_c[c1].y : vacuum;
     if (!hit_inside) {
