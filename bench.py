@@ -200,6 +200,17 @@ def main():
             extra_parts = max(0, min(6, int(round(g_ms / k_ms)) - 1))
         calib = {"render_ms_even_share": round(k_ms, 4), "gather_ms_even_share_unoverlapped": round(g_ms, 4)}
         if extra_parts > 0:
+            # the even split, timed the same way as the split `value` is measured with: so that the first run on real xGMI
+            # links can be read (is the (N + E)-way split what the calibration promised?)
+            fence()
+            drain()
+            t_even = time.perf_counter()
+            run(args.steps)
+            fence()
+            e_even = torch.tensor([time.perf_counter() - t_even], dtype=torch.float64, device=device)
+            dist.all_reduce(e_even, op=dist.ReduceOp.MAX)
+            calib["even_split_ms_per_step"] = round(float(e_even.item()) / args.steps * 1e3, 4)
+            drain()
             gather = BandGather(camera.height, camera.width, 3, torch.float32, device, rank, world_size, extra_parts=extra_parts)
             run = make_runner(gather)
             run(max(2, min(args.warmup, 3)))
@@ -291,6 +302,8 @@ def main():
             # `value` gathers the f32 Canvas rows (12 B / pixel) to rank 0 over xGMI: one link per peer, so the step is
             # max(render, rows_of_one_peer / link rate).  Render and transport separately:
             n_parts = world_size + extra_parts
+            if calib and "even_split_ms_per_step" in calib:
+                calib["even_split_value_Mrays_per_s"] = round(rays / (calib["even_split_ms_per_step"] * 1e-3) / 1e6, 2)
             line["multi_gpu"] = {"gather": "f32 Canvas rows to rank 0, double-buffered (frame i's gather overlaps frame i+1's render)",
                                  "split": "%d parts; rank 0 renders %d (its rows do not travel), each peer 1" % (n_parts, extra_parts + 1),
                                  "calibration": calib,

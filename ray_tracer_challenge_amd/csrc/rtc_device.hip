@@ -257,7 +257,9 @@ static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows) {
     if (const char* e = std::getenv("RTC_AMD_SHARE_LOG2"))
         if (e[0] >= '0' && e[0] <= '3' && !e[1]) return (uint32_t)(e[0] - '0');
     const uint64_t waves = ((uint64_t)hdr.width * rows + 63) / 64;
-    if (runs) return 3u;
+    // measured (tools/ab_env.py): here_be_dragons 1000 x 400 (6 k waves) 2.88 / 0.93 / 0.79 ms with 1 / 4 / 8 lanes per pixel in
+    // the mesh tiles; mesh 2048^2 (65 k waves) 5.3 / 4.2 / 5.9 ms; here_be_dragons 4000 x 1600 (100 k) 3.9 / 3.6 / 4.8 ms
+    if (runs) return waves <= 16384u ? 3u : 2u;
     uint32_t s = 0;
     while (s < 3u && (waves << s) < 24576u) s++;
     return s;
@@ -1210,11 +1212,12 @@ static void project_heavy_boxes(const std::vector<float>& boxes, const rtc_camer
 }
 
 // The block list of one partition (RenderArgs::tiles): the 16 x 16 tiles of the partition's compact rows, those a mesh
-// projects to first and cut into eight 8 x 4 blocks of 8 lanes per pixel, the others after them, whole, one lane per pixel.
-static void build_block_list(const rtc_ctx_tiles& T, uint32_t width, uint32_t height, uint32_t rows, const Partition& q, std::vector<uint32_t>* out) {
+// projects to first and cut into blocks of 2^mesh_share_log2 lanes per pixel (8 x 8 or 8 x 4 pixels), the others after
+// them, whole, one lane per pixel.
+static void build_block_list(const rtc_ctx_tiles& T, uint32_t width, uint32_t mesh_share_log2, uint32_t rows, const Partition& q, std::vector<uint32_t>* out) {
     out->clear();
     std::vector<uint32_t> light;
-    uint32_t hs = 3u;  // lanes per pixel (log2) in the mesh tiles; RTC_AMD_BLOCK_S=0..3: development
+    uint32_t hs = mesh_share_log2;  // lanes per pixel (log2) in the mesh tiles; RTC_AMD_BLOCK_S=0..3: development
     if (const char* e = std::getenv("RTC_AMD_BLOCK_S"))
         if (e[0] >= '0' && e[0] <= '3' && !e[1]) hs = (uint32_t)(e[0] - '0');
     const uint32_t hbw = 16u >> (hs >> 1), hbh = 16u >> ((hs + 1u) >> 1);
@@ -1232,7 +1235,6 @@ static void build_block_list(const rtc_ctx_tiles& T, uint32_t width, uint32_t he
             }
         }
     }
-    (void)height;
     out->insert(out->end(), light.begin(), light.end());
 }
 
@@ -1349,7 +1351,9 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         const std::string how = scene->n_groups ? "tree" : "tree,bvh";
         c->kernel_name = "render_kernel<" + how + ">";
         const int policy = specialise_policy();
-        if (policy == 1 || (policy == 2 && (uint64_t)hdr.width * hdr.height >= (1ull << 18))) {
+        // (worlds with divided meshes are compiled whatever the frame's size: the ahead-of-time walk has neither the
+        // triangle pre-culling specialisation nor the leaf-sharing lanes -- mesh 512 x 384: 7.9 ms)
+        if (policy == 1 || (policy == 2 && ((uint64_t)hdr.width * hdr.height >= (1ull << 18) || hdr.max_leaf_run >= 16u))) {
             // the traversal kernel compiled for this scene's light kind / jitter mode / pattern use and, when every object
             // shares one kind / flags word (a triangle mesh, a grid of spheres), for that word as well
             uint32_t first;
@@ -1472,7 +1476,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             const rtc_ctx_tiles T = {c->heavy_tiles.data(), c->heavy_w, c->heavy_h};
             // the previous list may still be read by a launch in flight
             HIP_TRY(hipDeviceSynchronize());
-            build_block_list(T, c->hdr.width, c->hdr.height, rows, q, &c->blocks_host);
+            build_block_list(T, c->hdr.width, share_log2, rows, q, &c->blocks_host);
             if (c->blocks_host.size() > c->blocks_cap) {
                 if (c->d_blocks) (void)hipFree(c->d_blocks);
                 c->d_blocks = nullptr;

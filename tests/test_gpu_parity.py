@@ -497,3 +497,40 @@ def test_lanes_sharing_a_pixel_change_nothing(name, size, kw, share, monkeypatch
     # (culled_shadow_rays may differ: the cull is decided per wave, and a wave now holds other pixels)
     assert r0.stats()["shaded_hits"] == st["shaded_hits"]
     r0.close()
+
+
+# ------------------------------------------------- leaf-sharing tree walk + block lists (worlds with divided meshes)
+@pytest.mark.parametrize("variant", ["default", "share0", "share1", "share2", "share3", "blocks_s0", "blocks_s1", "blocks_s3", "no_block_list"])
+@pytest.mark.parametrize("name,size", [("mesh", (230, 170)), ("here_be_dragons", (250, 100)), ("mesh", (64, 610))])
+def test_lanes_splitting_leaf_runs_change_nothing(name, size, variant, monkeypatch):
+    """Worlds whose GroupShapes hold long runs of leaves (the rings divide() leaves around a mesh): the 2^s lanes of a
+    pixel split every run between them (for_each_leaf_shared: nearest hit, point-light shadow ray, the n1/n2 container
+    walk), mesh runs take the ray into object space once, and the launch is a block list -- the tiles a mesh projects to
+    first and with more lanes per pixel than the rest.  None of it may change a pixel, the ray count or the shaded hits."""
+    from ray_tracer_challenge_amd.renderer import Renderer
+    world, camera, depth = getattr(scenes, name)(*size)
+    env = {"default": {}, "share0": {"RTC_AMD_SHARE_LOG2": "0"}, "share1": {"RTC_AMD_SHARE_LOG2": "1"}, "share2": {"RTC_AMD_SHARE_LOG2": "2"},
+           "share3": {"RTC_AMD_SHARE_LOG2": "3"}, "blocks_s0": {"RTC_AMD_BLOCK_S": "0"}, "blocks_s1": {"RTC_AMD_BLOCK_S": "1"},
+           "blocks_s3": {"RTC_AMD_BLOCK_S": "3"}, "no_block_list": {"RTC_AMD_BLOCK_LIST": "0"}}[variant]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r = Renderer(world, camera, device=0)
+    assert r.kernel_name.startswith("render_kernel_spec[tree"), r.kernel_name   # compiled for the scene whatever the size
+    img = r.render(depth).cpu().numpy()
+    st = r.stats()
+    exp, rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=8)
+    H.assert_images_equal(img, exp, "%s %s" % (name, variant))
+    assert st["rays"] == rays
+    # a band partition (the multi-GPU split) of the same frame: block lists are built per partition
+    parts = []
+    for p in range(3):
+        part = Renderer.partition(16, 3, p)
+        parts.append(r.render(depth, part=part).cpu().numpy())
+    got = np.zeros_like(img)
+    cursor = [0, 0, 0]
+    for b in range((camera.height + 15) // 16):
+        p, y0, y1 = b % 3, b * 16, min((b + 1) * 16, camera.height)
+        got[y0:y1] = parts[p][cursor[p]:cursor[p] + (y1 - y0)]
+        cursor[p] += y1 - y0
+    assert np.array_equal(got, img)
+    r.close()
