@@ -462,6 +462,18 @@ struct Camera {
         check(rtc_render(&scene, &c, reflection_recursion_depth, device, canvas.data.data(), &last_stats));
         return canvas;
     }
+    // the same frame split over several GPUs (rtc_render_ex: the image's 64-row bands dealt round-robin over `devices`)
+    Canvas render(World world, int16_t reflection_recursion_depth, const std::vector<int32_t>& devices) {
+        std::vector<rtc_object> objs;
+        std::vector<rtc_group> groups;
+        for (Shape& s : world.objects) flatten(s, objs, groups);
+        rtc_scene scene{(uint32_t)objs.size(), objs.data(), world.light ? &world.light->l : nullptr,
+                        (uint32_t)groups.size(), groups.data()};
+        rtc_opts opts{devices.data(), (uint32_t)devices.size(), 0u, 0, 0};
+        Canvas canvas(c.width, c.height);
+        check(rtc_render_ex(&scene, &c, reflection_recursion_depth, &opts, canvas.data.data(), &last_stats));
+        return canvas;
+    }
 };
 
 constexpr float PI = 3.14159265358979323846264338327950288f;  // std::f32::consts::PI
