@@ -1408,6 +1408,16 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         defs.push_back(share_def);
         defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
         if (reg_waves) defs.push_back(reg_waves);
+        // A point light has no sample loop to keep registers free for: cold state stays in VGPRs instead of being parked
+        // in LDS around intensity_at (C4 0.86 -> 0.77 ms), and in kernels of a few scale+translate objects the hit
+        // object's records are selected from the scalar loads the loops hold anyway instead of being gathered per lane
+        // (0.77 -> 0.74 ms; C2 13.9 -> 12.4 us).  Both cost registers that an area light's loop needs (C3 +6 %), and the
+        // pattern / rotated-object kernels spill without the parking (reflect_refract 1.21 -> 1.49 ms): left as they were.
+        if (hdr.light_kind == RTC_LIGHT_POINT && c->simple && !reg_waves) {
+            defs.push_back("-DRTC_SPEC_STASH=0");
+            if (n <= 4) defs.push_back("-DRTC_SPEC_SELECT=1");
+            defs.push_back("-DRTC_WAVES_PER_SIMD=6");
+        }
         rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
         if (jst != RTC_OK) {
             if ((jst = jit_failed(c, policy, jst)) != RTC_OK) return jst;

@@ -629,6 +629,16 @@ constexpr bool ANY_SPECULAR = RTC_SPEC_ANY_SPECULAR != 0;
 #else
 constexpr bool ANY_SPECULAR = true;
 #endif
+#if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_SELECT)
+constexpr bool SELECT_RECORDS = RTC_SPEC_SELECT != 0;
+#else
+constexpr bool SELECT_RECORDS = false;
+#endif
+#if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_STASH)
+constexpr bool USE_STASH = RTC_SPEC_STASH != 0;
+#else
+constexpr bool USE_STASH = true;
+#endif
 #if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_REG_LEVELS)
 constexpr int STACK_REG_LEVELS = RTC_SPEC_REG_LEVELS;
 #else
@@ -2055,6 +2065,30 @@ struct LaneStash {
     DI uint32_t getu(int k) const { return __float_as_uint(base[k * stride]); }
 };
 
+// The hit object's records for shading.  `ob` differs from lane to lane, so `S.geo[ob]` is a gather through the vector
+// memory path -- two dependent round trips per shade point (geometry for the normal, then the material).  In an
+// unrolled kernel of a few objects every record is a wave-uniform scalar load the intersection loops hold in SGPRs
+// anyway: take them all and keep the one whose index matches (-DRTC_SPEC_SELECT=1).
+template <int NOBJ>
+DI Obj select_obj(const SceneSoA& S, int ob) {
+    Obj r = load_obj_static<false>(S, 0u);
+#pragma unroll
+    for (uint32_t i = 1; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) {
+        const Obj t = load_obj_static<false>(S, i);
+        if (ob == (int)i) r = t;
+    }
+    return r;
+}
+template <int NOBJ>
+DI void select_material(const SceneSoA& S, int ob, float4& ma, float4& mb, float4& mc) {
+    ma = S.mat_a[0], mb = S.mat_b[0], mc = S.mat_c[0];
+#pragma unroll
+    for (uint32_t i = 1; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) {
+        const float4 a = S.mat_a[i], b = S.mat_b[i], c = S.mat_c[i];
+        if (ob == (int)i) ma = a, mb = b, mc = c;
+    }
+}
+
 // One suspended shade_hit (world.rs:62-86) waiting for a child colour.
 // Split in two so that the common frame -- a mirror-like hit waiting for its reflection only -- moves 6 dwords
 // instead of 13: the refraction half is written and read only when there is a refraction child.
@@ -2161,7 +2195,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
             bool inside;
             V3 over_point;
             {
-                Obj rec = load_obj(S, ob);
+                Obj rec = SELECT_RECORDS && NOBJ > 0 ? select_obj<NOBJ>(S, ob) : load_obj(S, ob);
                 V3 point = o + d * h.t;
                 V3 op = obj_point(rec, point);
                 n = obj_normal_to_world(rec, local_normal(rec.bits & SHAPE_KIND_MASK, rec.min_y(), rec.max_y(), S.tri + 3 * ob, op));
@@ -2172,7 +2206,12 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
 
             // shade_hit, world.rs:62-86
             cnt.shaded += cnt.lead();
-            // park everything the sampling loop does not touch
+            // park everything the sampling loop does not touch (a kernel compiled for a point light has no such loop --
+            // one shadow ray -- and keeps the state where it is: -DRTC_SPEC_STASH=0)
+            float li;
+            if constexpr (!USE_STASH) {
+                li = intensity_at<NOBJ, SIMPLE>(H, S, over_point, pixel, path, cnt);
+            } else {
             stash.put(0, o.x), stash.put(1, o.y), stash.put(2, o.z);
             stash.put(3, d.x), stash.put(4, d.y), stash.put(5, d.z);
             stash.put(6, n.x), stash.put(7, n.y), stash.put(8, n.z);
@@ -2181,7 +2220,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
             stash.putu(11, pixel);
             stash.putu(12, path | ((uint32_t)rem << 16) | ((uint32_t)sp << 20) | ((uint32_t)depth << 24));
             asm volatile("" ::: "memory");
-            float li = intensity_at<NOBJ, SIMPLE>(H, S, over_point, pixel, path, cnt);
+            li = intensity_at<NOBJ, SIMPLE>(H, S, over_point, pixel, path, cnt);
             asm volatile("" ::: "memory");
             o = v3(stash.get(0), stash.get(1), stash.get(2));
             d = v3(stash.get(3), stash.get(4), stash.get(5));
@@ -2197,12 +2236,18 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                 sp = (int)((w12 >> 20) & 0xfu);
                 depth = (int)(w12 >> 24);
             }
+            }
 
             V3 eye = -d;
             V3 reflectv = reflect3(d, inside ? -n : n);  // world.rs:221 uses the normal before the inside flip
             V3 point = o + d * h.t;
             V3 under_point = point - n * SELF_EPS;
-            float4 ma = S.mat_a[ob], mb = S.mat_b[ob], mc = S.mat_c[ob];
+            float4 ma, mb, mc;
+            if constexpr (SELECT_RECORDS && NOBJ > 0) {
+                select_material<NOBJ>(S, ob, ma, mb, mc);
+            } else {
+                ma = S.mat_a[ob], mb = S.mat_b[ob], mc = S.mat_c[ob];
+            }
             const float reflective = mb.w, transparency = mc.x;
             V3 material_color = v3(ma.x, ma.y, ma.z);
             if constexpr (!SIMPLE) {

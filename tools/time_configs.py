@@ -11,7 +11,9 @@ CASES = [("C1 soft_shadows 1000x400", "soft_shadows", (1000, 400)), ("C2 single_
          ("first_plane 4096x2048", "first_plane", (4096, 2048)), ("first_patterns 4096x2048", "first_patterns", (4096, 2048)),
          ("reflect_refract 4096x2048", "reflect_refract", (4096, 2048)), ("hexagons 4096x2048", "hexagons", (4096, 2048)),
          ("first_textures 4096x2048", "first_textures", (4096, 2048)), ("skybox 4096x2048", "skybox", (4096, 2048)),
-         ("grouped_grid 4096^2", "grouped_grid", (4096, 4096)), ("mesh 2048^2", "mesh", (2048, 2048))]
+         ("grouped_grid 4096^2", "grouped_grid", (4096, 4096)), ("mesh 2048^2", "mesh", (2048, 2048)),
+         ("mesh 512x384", "mesh", (512, 384)), ("here_be_dragons 1000x400 (17.9 k triangles)", "here_be_dragons", (1000, 400)),
+         ("here_be_dragons 4000x1600", "here_be_dragons", (4000, 1600))]
 for label, name, size in CASES:
     world, camera, depth = getattr(scenes, name)(*size)
     r = Renderer(world, camera, device=0); out = r.alloc()
