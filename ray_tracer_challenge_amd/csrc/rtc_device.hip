@@ -841,7 +841,8 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     hdr->all_cast = 1;
     for (uint32_t i = 0; i < n; i++)
         if (!scene->objects[i].casts_shadow) hdr->all_cast = 0;
-    hdr->cull_flags = (env_flag("RTC_AMD_LIGHT_CULL", true) ? CULL_ENABLED : 0u) | (env_flag("RTC_AMD_DARK", true) ? CULL_DARK : 0u);
+    hdr->cull_flags = (env_flag("RTC_AMD_LIGHT_CULL", true) ? CULL_ENABLED : 0u) | (env_flag("RTC_AMD_DARK", true) ? CULL_DARK : 0u) |
+                      (env_flag("RTC_AMD_FAST_SHADOW", true) ? CULL_FAST_SHADOW : 0u);
     hdr->uvrec_off = (uint32_t)soa->size();
     soa->insert(soa->end(), uvrec.begin(), uvrec.end());
     if (cam) {

@@ -504,12 +504,13 @@ struct SceneHdr {
     uint32_t gate_mask[8];
     // Light-cone culling switches (light_cull_mask), set by the host from RTC_AMD_LIGHT_CULL / RTC_AMD_DARK (default: both
     // on): bit 0 -- cull at all; bit 1 -- the `dark` shortcut (every sample blocked on the far side of a casting sphere),
-    // the one decision that asserts hits instead of removing tests.  Off, every shadow ray is tested against every
-    // object: the image and the ray counts must not change (tests/test_gpu_light_cull.py, whole frames).
+    // the one decision that asserts hits instead of removing tests; bit 2 -- shadow_fast (RTC_AMD_FAST_SHADOW), the
+    // margin-guarded decision of a sample without normalising its ray.  Off, every shadow ray is tested against every
+    // object the exact way: the image and the ray counts must not change (tests/test_gpu_fullsize.py, whole frames).
     uint32_t cull_flags;
     uint32_t max_leaf_run;  // the longest run of consecutive leaf entries in SceneSoA::trav (host: lanes per pixel, for_each_leaf_shared)
 };
-constexpr uint32_t CULL_ENABLED = 1u, CULL_DARK = 2u;
+constexpr uint32_t CULL_ENABLED = 1u, CULL_DARK = 2u, CULL_FAST_SHADOW = 4u;
 constexpr uint32_t RTC_MAX_GATES = 8;
 
 // Structure-of-arrays scene records in HBM: 4 float4 of geometry (64 B) and
@@ -1678,6 +1679,105 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p, bool& da
     return mask;
 }
 
+// ---- fast decision of an area-light shadow sample -------------------------------------------------------------------
+// World::is_shadowed (world.rs:104-119) answers a yes / no question, and for most samples the answer is far from close:
+// the ray passes well inside or well outside a sphere, well before or well beyond the light.  When every object still
+// in play for this shade point (light_cull_mask) is a shadow-casting sphere or plane of a scale+translate-only scene,
+// "the nearest hit is a caster closer than the light" is simply "SOME caster has its first intersection at a ray
+// parameter in [0, distance)", and that can be decided per caster from the UNNORMALISED vector v = sample - point:
+// with pd = t_inverse v, a = pd.pd, hb = pd.o, q = hb^2 - a c (a quarter of the discriminant, c the exact test's own
+// constant term) the roots along v are (-hb -+ sqrt q) / a, the light sits at parameter 1, so
+//     no hit      <=>  q < 0, or both numerators < 0
+//     blocked     <=>  the smallest non-negative numerator n satisfies n < a
+// -- no normalisation (an exact square root and three exact divisions per sample), no division, an approximate square
+// root.  The answer is only taken when every comparison holds with a RELATIVE margin of 1e-3 against the magnitudes
+// that went into it (the exact evaluation's own rounding, and this one's, are ~1e-6 of those same magnitudes: where
+// both are three orders away from a boundary they are on the same side of it); anything closer, any NaN, any
+// magnitude outside [1e-30, 1e30] is "uncertain" and the sample takes the exact path (is_shadowed_pre) as before.
+// RTC_AMD_FAST_SHADOW=0 switches it off; whole C3 frames with it on and off are compared value for value and count for
+// count (tests/test_gpu_fullsize.py), as are the boundary-hugging scenes of tests/test_gpu_light_cull.py.
+constexpr float FAST_MARGIN = 1e-3f;
+enum { SHADOW_LIT = 0, SHADOW_BLOCKED = 1, SHADOW_UNCERTAIN = 2 };
+// wave-uniform: may the samples of this shade point be decided by shadow_fast?
+template <int NOBJ, bool SIMPLE>
+DI bool shadow_fast_usable(const SceneHdr& H, const SceneSoA& S, uint32_t skip) {
+    if constexpr (!SIMPLE || NOBJ <= 0) return false;
+    if (!(H.cull_flags & CULL_FAST_SHADOW)) return false;
+    bool ok = true;
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) {
+        const uint32_t bits = spec_bits(i, __float_as_uint(S.geo[i].w)), kind = bits & SHAPE_KIND_MASK;
+        if (kind == SHAPE_NONE || ((skip >> i) & 1u)) continue;
+        if (!(bits & SHAPE_CASTS) || (kind != RTC_SPHERE && kind != RTC_PLANE)) ok = false;
+    }
+    return ok;
+}
+template <int NOBJ>
+DI int shadow_fast(const SceneSoA& S, const ShadowPre* pre, V3 v, uint32_t skip) {
+    bool blocked = false, uncertain = false;
+    const float vv = dot3(v, v);
+    if (!(vv >= 1e-30f && vv <= 1e30f)) return SHADOW_UNCERTAIN;
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) {
+        const float4 g = S.geo[i];
+        const uint32_t bits = spec_bits(i, __float_as_uint(g.w)), kind = bits & SHAPE_KIND_MASK;
+        if (kind == SHAPE_NONE || ((skip >> i) & 1u)) continue;  // wave-uniform
+        const V3 o = pre[i].o;
+        if (kind == RTC_SPHERE) {
+            const V3 pd = v3(g.x * v.x, g.y * v.y, g.z * v.z);
+            const float a = dot3(pd, pd), hb = dot3(pd, o), hb2 = hb * hb, ac = a * pre[i].c;
+            const float q = hb2 - ac;
+            if (!(a >= 1e-30f && a <= 1e30f) || !(fabsf(q) >= FAST_MARGIN * (hb2 + fabsf(ac)))) {
+                uncertain = true;
+                continue;
+            }
+            if (q < 0.0f) continue;  // the line misses the sphere
+            const float sq = __builtin_amdgcn_sqrtf(q), mag = fabsf(hb) + sq;
+            float n = -hb - sq;      // numerator of the first root; the second one if that lies behind the origin
+            if (!(fabsf(n) >= FAST_MARGIN * mag)) {
+                uncertain = true;
+                continue;
+            }
+            if (n < 0.0f) {
+                n = -hb + sq;
+                if (!(fabsf(n) >= FAST_MARGIN * mag)) {
+                    uncertain = true;
+                    continue;
+                }
+                if (n < 0.0f) continue;  // the sphere lies behind the shade point
+            }
+            if (!(fabsf(n - a) >= FAST_MARGIN * (n + a))) uncertain = true;  // the hit is about as far as the light
+            else if (n < a) blocked = true;
+        } else {  // RTC_PLANE (plane.rs:45-56): parallel if |d.y| < PLANE_EPS for the normalised direction d = pd / |v|
+            const float pdy = g.y * v.y, pdy2 = pdy * pdy, lim = PLANE_EPS * PLANE_EPS * vv;
+            if (!(fabsf(pdy2 - lim) >= FAST_MARGIN * (pdy2 + lim)) || !(fabsf(o.y) >= 1e-30f)) {
+                uncertain = true;
+                continue;
+            }
+            if (pdy2 < lim) continue;                                    // parallel: no intersection
+            if ((o.y > 0.0f) == (pdy > 0.0f)) continue;                  // t = -o.y / pd.y < 0: the plane lies behind
+            const float ay = fabsf(o.y), ap = fabsf(pdy);                // t = ay / ap against the light's parameter 1
+            if (!(fabsf(ay - ap) >= FAST_MARGIN * (ay + ap))) uncertain = true;
+            else if (ay < ap) blocked = true;
+        }
+    }
+    return blocked ? SHADOW_BLOCKED : uncertain ? SHADOW_UNCERTAIN : SHADOW_LIT;
+}
+// one sample of intensity_at's loop (unrolled kernels): the fast decision where it applies and is certain, else the exact one
+template <int NOBJ, bool SIMPLE>
+DI bool sample_blocked(const SceneHdr& H, const SceneSoA& S, const ShadowPre* pre, V3 lp, V3 p, Counters& cnt, uint32_t skip, bool fast) {
+    if constexpr (SIMPLE && NOBJ > 0) {
+        if (fast) {  // wave-uniform
+            const int r = shadow_fast<NOBJ>(S, pre, lp - p, skip);
+            if (r != SHADOW_UNCERTAIN) {
+                cnt.rays++;
+                return r == SHADOW_BLOCKED;
+            }
+        }
+    }
+    return is_shadowed_pre<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt, skip);
+}
+
 // Pinned jitter (DESIGN.md "Jitter"): counter-based hash keyed by (pixel, path code, cell, draw):
 // h = mix32(base + (2 cell + draw) * 0x85EBCA6B), one 32-bit mix per draw, mapped to the 23-bit grid of rand's
 // OpenClosed01 (rectangle_light.rs:46): ((h >> 9) + 1) * 2^-23 in (0, 1].
@@ -1732,6 +1832,7 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
         return 0.0f / H.cells_f;
     }
     if constexpr (PRE) shadow_prepare<NOBJ>(H, S, p, pre);
+    const bool fast = shadow_fast_usable<NOBJ, SIMPLE>(H, S, skip);  // wave-uniform
     // The cells of the light in the reference's order (v outer, u inner), this lane's share of them: cell = sub, sub +
     // 2^s, ...  `total` only ever holds a whole number of at most `cells` (< 2^24), so the order of the additions and
     // their split over lanes cannot change it.
@@ -1748,7 +1849,7 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
                 // corner + u_vec * (u + jitter1) + v_vec * (v + jitter2)
                 V3 lp = corner + uvec * ((float)u + j1) + vvec * ((float)v + j2);
                 bool blocked;
-                if constexpr (PRE) blocked = is_shadowed_pre<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt, skip);
+                if constexpr (PRE) blocked = sample_blocked<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt, skip, fast);
                 else blocked = is_shadowed<NOBJ>(H, S, lp, p, cnt, skip & 0x7fffffffu);
                 if (!blocked) total += 1.0f;
             }
@@ -1770,7 +1871,7 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
         // corner + u_vec * (u + jitter1) + v_vec * (v + jitter2)
         V3 lp = corner + uvec * ((float)u + j1) + vvec * ((float)v + j2);
         bool blocked;
-        if constexpr (PRE) blocked = is_shadowed_pre<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt, skip);
+        if constexpr (PRE) blocked = sample_blocked<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt, skip, fast);
         else blocked = is_shadowed<NOBJ>(H, S, lp, p, cnt, skip & 0x7fffffffu);
         if (!blocked) total += 1.0f;
         u += (int)stride;

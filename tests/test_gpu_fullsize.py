@@ -50,7 +50,7 @@ def _check_whole_frame(image, rays, world, camera, depth, what):
 @pytest.fixture
 def cull_env():
     """Sets / restores the light-cone culling switches (read by the library when a scene is set)."""
-    saved = {k: os.environ.get(k) for k in ("RTC_AMD_LIGHT_CULL", "RTC_AMD_DARK")}
+    saved = {k: os.environ.get(k) for k in ("RTC_AMD_LIGHT_CULL", "RTC_AMD_DARK", "RTC_AMD_FAST_SHADOW")}
 
     def set_(**kw):
         for k, v in kw.items():
@@ -118,30 +118,36 @@ def test_c3_constant_jitter_whole_frame(torch):
 
 @pytest.mark.parametrize("config", ["C3 hashed", "C3 constant 0.5", "C1 hashed", "C1 constant 0.5"])
 def test_light_cone_cull_changes_nothing_whole_frame(torch, cull_env, config):
-    """The cull answers ~79 % of C3's shadow rays without an object test (world.rs:104-119, rectangle_light.rs:76-88 are
-    what it must preserve).  Whole frames with it on, with it off, and with only the `dark` rule off: same image, same
-    rays, same shaded hits -- and with it off no ray may be counted as culled."""
+    """The cull answers ~79 % of C3's shadow rays without an object test, and the margin-guarded fast decision (shadow_fast)
+    most of the rest without normalising the ray (world.rs:104-119, rectangle_light.rs:76-88 are what both must
+    preserve).  Whole frames with everything on, everything off, and each shortcut off alone: same image, same rays,
+    same shaded hits -- and with the cull off no ray may be counted as culled."""
     size = (4096, 4096) if config.startswith("C3") else (1000, 400)
     jitter = ("hashed", scenes.DEFAULT_SEED) if config.endswith("hashed") else ("constant", 0.5)
     world, camera, depth = scenes.soft_shadows(*size, jitter=jitter)
     frames = {}
-    for name, env in (("on", dict(RTC_AMD_LIGHT_CULL=None, RTC_AMD_DARK=None)), ("off", dict(RTC_AMD_LIGHT_CULL="0", RTC_AMD_DARK=None)),
-                      ("no_dark", dict(RTC_AMD_LIGHT_CULL=None, RTC_AMD_DARK="0"))):
+    for name, env in (("on", dict(RTC_AMD_LIGHT_CULL=None, RTC_AMD_DARK=None, RTC_AMD_FAST_SHADOW=None)),
+                      ("off", dict(RTC_AMD_LIGHT_CULL="0", RTC_AMD_DARK=None, RTC_AMD_FAST_SHADOW="0")),
+                      ("no_dark", dict(RTC_AMD_LIGHT_CULL=None, RTC_AMD_DARK="0", RTC_AMD_FAST_SHADOW=None)),
+                      ("no_fast", dict(RTC_AMD_LIGHT_CULL=None, RTC_AMD_DARK=None, RTC_AMD_FAST_SHADOW="0")),
+                      ("fast_only", dict(RTC_AMD_LIGHT_CULL="0", RTC_AMD_DARK=None, RTC_AMD_FAST_SHADOW=None))):
         cull_env(**env)
         r = _renderer(world, camera)
         img = r.render(depth).cpu().numpy()
         frames[name] = (img, r.stats(), r.kernel_name)
         r.close()
-    on, off, no_dark = frames["on"], frames["off"], frames["no_dark"]
-    assert on[2] == off[2] == no_dark[2]  # the same kernel: the switches are run-time data
-    for other, what in ((off, "cull off"), (no_dark, "dark off")):
+    on, off, no_dark, no_fast, fast_only = (frames[k] for k in ("on", "off", "no_dark", "no_fast", "fast_only"))
+    assert on[2] == off[2] == no_dark[2] == no_fast[2]  # the same kernel: the switches are run-time data
+    for other, what in ((off, "every shortcut off"), (no_dark, "dark off"), (no_fast, "fast sample decision off"),
+                        (fast_only, "cull off, fast sample decision on")):
         assert np.array_equal(on[0], other[0]), (config, what, int((on[0] != other[0]).sum()))
         for key in ("rays", "shaded_hits", "pixels"):
             assert on[1][key] == other[1][key], (config, what, key)
     assert off[1]["culled_shadow_rays"] == 0 and on[1]["culled_shadow_rays"] > 0
     assert no_dark[1]["culled_shadow_rays"] <= on[1]["culled_shadow_rays"]
-    print("\n%s: kernel ms cull on %.3f, dark off %.3f, cull off %.3f; %d of %d rays answered by the cull"
-          % (config, on[1]["kernel_ms"], no_dark[1]["kernel_ms"], off[1]["kernel_ms"], on[1]["culled_shadow_rays"], on[1]["rays"]))
+    print("\n%s: kernel ms all shortcuts %.3f, dark off %.3f, fast sample decision off %.3f, cull off (fast on) %.3f, all off %.3f; "
+          "%d of %d rays answered by the cull" % (config, on[1]["kernel_ms"], no_dark[1]["kernel_ms"], no_fast[1]["kernel_ms"],
+                                                    fast_only[1]["kernel_ms"], off[1]["kernel_ms"], on[1]["culled_shadow_rays"], on[1]["rays"]))
 
 
 def test_c2_single_sphere_1024_full_image(torch):
