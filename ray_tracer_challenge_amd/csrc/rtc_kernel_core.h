@@ -1724,30 +1724,19 @@ DI int shadow_fast(const SceneSoA& S, const ShadowPre* pre, V3 v, uint32_t skip)
         if (kind == SHAPE_NONE || ((skip >> i) & 1u)) continue;  // wave-uniform
         const V3 o = pre[i].o;
         if (kind == RTC_SPHERE) {
+            // straight-line code: every quantity is formed, the verdicts are combined at the end (the branches this
+            // replaces cost more than the few operations they skipped)
             const V3 pd = v3(g.x * v.x, g.y * v.y, g.z * v.z);
             const float a = dot3(pd, pd), hb = dot3(pd, o), hb2 = hb * hb, ac = a * pre[i].c;
             const float q = hb2 - ac;
-            if (!(a >= 1e-30f && a <= 1e30f) || !(fabsf(q) >= FAST_MARGIN * (hb2 + fabsf(ac)))) {
-                uncertain = true;
-                continue;
-            }
-            if (q < 0.0f) continue;  // the line misses the sphere
-            const float sq = __builtin_amdgcn_sqrtf(q), mag = fabsf(hb) + sq;
-            float n = -hb - sq;      // numerator of the first root; the second one if that lies behind the origin
-            if (!(fabsf(n) >= FAST_MARGIN * mag)) {
-                uncertain = true;
-                continue;
-            }
-            if (n < 0.0f) {
-                n = -hb + sq;
-                if (!(fabsf(n) >= FAST_MARGIN * mag)) {
-                    uncertain = true;
-                    continue;
-                }
-                if (n < 0.0f) continue;  // the sphere lies behind the shade point
-            }
-            if (!(fabsf(n - a) >= FAST_MARGIN * (n + a))) uncertain = true;  // the hit is about as far as the light
-            else if (n < a) blocked = true;
+            const bool sure_q = a >= 1e-30f && a <= 1e30f && fabsf(q) >= FAST_MARGIN * (hb2 + fabsf(ac));  // NaN: false
+            const float sq = __builtin_amdgcn_sqrtf(fmaxf(q, 0.0f)), tol = FAST_MARGIN * (fabsf(hb) + sq);
+            const float n1 = -hb - sq, n2 = -hb + sq;  // numerators of the two roots, n1 <= n2
+            const float n = n1 >= 0.0f ? n1 : n2;      // the first intersection at a parameter >= 0, if n >= 0
+            const bool sure_n = fabsf(n1) >= tol && fabsf(n2) >= tol && fabsf(n - a) >= FAST_MARGIN * (fabsf(n) + a);
+            const bool misses = q < 0.0f || n < 0.0f;  // the line misses the sphere, or the sphere lies behind
+            if (!sure_q || (!(q < 0.0f) && !sure_n)) uncertain = true;
+            else if (!misses && n < a) blocked = true;
         } else {  // RTC_PLANE (plane.rs:45-56): parallel if |d.y| < PLANE_EPS for the normalised direction d = pd / |v|
             const float pdy = g.y * v.y, pdy2 = pdy * pdy, lim = PLANE_EPS * PLANE_EPS * vv;
             if (!(fabsf(pdy2 - lim) >= FAST_MARGIN * (pdy2 + lim)) || !(fabsf(o.y) >= 1e-30f)) {
