@@ -727,6 +727,7 @@ DI V3 obj_vector(const Obj& b, V3 v) {
 }
 // normal_to_world (shape.rs:72-146): transpose(t_inverse) * n, w := 0, normalise
 DI V3 obj_normal_to_world(const Obj& b, V3 n) {
+    if (b.bits & SHAPE_DIAG) return norm3(v3(b.geo.x * n.x, b.geo.y * n.y, b.geo.z * n.z));  // the other terms are +-0 (see obj_point)
     V3 w = {b.geo.x * n.x + b.off1.x * n.y + b.off2.x * n.z, b.off0.x * n.x + b.geo.y * n.y + b.off2.y * n.z,
             b.off0.y * n.x + b.off1.y * n.y + b.geo.z * n.z};
     return norm3(w);
@@ -2159,23 +2160,40 @@ struct LaneStash {
 // memory path -- two dependent round trips per shade point (geometry for the normal, then the material).  In an
 // unrolled kernel of a few objects every record is a wave-uniform scalar load the intersection loops hold in SGPRs
 // anyway: take them all and keep the one whose index matches (-DRTC_SPEC_SELECT=1).
+// (The values pass through readfirstlane -- a no-op for a scalar-loaded value -- because the compiler otherwise turns
+// "select between two loaded values" back into "load from a selected address", i.e. into the gather this replaces.)
+DI float uniform_value(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+DI float4 uniform_value(float4 x) { return make_float4(uniform_value(x.x), uniform_value(x.y), uniform_value(x.z), uniform_value(x.w)); }
+DI float4 pick(bool mine, float4 a, float4 b) { return make_float4(mine ? a.x : b.x, mine ? a.y : b.y, mine ? a.z : b.z, mine ? a.w : b.w); }
 template <int NOBJ>
 DI Obj select_obj(const SceneSoA& S, int ob) {
-    Obj r = load_obj_static<false>(S, 0u);
+    Obj r;
+    r.geo = r.off0 = r.off1 = r.off2 = r.trn = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    r.bits = 0u;
 #pragma unroll
-    for (uint32_t i = 1; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) {
+    for (uint32_t i = 0; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) {
         const Obj t = load_obj_static<false>(S, i);
-        if (ob == (int)i) r = t;
+        const bool mine = ob == (int)i;
+        r.geo = pick(mine, uniform_value(t.geo), r.geo);
+        r.trn = pick(mine, uniform_value(t.trn), r.trn);
+        if (mine) r.bits = t.bits;
+        if (!(t.bits & SHAPE_DIAG) || (t.bits & SHAPE_KIND_MASK) == RTC_CYLINDER || (t.bits & SHAPE_KIND_MASK) == RTC_CONE) {  // compile-time in these kernels
+            r.off0 = pick(mine, uniform_value(t.off0), r.off0);
+            r.off1 = pick(mine, uniform_value(t.off1), r.off1);
+            r.off2 = pick(mine, uniform_value(t.off2), r.off2);
+        }
     }
     return r;
 }
 template <int NOBJ>
 DI void select_material(const SceneSoA& S, int ob, float4& ma, float4& mb, float4& mc) {
-    ma = S.mat_a[0], mb = S.mat_b[0], mc = S.mat_c[0];
+    ma = mb = mc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-    for (uint32_t i = 1; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) {
-        const float4 a = S.mat_a[i], b = S.mat_b[i], c = S.mat_c[i];
-        if (ob == (int)i) ma = a, mb = b, mc = c;
+    for (uint32_t i = 0; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) {
+        const bool mine = ob == (int)i;
+        ma = pick(mine, uniform_value(S.mat_a[i]), ma);
+        mb = pick(mine, uniform_value(S.mat_b[i]), mb);
+        mc = pick(mine, uniform_value(S.mat_c[i]), mc);
     }
 }
 
