@@ -1324,7 +1324,16 @@ DI bool is_shadowed(const SceneHdr& H, const SceneSoA& S, V3 light_position, V3 
     cnt.rays += SHARED ? cnt.lead() : 1u;
     Hit h = nearest_hit<NOBJ, SHARED>(H, S, p, direction, cnt, distance, H.all_cast != 0u, skip);
     if (h.obj < 0) return false;
-    bool casts = (__float_as_uint(S.geo[h.obj].w) & SHAPE_CASTS) != 0;
+    bool casts;
+    if constexpr (NOBJ > 0) {  // the flags of a few objects as one wave-uniform mask (a constant in a scene-compiled kernel) instead of a gather
+        uint32_t casters = 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++)
+            if (spec_bits(i, __float_as_uint(S.geo[i].w)) & SHAPE_CASTS) casters |= 1u << i;
+        casts = ((casters >> h.obj) & 1u) != 0u;
+    } else {
+        casts = (__float_as_uint(S.geo[h.obj].w) & SHAPE_CASTS) != 0;
+    }
     return casts && h.t < distance;
 }
 
@@ -2033,6 +2042,47 @@ DI V3 phong(const SceneHdr& H, V3 material_color, float4 ma, float4 mb, V3 p, V3
     return ambient + (diffuse + specular) * light_intensity;
 }
 
+// The hit object's records for shading.  `ob` differs from lane to lane, so `S.geo[ob]` is a gather through the vector
+// memory path -- two dependent round trips per shade point (geometry for the normal, then the material).  In an
+// unrolled kernel of a few objects every record is a wave-uniform scalar load the intersection loops hold in SGPRs
+// anyway: take them all and keep the one whose index matches (-DRTC_SPEC_SELECT=1).
+// (The values pass through readfirstlane -- a no-op for a scalar-loaded value -- because the compiler otherwise turns
+// "select between two loaded values" back into "load from a selected address", i.e. into the gather this replaces.)
+DI float uniform_value(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+DI float4 uniform_value(float4 x) { return make_float4(uniform_value(x.x), uniform_value(x.y), uniform_value(x.z), uniform_value(x.w)); }
+DI float4 pick(bool mine, float4 a, float4 b) { return make_float4(mine ? a.x : b.x, mine ? a.y : b.y, mine ? a.z : b.z, mine ? a.w : b.w); }
+template <int NOBJ>
+DI Obj select_obj(const SceneSoA& S, int ob) {
+    Obj r;
+    r.geo = r.off0 = r.off1 = r.off2 = r.trn = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    r.bits = 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) {
+        const Obj t = load_obj_static<false>(S, i);
+        const bool mine = ob == (int)i;
+        r.geo = pick(mine, uniform_value(t.geo), r.geo);
+        r.trn = pick(mine, uniform_value(t.trn), r.trn);
+        if (mine) r.bits = t.bits;
+        if (!(t.bits & SHAPE_DIAG) || (t.bits & SHAPE_KIND_MASK) == RTC_CYLINDER || (t.bits & SHAPE_KIND_MASK) == RTC_CONE) {  // compile-time in these kernels
+            r.off0 = pick(mine, uniform_value(t.off0), r.off0);
+            r.off1 = pick(mine, uniform_value(t.off1), r.off1);
+            r.off2 = pick(mine, uniform_value(t.off2), r.off2);
+        }
+    }
+    return r;
+}
+template <int NOBJ>
+DI void select_material(const SceneSoA& S, int ob, float4& ma, float4& mb, float4& mc) {
+    ma = mb = mc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) {
+        const bool mine = ob == (int)i;
+        ma = pick(mine, uniform_value(S.mat_a[i]), ma);
+        mb = pick(mine, uniform_value(S.mat_b[i]), mb);
+        mc = pick(mine, uniform_value(S.mat_c[i]), mc);
+    }
+}
+
 // n1/n2 of precompute_values (world.rs:235-263) without the sorted list.
 // Every intersection listed before the hit has t < 0 (the hit is the first
 // non-negative minimum of a stably sorted list).  Walking those toggles each
@@ -2114,11 +2164,21 @@ DI void refraction_indices(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int
       }
     if (!walked) for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) { per_object(i, load_obj_static<NOBJ <= 0>(S, i), UniformIdx()); });
     const float vacuum = 1.0f;  // REFRACTION_VACCUM, constants.rs:6
-    n1 = c1 >= 0 ? S.mat_c[c1].y : vacuum;
+    auto index_of = [&](int c) {  // Material.refractive_index of object c
+        if constexpr (SELECT_RECORDS && NOBJ > 0) {
+            float r = 0.0f;
+#pragma unroll
+            for (uint32_t i = 0; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) r = c == (int)i ? uniform_value(S.mat_c[i].y) : r;
+            return r;
+        } else {
+            return S.mat_c[c].y;
+        }
+    };
+    n1 = c1 >= 0 ? index_of(c1) : vacuum;
     if (!hit_inside) {
-        n2 = S.mat_c[hit_obj].y;  // entering: the hit object becomes the innermost container
+        n2 = index_of(hit_obj);  // entering: the hit object becomes the innermost container
     } else if (c1 == hit_obj) {
-        n2 = c2 >= 0 ? S.mat_c[c2].y : vacuum;
+        n2 = c2 >= 0 ? index_of(c2) : vacuum;
     } else {
         n2 = n1;
     }
@@ -2155,47 +2215,6 @@ struct LaneStash {
     DI float get(int k) const { return base[k * stride]; }
     DI uint32_t getu(int k) const { return __float_as_uint(base[k * stride]); }
 };
-
-// The hit object's records for shading.  `ob` differs from lane to lane, so `S.geo[ob]` is a gather through the vector
-// memory path -- two dependent round trips per shade point (geometry for the normal, then the material).  In an
-// unrolled kernel of a few objects every record is a wave-uniform scalar load the intersection loops hold in SGPRs
-// anyway: take them all and keep the one whose index matches (-DRTC_SPEC_SELECT=1).
-// (The values pass through readfirstlane -- a no-op for a scalar-loaded value -- because the compiler otherwise turns
-// "select between two loaded values" back into "load from a selected address", i.e. into the gather this replaces.)
-DI float uniform_value(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
-DI float4 uniform_value(float4 x) { return make_float4(uniform_value(x.x), uniform_value(x.y), uniform_value(x.z), uniform_value(x.w)); }
-DI float4 pick(bool mine, float4 a, float4 b) { return make_float4(mine ? a.x : b.x, mine ? a.y : b.y, mine ? a.z : b.z, mine ? a.w : b.w); }
-template <int NOBJ>
-DI Obj select_obj(const SceneSoA& S, int ob) {
-    Obj r;
-    r.geo = r.off0 = r.off1 = r.off2 = r.trn = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    r.bits = 0u;
-#pragma unroll
-    for (uint32_t i = 0; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) {
-        const Obj t = load_obj_static<false>(S, i);
-        const bool mine = ob == (int)i;
-        r.geo = pick(mine, uniform_value(t.geo), r.geo);
-        r.trn = pick(mine, uniform_value(t.trn), r.trn);
-        if (mine) r.bits = t.bits;
-        if (!(t.bits & SHAPE_DIAG) || (t.bits & SHAPE_KIND_MASK) == RTC_CYLINDER || (t.bits & SHAPE_KIND_MASK) == RTC_CONE) {  // compile-time in these kernels
-            r.off0 = pick(mine, uniform_value(t.off0), r.off0);
-            r.off1 = pick(mine, uniform_value(t.off1), r.off1);
-            r.off2 = pick(mine, uniform_value(t.off2), r.off2);
-        }
-    }
-    return r;
-}
-template <int NOBJ>
-DI void select_material(const SceneSoA& S, int ob, float4& ma, float4& mb, float4& mc) {
-    ma = mb = mc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-    for (uint32_t i = 0; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) {
-        const bool mine = ob == (int)i;
-        ma = pick(mine, uniform_value(S.mat_a[i]), ma);
-        mb = pick(mine, uniform_value(S.mat_b[i]), mb);
-        mc = pick(mine, uniform_value(S.mat_c[i]), mc);
-    }
-}
 
 // One suspended shade_hit (world.rs:62-86) waiting for a child colour.
 // Split in two so that the common frame -- a mirror-like hit waiting for its reflection only -- moves 6 dwords
