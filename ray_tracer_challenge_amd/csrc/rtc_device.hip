@@ -1412,11 +1412,11 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         // A point light has no sample loop to keep registers free for: cold state stays in VGPRs instead of being parked
         // in LDS around intensity_at (C4 0.86 -> 0.77 ms), and in kernels of a few scale+translate objects the hit
         // object's records are selected from the scalar loads the loops hold anyway instead of being gathered per lane
-        // (0.77 -> 0.74 ms; C2 13.9 -> 12.4 us).  Both cost registers that an area light's loop needs (C3 +6 %), and the
+        // (C4 0.77 -> 0.68 ms; C2 13.9 -> 12.4 us).  Both cost registers that an area light's loop needs (C3 +6 %), and the
         // pattern / rotated-object kernels spill without the parking (reflect_refract 1.21 -> 1.49 ms): left as they were.
         if (hdr.light_kind == RTC_LIGHT_POINT && c->simple && !reg_waves) {
             defs.push_back("-DRTC_SPEC_STASH=0");
-            if (n <= 4) defs.push_back("-DRTC_SPEC_SELECT=1");
+            if (n <= 2) defs.push_back("-DRTC_SPEC_SELECT=1");  // (4 - 6 objects: the selects cost more than the gathers, +13 ... +30 %)
             defs.push_back("-DRTC_WAVES_PER_SIMD=6");
         }
         rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
