@@ -640,6 +640,11 @@ constexpr bool USE_STASH = RTC_SPEC_STASH != 0;
 #else
 constexpr bool USE_STASH = true;
 #endif
+#if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_LDS_FRAMES)
+constexpr int LDS_FRAME_LEVELS = RTC_SPEC_LDS_FRAMES;
+#else
+constexpr int LDS_FRAME_LEVELS = 0;
+#endif
 #if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_REG_LEVELS)
 constexpr int STACK_REG_LEVELS = RTC_SPEC_REG_LEVELS;
 #else
@@ -2207,6 +2212,8 @@ DI float schlick(V3 eye, V3 n, float n1, float n2) {
 // the 100-sample loop and no scratch (HBM-side) traffic; slot k of lane t lives at lds[k*stride + t],
 // so a wave's accesses are consecutive dwords (conflict-free).
 constexpr int STASH_SLOTS = 13;
+constexpr int FRAME_LDS_SLOT0 = USE_STASH ? STASH_SLOTS : 0;                  // recursion frames kept in LDS come after the parking slots
+constexpr int LDS_SLOTS = FRAME_LDS_SLOT0 + 6 * LDS_FRAME_LEVELS > 0 ? FRAME_LDS_SLOT0 + 6 * LDS_FRAME_LEVELS : 1;
 struct LaneStash {
     float* base;
     uint32_t stride;
@@ -2251,16 +2258,27 @@ struct FrameMem {
     Frame f[M > 0 ? M : 1];
     FrameRefr r[M > 0 ? M : 1];
 };
+// A third home for the reflection half of a frame (6 dwords): the workgroup's LDS, for the first LDS_FRAME_LEVELS levels
+// (-DRTC_SPEC_LDS_FRAMES).  A point-light kernel that no longer parks state there (RTC_SPEC_STASH=0) has the LDS free:
+// five levels are 30 dwords per lane, 30 KB per workgroup, five workgroups per CU -- and the mirror floor of the
+// glass-and-mirror scene, whose frames are reflection-only, stops writing its recursion to memory.
 struct FrameStack {
-    static constexpr int R = FrameRegs::R, M = FrameMem::M;
+    static constexpr int R = FrameRegs::R, M = FrameMem::M, L = LDS_FRAME_LEVELS;
     FrameRegs& reg;
     FrameMem& mem;
+    LaneStash lds;  // slots FRAME_LDS_SLOT0 + 6 * level + k of this lane
+    DI bool in_lds(int sp) const { return L > 0 && sp >= R && sp < R + L; }
     DI void put(int sp, const Frame& f) const {
 #pragma unroll
         for (int u = 0; u < R; u++)
             if (__any(sp == u)) {  // wave-uniform: some lane is at this level
                 if (sp == u) reg.f[u] = f;
             }
+        if (in_lds(sp)) {
+            const int b = FRAME_LDS_SLOT0 + 6 * (sp - R);
+            lds.put(b, f.acc.x), lds.put(b + 1, f.acc.y), lds.put(b + 2, f.acc.z), lds.put(b + 3, f.reflective), lds.put(b + 4, f.R), lds.putu(b + 5, f.flags);
+            return;
+        }
         if (M > 0 && sp >= R) mem.f[sp - R] = f;
     }
     DI void put_refr(int sp, const FrameRefr& f) const {
@@ -2278,6 +2296,12 @@ struct FrameStack {
             if (__any(sp == u)) {
                 if (sp == u) f = reg.f[u];
             }
+        if (in_lds(sp)) {
+            const int b = FRAME_LDS_SLOT0 + 6 * (sp - R);
+            f.acc = v3(lds.get(b), lds.get(b + 1), lds.get(b + 2));
+            f.reflective = lds.get(b + 3), f.R = lds.get(b + 4), f.flags = lds.getu(b + 5);
+            return f;
+        }
         if (M > 0 && sp >= R) f = mem.f[sp - R];
         return f;
     }
@@ -2302,7 +2326,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                const LaneStash stash) {
     FrameRegs stack_regs;
     FrameMem stack_mem;
-    const FrameStack stack = {stack_regs, stack_mem};
+    const FrameStack stack = {stack_regs, stack_mem, stash};
     int sp = 0;
     int rem = depth;
     uint32_t path = 1;
@@ -2521,7 +2545,7 @@ DI void render_body(const RenderArgs& A) {
     const uint32_t x = bx0 + ((wave & 1u) << tw_log2) + (q & ((1u << tw_log2) - 1u));
     const uint32_t yl = by0 + ((wave >> 1) << th_log2) + (q >> tw_log2);
     Counters cnt = {0u, 0u, sl};
-    __shared__ float stash_lds[STASH_SLOTS * 256];
+    __shared__ float stash_lds[LDS_SLOTS * 256];
     const LaneStash stash = {stash_lds + threadIdx.x, 256u};
     if (x < H.width && yl < A.rows) {
         // compact local row -> global row of the image
