@@ -886,6 +886,7 @@ struct rtc_ctx {
     uint32_t* d_ppm_bits = nullptr;
     size_t ppm_rows_cap = 0, ppm_bits_cap = 0;
     bool spec_shares = false;         // spec_fn was compiled with -DRTC_SPEC_SHARE=1
+    bool spec_blocks_y = false;       // ... with -DRTC_SPEC_BLOCKS_Y=1 (several blocks per workgroup)
     hipFunction_t spec_fn = nullptr;  // scene-specialised kernel (hiprtc), or null: ahead-of-time kernels
     std::string kernel_name;          // what rtc_ctx_render launches, for rtc_ctx_kernel_name()
     // Block list of the current scene (RenderArgs::tiles): which 16 x 16 pixel tiles of the image a mesh projects to
@@ -897,6 +898,7 @@ struct rtc_ctx {
     size_t blocks_cap = 0;
     uint32_t blocks_for[3] = {0u, 0u, 0u};  // band_rows, n_parts, part
     bool blocks_valid = false;
+    float scene_box_coverage = 1.0f;  // share of the image the scene's box projects to (1: unknown / all of it)
     std::string kernel_id;            // rtc_ctx_kernel_id(): names the code object (source + options + compiler), not the scene
     std::string jit_note;             // why spec_fn is null although the policy wanted one (rtc_ctx_jit_status)
     // the scene as last uploaded: an identical one (rtc_render_ex called again for the next frame) is not uploaded twice
@@ -1315,11 +1317,25 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     c->texels_host = texels;
     c->blocks_valid = false;
     project_heavy_boxes(heavy_boxes, camera, &c->heavy_tiles, &c->heavy_w, &c->heavy_h);
+
     // which kernel will render this scene
     c->spec_fn = nullptr;
     // sample-parallel rendering (render_body): compiled in when this frame is small enough to want it
     c->spec_shares = choose_share_log2(hdr, hdr.height) != 0u;
+    // several blocks per workgroup (render_body) where most workgroups see nothing but the sky: the scene's box projects to
+    // less than a quarter of the image
+    c->scene_box_coverage = 1.0f;
+    if (hdr.has_scene_box && camera && env_flag("RTC_AMD_BLOCK_LIST", true)) {
+        std::vector<uint8_t> covered;
+        uint32_t tw = 0, th = 0;
+        project_heavy_boxes(std::vector<float>(hdr.scene_box, hdr.scene_box + 6), camera, &covered, &tw, &th);
+        size_t n_cov = 0;
+        for (uint8_t b : covered) n_cov += b;
+        if (!covered.empty()) c->scene_box_coverage = (float)n_cov / (float)covered.size();
+    }
+    c->spec_blocks_y = c->scene_box_coverage < 0.25f || std::getenv("RTC_AMD_BLOCKS_Y") != nullptr;
     const std::string share_def = std::string("-DRTC_SPEC_SHARE=") + (c->spec_shares ? "1" : "0");
+    const std::string blocks_def = std::string("-DRTC_SPEC_BLOCKS_Y=") + (c->spec_blocks_y ? "1" : "0");
     // Material facts (rtc_kernel_core.h): does any material reflect / transmit at all (a scene without either carries no
     // recursion code), does any need powf for a highlight, and how many levels of the recursion stack the kernel keeps in
     // registers (FrameStack).  Register levels were built to take the 2.5 GB of frame traffic out of the glass-and-mirror
@@ -1376,6 +1392,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
                                              "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
                                              std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
             defs.push_back(share_def);
+            defs.push_back(blocks_def);
             defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
             rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
             if (jst != RTC_OK) {
@@ -1407,6 +1424,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         defs.push_back(std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0"));
         defs.push_back(std::string("-DRTC_SPEC_GATES=") + (hdr.n_gates ? "1" : "0"));
         defs.push_back(share_def);
+        defs.push_back(blocks_def);
         defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
         if (reg_waves) defs.push_back(reg_waves);
         // A point light has no sample loop to keep registers free for: cold state stays in VGPRs instead of being parked
@@ -1449,6 +1467,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
                                              "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
                                              std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
             defs.push_back(share_def);
+            defs.push_back(blocks_def);
             if (reg_waves) defs.push_back(reg_waves);
             defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
             rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
@@ -1481,6 +1500,18 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     const uint32_t share_log2 = (c->spec_fn && c->spec_shares) ? choose_share_log2(c->hdr, rows) : 0u;  // only kernels compiled for it share lanes
     const uint32_t bw = 16u >> (share_log2 >> 1), bh = 16u >> ((share_log2 + 1u) >> 1);  // pixels per workgroup (2x2 wave tiles)
     dim3 grid((c->hdr.width + bw - 1) / bw, (rows + bh - 1) / bh), block(256);
+    // Frames of very many very short waves: several blocks per workgroup (RTC_AMD_BLOCKS_Y=1..8 overrides)
+    uint32_t blocks_y = 1u;
+    if (!(c->spec_fn && c->spec_blocks_y)) {
+        // (only kernels compiled for it loop over blocks)
+    } else if (const char* e = std::getenv("RTC_AMD_BLOCKS_Y")) {
+        if (e[0] >= '1' && e[0] <= '8' && !e[1]) blocks_y = (uint32_t)(e[0] - '0');
+    } else if ((uint64_t)grid.x * grid.y >= (1u << 15)) {
+        // most workgroups see nothing but the sky: C5 8192^2 0.51 -> 0.43 ms, single_sphere 4096^2 0.088 -> 0.061 ms.  (Where the
+        // waves have work -- hexagons, grouped_grid, whose boxes fill the frame -- four blocks per workgroup cost 8 ... 17 %.)
+        blocks_y = 4u;
+    }
+    grid.y = (grid.y + blocks_y - 1) / blocks_y;
     // Tree worlds with meshes: a block list instead of the regular grid -- the tiles a mesh projects to first, eight
     // lanes per pixel there and one elsewhere (build_block_list).  Not when RTC_AMD_SHARE_LOG2 pins one value for all.
     const uint32_t* d_tiles = nullptr;
@@ -1543,6 +1574,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     a.depth = depth;
     a.share_log2 = share_log2;
     a.tiles = d_tiles;
+    a.blocks_y = blocks_y;
     if (c->events_used == c->events.size()) {
         if (c->events.size() >= 4096) {
             c->events_used = 0;  // nobody is reading the timings: recycle

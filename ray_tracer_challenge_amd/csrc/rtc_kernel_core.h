@@ -2515,6 +2515,7 @@ struct RenderArgs {
     // projects to first and with 8 lanes per pixel, the rest after them with one (rtc_device.hip build_block_list):
     // such a frame's time is that of its slowest waves, so those start first and are cut into eight.  nullptr: regular grid.
     const uint32_t* tiles;
+    uint32_t blocks_y;  // regular grid: blocks rendered by one workgroup, stacked vertically (>= 1)
 };
 
 // Camera::render (camera.rs:76-91): one lane per pixel, 8x8 pixel tile per
@@ -2543,10 +2544,20 @@ DI void render_body(const RenderArgs& A) {
     const uint32_t q = lane >> sl;  // q: the pixel's slot in the wave's tile
     const uint32_t tw_log2 = 3u - (sl >> 1), th_log2 = 3u - ((sl + 1u) >> 1);
     const uint32_t x = bx0 + ((wave & 1u) << tw_log2) + (q & ((1u << tw_log2) - 1u));
-    const uint32_t yl = by0 + ((wave >> 1) << th_log2) + (q >> tw_log2);
     Counters cnt = {0u, 0u, sl};
     __shared__ float stash_lds[LDS_SLOTS * 256];
     const LaneStash stash = {stash_lds + threadIdx.x, 256u};
+    // A workgroup of the regular grid renders `blocks_y` blocks, one below the other (host: frames whose waves are so
+    // short -- C5: 95 % of 67 M pixels miss the scene's box -- that launching them is what the frame costs)
+    // Compiled in only where the host asks for it (-DRTC_SPEC_BLOCKS_Y=1): the loop's carried state costs other kernels
+    // registers (first_patterns: 6 -> 18 spilled VGPRs, +45 %).
+#if defined(RTC_SPEC_BLOCKS_Y) && RTC_SPEC_BLOCKS_Y
+    const uint32_t blocks_y = A.tiles != nullptr ? 1u : A.blocks_y;
+#else
+    constexpr uint32_t blocks_y = 1u;
+#endif
+    for (uint32_t rep = 0; rep < blocks_y; rep++) {
+    const uint32_t yl = (A.tiles != nullptr ? by0 : (blockIdx.y * blocks_y + rep) << (4u - ((sl + 1u) >> 1))) + ((wave >> 1) << th_log2) + (q >> tw_log2);
     if (x < H.width && yl < A.rows) {
         // compact local row -> global row of the image
         const uint32_t band = yl / A.band_rows;
@@ -2590,6 +2601,7 @@ DI void render_body(const RenderArgs& A) {
             dst[1] = col.y;
             dst[2] = col.z;
         }
+    }
     }
     // work statistics: wave reduce, then one partial per wave
     uint32_t rays = cnt.rays, shaded = cnt.shaded & CNT_SHADED_MASK, culled = cnt.shaded >> CNT_CULLED_SHIFT;
