@@ -27,8 +27,13 @@ for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {"kernel": r["Kernel_Name"], "grid": r["Grid_Size"], "workgroup": r["Workgroup_Size"],
                     "vgpr": r["VGPR_Count"], "sgpr": r["SGPR_Count"], "scratch_bytes_per_lane": r["Scratch_Size"]}
-m = {k: sum(v) / len(v) for k, v in agg.items()}
-out = {"tag": tag, "launch": meta, "counters_mean_per_launch": m}
+def typical(v):  # the median: the first dispatch of a run (module load, cold caches) can be far off and must not drag a mean
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+m = {k: typical(v) for k, v in agg.items()}
+out = {"tag": tag, "launch": meta, "counters_mean_per_launch": m, "counters_are": "medians over the profiled launches"}
 for r in csv.DictReader(open(stats)):
     if "render_kernel" in r["Name"]:
         out["kernel_trace"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),

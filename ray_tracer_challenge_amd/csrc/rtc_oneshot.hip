@@ -133,7 +133,7 @@ struct DevState {
     size_t d_u8_cap = 0;
     char* h_stage[2] = {nullptr, nullptr};  // pinned
     size_t stage_cap = 0;
-    hipStream_t s_render = nullptr, s_copy = nullptr;
+    hipStream_t s_render = nullptr, s_copy2[2] = {nullptr, nullptr};  // chunks alternate between two copy streams: two DMA engines
     std::vector<hipEvent_t> ev_render, ev_copy;
 
     void release() {
@@ -148,7 +148,8 @@ struct DevState {
         for (hipEvent_t e : ev_render) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_copy) (void)hipEventDestroy(e);
         if (s_render) (void)hipStreamDestroy(s_render);
-        if (s_copy) (void)hipStreamDestroy(s_copy);
+        for (hipStream_t& c : s_copy2)
+            if (c) (void)hipStreamDestroy(c), c = nullptr;
         *this = DevState();
     }
 };
@@ -246,7 +247,8 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
         HIP_TRY(hipSetDevice(S.device));
         if (!S.ctx) RTC_TRY(rtc_ctx_create(S.device, &S.ctx));
         if (!S.s_render) HIP_TRY(hipStreamCreateWithFlags(&S.s_render, hipStreamNonBlocking));
-        if (!S.s_copy) HIP_TRY(hipStreamCreateWithFlags(&S.s_copy, hipStreamNonBlocking));
+        for (hipStream_t& c : S.s_copy2)
+            if (!c) HIP_TRY(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
         while (S.ev_render.size() < C) {
             hipEvent_t e;
             HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -299,19 +301,20 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
             for (uint32_t k = 0; k < D; k++) {
                 DevState& S = g_state[k];
                 HIP_TRY(hipSetDevice(S.device));
-                HIP_TRY(hipStreamWaitEvent(S.s_copy, S.ev_render[j], 0));
+                hipStream_t s_copy = S.s_copy2[j & 1];
+                HIP_TRY(hipStreamWaitEvent(s_copy, S.ev_render[j], 0));
                 for (const Band& b : bands[k][j]) {
                     char* dst = (char*)out + (size_t)b.y0 * row_out;
                     const char* src = src_of(k) + b.src_row * row_out;
                     const size_t n = (size_t)b.rows * row_out;
-                    if (!on_device) HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, S.s_copy));
-                    else if (S.device == devices[0]) HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, S.s_copy));
-                    else HIP_TRY(hipMemcpyPeerAsync(dst, devices[0], src, S.device, n, S.s_copy));
+                    if (!on_device) HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s_copy));
+                    else if (S.device == devices[0]) HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s_copy));
+                    else HIP_TRY(hipMemcpyPeerAsync(dst, devices[0], src, S.device, n, s_copy));
                 }
             }
         for (uint32_t k = 0; k < D; k++) {
             HIP_TRY(hipSetDevice(g_state[k].device));
-            HIP_TRY(hipStreamSynchronize(g_state[k].s_copy));
+            for (hipStream_t c : g_state[k].s_copy2) HIP_TRY(hipStreamSynchronize(c));
         }
     } else {
         // pageable host memory: DMA into pinned staging (two slots per device), emptied into `out` by the copy pool
@@ -320,9 +323,10 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
             DevState& S = g_state[k];
             const Chunk& c = chunks[k][j];
             HIP_TRY(hipSetDevice(S.device));
-            HIP_TRY(hipStreamWaitEvent(S.s_copy, S.ev_render[j], 0));
-            if (c.rows) HIP_TRY(hipMemcpyAsync(S.h_stage[j & 1], src_of(k) + c.row0 * row_out, (size_t)c.rows * row_out, hipMemcpyDeviceToHost, S.s_copy));
-            HIP_TRY(hipEventRecord(S.ev_copy[j], S.s_copy));
+            hipStream_t s_copy = S.s_copy2[j & 1];  // (slot j & 1 of the staging memory belongs to this stream alone)
+            HIP_TRY(hipStreamWaitEvent(s_copy, S.ev_render[j], 0));
+            if (c.rows) HIP_TRY(hipMemcpyAsync(S.h_stage[j & 1], src_of(k) + c.row0 * row_out, (size_t)c.rows * row_out, hipMemcpyDeviceToHost, s_copy));
+            HIP_TRY(hipEventRecord(S.ev_copy[j], s_copy));
             return RTC_OK;
         };
         for (uint32_t k = 0; k < D; k++)
