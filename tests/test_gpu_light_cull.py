@@ -243,3 +243,57 @@ def test_points_all_around_cubes_and_cylinders(jitter):
             exp = ow.intensity_at(pts[i])
             assert got[i] == exp, (jitter, k, pts[i], got[i], exp)
         assert (got == 1.0).mean() > 0.03 and (got < 1.0).mean() > 0.03  # lit and shadowed points both occur
+
+
+def _random_simple_world(rng, n_objects, jitter):
+    """Scale+translate-only spheres and planes (what the SIMPLE kernels and their margin-guarded fast sample decision,
+    shadow_fast, are for): casters and non-casters, tiny and huge, mirrored, touching and overlapping, a floor."""
+    objs = [P.Plane(P.translation(0.0, float(rng.choice([0.0, -0.5, rng.uniform(-1, 0.5)])), 0.0),
+                    P.Material(color=tuple(rng.uniform(0.3, 1, 3)), specular=float(rng.choice([0.0, 0.4])), reflective=float(rng.choice([0.0, 0.25]))),
+                    casts_shadow=bool(rng.random() < 0.7))]
+    for _ in range(n_objects - 1):
+        if rng.random() < 0.15:
+            t = P.chain(P.translation(0.0, float(rng.uniform(2.0, 7.0)), 0.0), P.scaling(1.0, float(rng.choice([1.0, -1.0, 0.2])), 1.0))
+            objs.append(P.Plane(t, P.Material(color=tuple(rng.uniform(0.3, 1, 3))), casts_shadow=bool(rng.random() < 0.5)))
+            continue
+        s = float(10.0 ** rng.uniform(-1.3, 0.3)) * rng.uniform(0.6, 1.6, 3)
+        if rng.random() < 0.2:
+            s[int(rng.integers(0, 3))] *= -1.0
+        pos = rng.uniform(-2.5, 2.5, 3) + np.array([0.0, 1.0, 0.0])
+        objs.append(P.Sphere(P.chain(P.translation(*[float(v) for v in pos]), P.scaling(*[float(v) for v in s])),
+                             P.Material(color=tuple(rng.uniform(0.2, 1, 3)), specular=float(rng.choice([0.0, 0.0, 0.6])),
+                                        reflective=float(rng.choice([0.0, 0.0, 0.3]))),
+                             casts_shadow=bool(rng.random() < 0.8)))
+    corner = rng.uniform(-2.5, 2.5, 3) + np.array([0.0, 3.5, 0.0])
+    u = np.array([rng.uniform(0.2, 3), 0.0, rng.uniform(-0.5, 0.5)])
+    v = np.array([0.0, float(rng.choice([0.0, rng.uniform(0.2, 2)])), rng.uniform(0.2, 3)])
+    light = P.RectangleLight(P.color(1.3, 1.2, 1.1), P.point(*corner), P.vector(*u), int(rng.integers(3, 9)), P.vector(*v), int(rng.integers(3, 9)), jitter)
+    return P.World(objs, light)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fast_sample_decision_changes_nothing_on_random_simple_scenes(seed, monkeypatch):
+    """shadow_fast decides an area-light sample from the unnormalised ray wherever its margins hold and every object in
+    play is a casting sphere or plane.  Random scale+translate-only worlds, ahead-of-time and scene-compiled kernels:
+    images, ray counts and shaded hits with it on equal those with it off -- and the oracle's."""
+    from ray_tracer_challenge_amd.renderer import Renderer
+    rng = np.random.default_rng(7000 + seed)
+    jitter = [("hashed", 1234 + seed), ("constant", 0.5), ("constant", 1.0), ("constant", 0.0)][seed % 4]
+    world = _random_simple_world(rng, int(rng.integers(2, 9)), jitter)
+    cam = P.Camera(88, 66, scenes.PI / f32(2.5),
+                   P.view_transform(P.point(*[float(x) for x in rng.uniform(-5, 5, 3) + np.array([0, 3.0, 0])]), P.point(0, 0.7, 0), P.vector(0, 1, 0)))
+    exp, rays = H.oracle_camera(cam).render(H.oracle_world(world), 3, threads=8)
+    for spec in ("0", "1"):
+        monkeypatch.setenv("RTC_AMD_SPECIALIZE", spec)
+        frames = {}
+        for fast in ("1", "0"):
+            monkeypatch.setenv("RTC_AMD_FAST_SHADOW", fast)
+            r = Renderer(world, cam, device=0)
+            assert "simple" in r.kernel_name, r.kernel_name
+            frames[fast] = (r.render(3).cpu().numpy(), r.stats())
+            r.close()
+        H.assert_images_equal(frames["1"][0], exp, "seed %d specialise=%s fast" % (seed, spec))
+        H.assert_images_equal(frames["0"][0], exp, "seed %d specialise=%s exact" % (seed, spec))
+        for key in ("rays", "shaded_hits"):
+            assert frames["1"][1][key] == frames["0"][1][key], (seed, spec, key)
+        assert frames["1"][1]["rays"] == rays
