@@ -250,6 +250,7 @@ static std::string tree_jit_waves() {
 // cells (intensity_at), while the frame would otherwise be fewer than ~4 waves per SIMD; and, in a tree walk, the long
 // runs of leaves a divided mesh leaves at every level (for_each_leaf_shared) -- there a frame's time is that of its
 // slowest wave, whatever the frame's size.  RTC_AMD_SHARE_LOG2=0..3 overrides.
+static uint32_t choose_share_log2_runs(uint64_t waves) { return waves <= 12000u ? 3u : waves <= 40000u ? 2u : 1u; }
 static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows) {
     const bool area = hdr.light_kind == RTC_LIGHT_RECT && hdr.u_steps * hdr.v_steps >= 8;
     const bool runs = hdr.n_trav != 0u && hdr.max_leaf_run >= 16u && !area;
@@ -257,9 +258,10 @@ static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows) {
     if (const char* e = std::getenv("RTC_AMD_SHARE_LOG2"))
         if (e[0] >= '0' && e[0] <= '3' && !e[1]) return (uint32_t)(e[0] - '0');
     const uint64_t waves = ((uint64_t)hdr.width * rows + 63) / 64;
-    // measured (tools/ab_env.py): here_be_dragons 1000 x 400 (6 k waves) 2.88 / 0.93 / 0.79 ms with 1 / 4 / 8 lanes per pixel in
-    // the mesh tiles; mesh 2048^2 (65 k waves) 5.3 / 4.2 / 5.9 ms; here_be_dragons 4000 x 1600 (100 k) 3.9 / 3.6 / 4.8 ms
-    if (runs) return waves <= 16384u ? 3u : 2u;
+    // measured (tools/sweep_block_s.sh), ms with 2 / 4 / 8 lanes per pixel in the mesh tiles: here_be_dragons 1000 x 400 (6 k
+    // waves) 1.33 / 0.93 / 0.77, 2000 x 800 (25 k) 1.61 / 1.41 / 1.50, 4000 x 1600 (100 k) 3.25 / 3.57 / 4.80; mesh 512 x 384
+    // (3 k) 3.81 / 2.54 / 2.05, 1024^2 (16 k) 3.12 / 2.58 / 3.13, 2048^2 (65 k) 3.65 / 4.37 / 5.86, 4096^2 (262 k) 8.5 / 11.1 / 16.8
+    if (runs) return choose_share_log2_runs(waves);
     uint32_t s = 0;
     while (s < 3u && (waves << s) < 24576u) s++;
     return s;
@@ -356,8 +358,150 @@ static bool build_flat_bvh(const rtc_scene* scene, const float cam_origin[4], st
     return true;
 }
 
+// A hierarchy of the library's own over every long run of boxed triangle leaves (the rings divide() leaves behind, group.rs:
+// 46-73: 168 / 48 / 63 / 27 ... direct children per level of a 3 k-triangle mesh, thousands for a scanned one), written into
+// the entry list as NODES -- group-like entries the kernel tells from GroupShapes by e2.w > 0 and tests with node_precull.  A
+// node never changes an answer: it is passed by only when tri_precull would have skipped each triangle under it, i.e. the
+// ray's line misses the hull of their padded boxes AND the ray is at more than asin(TRI_GUARD) from every one of their
+// planes, which the node knows through a cone around their normals (axis a, half-angle phi: |d.a| >= sin(phi +
+// asin(TRI_GUARD)) |d| implies |d.n| >= TRI_GUARD |d| for every n within phi of +-a).  The run's leaves are re-ordered
+// (median splits of their boxes' centres): the tree kernels resolve equal distances by object index, not by position.
+// `trav` must carry the run lengths of mark_leaf_runs; the caller marks the new list again.
+static void cluster_leaf_runs(std::vector<float4>* trav, double tri_guard) {
+    uint32_t MIN_RUN = 24;  // (RTC_AMD_CLUSTER_MIN_RUN, _LEAF, _GMAX: development and tests)
+    uint32_t LEAF = 8;      // triangles under a node of the lowest level, at most
+    if (const char* e = std::getenv("RTC_AMD_CLUSTER_MIN_RUN")) MIN_RUN = std::max(3u, (uint32_t)std::atoi(e));
+    double g_max = 0.85;   // a node whose cone lets fewer than ~15 % of all directions pass is not worth its test
+    if (const char* e = std::getenv("RTC_AMD_CLUSTER_LEAF")) LEAF = std::min(64u, std::max(2u, (uint32_t)std::atoi(e)));
+    if (const char* e = std::getenv("RTC_AMD_CLUSTER_GMAX")) g_max = std::atof(e);
+    const size_t ne = trav->size() / TRAV_STRIDE;
+    const std::vector<float4>& in = *trav;
+    std::vector<float4> out;
+    out.reserve(in.size() + in.size() / 4);
+    std::vector<uint32_t> new_index(ne + 1, 0);
+    std::vector<size_t> groups;  // new positions of the copied group entries (their skip indices are mapped at the end)
+    auto as_f = [](uint32_t u) {
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    };
+    struct Build {
+        const std::vector<float4>& in;
+        std::vector<float4>& out;
+        double tri_guard, g_max;
+        uint32_t LEAF;
+        float (*as_f)(uint32_t);
+        void go(std::vector<size_t>& ord, size_t b, size_t e) {
+            if (e - b <= LEAF) {
+                for (size_t k = b; k < e; k++)
+                    for (uint32_t r = 0; r < TRAV_STRIDE; r++) out.push_back(in[TRAV_STRIDE * ord[k] + r]);
+                return;
+            }
+            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            double axis[3] = {0.0, 0.0, 0.0};
+            for (size_t k = b; k < e; k++) {
+                const float4 &mn = in[TRAV_STRIDE * ord[k]], &mx = in[TRAV_STRIDE * ord[k] + 1], &nr = in[TRAV_STRIDE * ord[k] + 2];
+                const double a[3] = {mn.x, mn.y, mn.z}, c[3] = {mx.x, mx.y, mx.z}, n[3] = {nr.x, nr.y, nr.z};
+                for (int j = 0; j < 3; j++) {
+                    lo[j] = std::fmin(lo[j], a[j]), hi[j] = std::fmax(hi[j], c[j]);
+                    clo[j] = std::fmin(clo[j], a[j] + c[j]), chi[j] = std::fmax(chi[j], a[j] + c[j]);
+                }
+                const double sgn = (n[0] * axis[0] + n[1] * axis[1] + n[2] * axis[2]) < 0.0 ? -1.0 : 1.0;  // n and -n are one plane
+                for (int j = 0; j < 3; j++) axis[j] += sgn * n[j];
+            }
+            const double al = std::sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+            double g = 2.0;  // sin(phi + asin(tri_guard)), or "no node"
+            if (al > 1e-6) {
+                double cmin = 1.0;  // cosine of the cone's half-angle
+                for (size_t k = b; k < e; k++) {
+                    const float4& nr = in[TRAV_STRIDE * ord[k] + 2];
+                    const double nl = std::sqrt((double)nr.x * nr.x + (double)nr.y * nr.y + (double)nr.z * nr.z);
+                    const double c = std::fabs(nr.x * axis[0] + nr.y * axis[1] + nr.z * axis[2]) / (al * nl);
+                    cmin = std::fmin(cmin, nl > 0.5 ? c : 0.0);
+                }
+                const double phi = std::acos(std::fmin(1.0, cmin)) + 1e-3;  // 1e-3 rad: the records' normals are f32, so is the kernel's dot product
+                const double lim = phi + std::asin(std::fmin(1.0, tri_guard));
+                if (lim < 1.5) g = std::sin(lim);
+            }
+            const bool node = g <= g_max && std::isfinite(lo[0] + lo[1] + lo[2] + hi[0] + hi[1] + hi[2]);
+            const size_t head = out.size();
+            if (node) {
+                float big = 0.0f;
+                for (int j = 0; j < 3; j++) big = std::fmax(big, (float)std::fmax(std::fabs(lo[j]), std::fabs(hi[j])));
+                // hull of boxes that are f32 already: exact.  The third record: |d.a'| >= tri_guard |d| <=> |d.a| >= g |d|
+                const double scale = (tri_guard > 0.0 ? tri_guard : 1.0) / (g * al);
+                out.push_back(make_float4((float)lo[0], (float)lo[1], (float)lo[2], 0.0f));
+                out.push_back(make_float4((float)hi[0], (float)hi[1], (float)hi[2], 1e-3f * big));
+                out.push_back(make_float4((float)(axis[0] * scale), (float)(axis[1] * scale), (float)(axis[2] * scale), 1.0f));
+            }
+            int ax = 0;
+            for (int j = 1; j < 3; j++)
+                if (chi[j] - clo[j] > chi[ax] - clo[ax]) ax = j;
+            const size_t mid = b + (e - b) / 2;
+            std::nth_element(ord.begin() + b, ord.begin() + mid, ord.begin() + e, [&](size_t x, size_t y) {
+                const float4 &xa = in[TRAV_STRIDE * x], &xb = in[TRAV_STRIDE * x + 1], &ya = in[TRAV_STRIDE * y], &yb = in[TRAV_STRIDE * y + 1];
+                const float cx = ax == 0 ? xa.x + xb.x : ax == 1 ? xa.y + xb.y : xa.z + xb.z;
+                const float cy = ax == 0 ? ya.x + yb.x : ax == 1 ? ya.y + yb.y : ya.z + yb.z;
+                return cx < cy || (cx == cy && x < y);
+            });
+            go(ord, b, mid);
+            go(ord, mid, e);
+            if (node) out[head].w = as_f((uint32_t)(out.size() / TRAV_STRIDE));
+        }
+    };
+    Build build = {in, out, tri_guard, g_max, LEAF, +as_f};
+    for (size_t e = 0; e < ne;) {
+        new_index[e] = (uint32_t)(out.size() / TRAV_STRIDE);
+        if (!(in[TRAV_STRIDE * e + 1].w < 0.0f)) {  // a group
+            groups.push_back(out.size() / TRAV_STRIDE);
+            for (uint32_t r = 0; r < TRAV_STRIDE; r++) out.push_back(in[TRAV_STRIDE * e + r]);
+            e++;
+            continue;
+        }
+        const uint32_t w = (uint32_t)in[TRAV_STRIDE * e + 2].w, run = std::max(1u, w >> 3);
+        const size_t end = std::min(ne, e + run);
+        bool all_boxed = (w & 4u) != 0u;  // a mesh run: boxed triangles under one transform
+        for (size_t k = e; k < end && all_boxed; k++) all_boxed = in[TRAV_STRIDE * k + 1].w == TRAV_BOXED_LEAF_TAG;
+        if (all_boxed && end - e >= MIN_RUN) {
+            std::vector<size_t> ord(end - e);
+            for (size_t k = e; k < end; k++) ord[k - e] = k;
+            build.go(ord, 0, ord.size());
+        } else {
+            for (size_t k = e; k < end; k++)
+                for (uint32_t r = 0; r < TRAV_STRIDE; r++) out.push_back(in[TRAV_STRIDE * k + r]);
+        }
+        for (size_t k = e + 1; k < end; k++) new_index[k] = new_index[e];  // (nothing points into a run)
+        e = end;
+    }
+    new_index[ne] = (uint32_t)(out.size() / TRAV_STRIDE);
+    if (env_flag("RTC_AMD_CLUSTER_STATS", false)) {  // development
+        size_t leaves = 0, nodes = 0, in_nodes = 0;
+        double gsum = 0.0;
+        for (size_t e = 0; e < out.size() / TRAV_STRIDE; e++) {
+            if (out[TRAV_STRIDE * e + 1].w < 0.0f) leaves++;
+            else if (out[TRAV_STRIDE * e + 2].w > 0.0f) {
+                nodes++;
+                const float4 a = out[TRAV_STRIDE * e + 2];
+                gsum += tri_guard / std::sqrt((double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z);
+                uint32_t skip;
+                std::memcpy(&skip, &out[TRAV_STRIDE * e].w, 4);
+                in_nodes += skip - e - 1;
+            }
+        }
+        std::fprintf(stderr, "cluster_leaf_runs: %zu entries -> %zu; %zu groups, %zu leaves, %zu nodes (mean g %.3f, entries under nodes incl. nested %zu)\n",
+                     ne, out.size() / TRAV_STRIDE, groups.size(), leaves, nodes, nodes ? gsum / nodes : 0.0, in_nodes);
+    }
+    for (size_t gpos : groups) {
+        uint32_t skip;
+        std::memcpy(&skip, &out[TRAV_STRIDE * gpos].w, 4);
+        out[TRAV_STRIDE * gpos].w = as_f(new_index[std::min<size_t>(skip, ne)]);
+    }
+    trav->swap(out);
+}
+
 // Every leaf entry learns how many consecutive leaf entries OF THE SAME GROUP start with it, and whether those are a MESH
-// run -- boxed triangle leaves of consecutive object indices that all share one inverse transform and one kind / flags
+// run -- boxed triangle leaves that all share one inverse transform and one kind / flags
 // word, which is what the children of a parsed, transformed, divided mesh are (group.rs:39-44 bakes the group's transform
 // into every child) -- see the kernel's trav_run / trav_mesh_run / trav_more, which share e2.w (it holds `more`, 0..3,
 // on entry).  A run ends where a group ends: the leaves after a nested group's last child belong to rays that may not
@@ -378,7 +522,7 @@ static uint32_t mark_leaf_runs(std::vector<float4>* trav, const rtc_scene* scene
     };
     auto same_mesh = [&](size_t a, size_t b) {  // entry b continues the mesh run of entry a
         const uint32_t ia = object_of(a), ib = object_of(b);
-        if (ib != ia + 1u || ib >= scene->n_objects) return false;
+        if (ia >= scene->n_objects || ib >= scene->n_objects) return false;
         const rtc_object &oa = scene->objects[ia], &ob = scene->objects[ib];
         return oa.kind == ob.kind && (oa.casts_shadow != 0) == (ob.casts_shadow != 0) && std::memcmp(oa.inv, ob.inv, sizeof(oa.inv)) == 0;
     };
@@ -678,12 +822,15 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         if (gi != scene->n_groups)
             return fail(RTC_ERR_INVALID_ARG, "group %u: groups must be listed in pre-order with first_object inside [0, n_objects)", gi);
         // boxed triangle leaves that follow one another are pre-culled two at a time (for_each_object): mark the first of a pair
-        for (size_t e = 0, ne = trav.size() / TRAV_STRIDE; e < ne; e++) {
-            if (trav[TRAV_STRIDE * e + 1].w != TRAV_BOXED_LEAF_TAG) continue;
-            int more = 0;  // boxed leaves right after this one, up to 3
-            while (more < 3 && e + more + 1 < ne && trav[TRAV_STRIDE * (e + more + 1) + 1].w == TRAV_BOXED_LEAF_TAG) more++;
-            trav[TRAV_STRIDE * e + 2].w = (float)more;
-        }
+        auto mark_pairs = [&trav]() {
+            for (size_t e = 0, ne = trav.size() / TRAV_STRIDE; e < ne; e++) {
+                if (trav[TRAV_STRIDE * e + 1].w != TRAV_BOXED_LEAF_TAG) continue;
+                int more = 0;  // boxed leaves right after this one, up to 3
+                while (more < 3 && e + more + 1 < ne && trav[TRAV_STRIDE * (e + more + 1) + 1].w == TRAV_BOXED_LEAF_TAG) more++;
+                trav[TRAV_STRIDE * e + 2].w = (float)more;
+            }
+        };
+        mark_pairs();
         hdr->max_leaf_run = mark_leaf_runs(&trav, scene);
         if (heavy_boxes)
             for (const auto& tl : top_level) {
@@ -695,8 +842,26 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
                     const rtc_group& g = scene->groups[tl.second];
                     for (int a = 0; a < 3; a++) heavy_boxes->push_back(g.bounds_min[a]);
                     for (int a = 0; a < 3; a++) heavy_boxes->push_back(g.bounds_max[a]);
+                    // how dear a pixel on this group is, as a rank: a surface that both reflects and refracts doubles its rays
+                    // at every level of the recursion, one that does either keeps them going
+                    bool refl = false, refr = false;
+                    for (uint32_t i = g.first_object; i < g.first_object + g.n_objects && i < n; i++) {
+                        refl |= scene->objects[i].material.reflective > 0.0f;
+                        refr |= scene->objects[i].material.transparency > 0.0f;
+                    }
+                    heavy_boxes->push_back(refl && refr ? 3.0f : (refl || refr) ? 2.0f : 1.0f);
                 }
             }
+        // Long runs of boxed triangles get a hierarchy of the library's own (RTC_AMD_CLUSTERS=0 / 1: never / always) -- in
+        // frames large enough to be traced by one or two lanes per pixel.  Where eight lanes split every run (small frames,
+        // whose time is that of their slowest wave) the nodes cut the runs into pieces of a lane's share and every piece
+        // ends in a round of shuffles: here_be_dragons 1000 x 400 0.79 -> 0.98 ms, 2000 x 800 1.41 -> 1.49; 4000 x 1600 3.25 -> 2.92.
+        const bool clusters_pay = cam && choose_share_log2_runs(((uint64_t)cam->width * cam->height + 63) / 64) <= 1u;
+        if (hdr->has_tbox && (hdr->max_leaf_run >= 24u || std::getenv("RTC_AMD_CLUSTER_MIN_RUN")) && env_flag("RTC_AMD_CLUSTERS", clusters_pay)) {
+            cluster_leaf_runs(&trav, (double)hdr->tri_guard);
+            mark_pairs();
+            (void)mark_leaf_runs(&trav, scene);  // (max_leaf_run keeps the length of the reference's runs: what the launch policy goes by)
+        }
         // A small tree (<= 8 leaves under <= 8 groups) keeps the unrolled flat kernels: every group becomes a GATE -- its box,
         // tested once per ray with the reference's own aabb test -- and a leaf is intersected only if the ray opens all the
         // groups around it, which is all the recursive walk does (group.rs:115-133).  Same leaves in the same order.
@@ -1181,6 +1346,7 @@ void rtc_ctx_destroy(rtc_ctx* c) {
 // pixel (px, py) through the camera-space point (half_width - (px + 0.5) s, half_height - (py + 0.5) s, -1); a world
 // point maps to camera space through the inverse of Camera.transform_inverse.  Performance only -- which blocks start
 // first and with how many lanes per pixel -- so generous padding and "everything" when a box reaches behind the camera.
+constexpr size_t HEAVY_BOX_FLOATS = 7;  // min, max, rank (1 .. 3: project_heavy_boxes keeps a tile's highest)
 static void project_heavy_boxes(const std::vector<float>& boxes, const rtc_camera* cam, std::vector<uint8_t>* tiles, uint32_t* tw, uint32_t* th) {
     tiles->clear();
     *tw = *th = 0;
@@ -1191,7 +1357,7 @@ static void project_heavy_boxes(const std::vector<float>& boxes, const rtc_camer
     tiles->assign((size_t)w * h, 0);
     *tw = w;
     *th = h;
-    for (size_t b = 0; b + 5 < boxes.size(); b += 6) {
+    for (size_t b = 0; b + HEAVY_BOX_FLOATS - 1 < boxes.size(); b += HEAVY_BOX_FLOATS) {
         double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
         bool everything = false;
         for (int k = 0; k < 8 && !everything; k++) {
@@ -1210,7 +1376,7 @@ static void project_heavy_boxes(const std::vector<float>& boxes, const rtc_camer
         const long tx0 = std::max(0L, (long)std::floor((x0 - 8.0) / 16.0)), tx1 = std::min((long)w - 1, (long)std::floor((x1 + 8.0) / 16.0));
         const long ty0 = std::max(0L, (long)std::floor((y0 - 8.0) / 16.0)), ty1 = std::min((long)h - 1, (long)std::floor((y1 + 8.0) / 16.0));
         for (long ty = ty0; ty <= ty1; ty++)
-            for (long tx = tx0; tx <= tx1; tx++) (*tiles)[(size_t)ty * w + tx] = 1;
+            for (long tx = tx0; tx <= tx1; tx++) (*tiles)[(size_t)ty * w + tx] = std::max((*tiles)[(size_t)ty * w + tx], (uint8_t)boxes[b + 6]);
     }
 }
 
@@ -1223,18 +1389,28 @@ static void build_block_list(const rtc_ctx_tiles& T, uint32_t width, uint32_t me
     uint32_t hs = mesh_share_log2;  // lanes per pixel (log2) in the mesh tiles; RTC_AMD_BLOCK_S=0..3: development
     if (const char* e = std::getenv("RTC_AMD_BLOCK_S"))
         if (e[0] >= '0' && e[0] <= '3' && !e[1]) hs = (uint32_t)(e[0] - '0');
-    const uint32_t hbw = 16u >> (hs >> 1), hbh = 16u >> ((hs + 1u) >> 1);
-    for (uint32_t yl0 = 0; yl0 < rows; yl0 += 16u) {
-        const uint32_t band = yl0 / q.band_rows;
-        const uint32_t y = (band * q.n_parts + q.part) * q.band_rows + (yl0 - band * q.band_rows);  // global row of the tile's first row
-        for (uint32_t x0 = 0; x0 < width; x0 += 16u) {
-            const uint32_t ty = std::min(y / 16u, T.h - 1u), tx = std::min(x0 / 16u, T.w - 1u);
-            if (T.bits[(size_t)ty * T.w + tx]) {
-                for (uint32_t dy = 0; dy < 16u && yl0 + dy < rows; dy += hbh)
-                    for (uint32_t dx = 0; dx < 16u && x0 + dx < width; dx += hbw)
-                        out->push_back(hs << 30 | ((x0 + dx) / 4u) << 16 | ((yl0 + dy) / 4u));
-            } else {
-                light.push_back(0u << 30 | (x0 / 4u) << 16 | (yl0 / 4u));
+    // the dearest tiles first (rank 3: glass that also reflects), or the frame ends waiting for a few waves that started
+    // late (RTC_AMD_BLOCK_ORDER=0: image order; RTC_AMD_BLOCK_S_TOP=0..3: lanes per pixel of rank 3 alone -- development)
+    const bool ordered = env_flag("RTC_AMD_BLOCK_ORDER", true);
+    uint32_t hs_top = hs;
+    if (const char* e = std::getenv("RTC_AMD_BLOCK_S_TOP"))
+        if (e[0] >= '0' && e[0] <= '3' && !e[1]) hs_top = (uint32_t)(e[0] - '0');
+    for (uint32_t rank = 3u; rank >= 1u; rank--) {
+        const uint32_t s = rank == 3u ? hs_top : hs;
+        const uint32_t hbw = 16u >> (s >> 1), hbh = 16u >> ((s + 1u) >> 1);
+        for (uint32_t yl0 = 0; yl0 < rows; yl0 += 16u) {
+            const uint32_t band = yl0 / q.band_rows;
+            const uint32_t y = (band * q.n_parts + q.part) * q.band_rows + (yl0 - band * q.band_rows);  // global row of the tile's first row
+            for (uint32_t x0 = 0; x0 < width; x0 += 16u) {
+                const uint32_t ty = std::min(y / 16u, T.h - 1u), tx = std::min(x0 / 16u, T.w - 1u);
+                const uint32_t r = T.bits[(size_t)ty * T.w + tx];
+                if (r != 0u && (ordered ? r == rank : rank == 1u)) {
+                    for (uint32_t dy = 0; dy < 16u && yl0 + dy < rows; dy += hbh)
+                        for (uint32_t dx = 0; dx < 16u && x0 + dx < width; dx += hbw)
+                            out->push_back(s << 30 | ((x0 + dx) / 4u) << 16 | ((yl0 + dy) / 4u));
+                } else if (rank == 1u && r == 0u) {
+                    light.push_back(0u << 30 | (x0 / 4u) << 16 | (yl0 / 4u));
+                }
             }
         }
     }
@@ -1328,7 +1504,9 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     if (hdr.has_scene_box && camera && env_flag("RTC_AMD_BLOCK_LIST", true)) {
         std::vector<uint8_t> covered;
         uint32_t tw = 0, th = 0;
-        project_heavy_boxes(std::vector<float>(hdr.scene_box, hdr.scene_box + 6), camera, &covered, &tw, &th);
+        std::vector<float> box(hdr.scene_box, hdr.scene_box + 6);
+        box.push_back(1.0f);
+        project_heavy_boxes(box, camera, &covered, &tw, &th);
         size_t n_cov = 0;
         for (uint8_t b : covered) n_cov += b;
         if (!covered.empty()) c->scene_box_coverage = (float)n_cov / (float)covered.size();

@@ -1042,6 +1042,23 @@ DI bool tri_precull(const WorldRay& wr, float4 b0, float4 b1, float4 b2) {
     const float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
     return lo > hi;
 }
+// A NODE of the library's own over part of a long run of boxed triangles (host: cluster_leaf_runs; e2.w > 0 marks it among
+// the group entries): its box is the hull of its triangles' padded boxes and its third record a vector a' with
+// |d.a'| >= TRI_GUARD |d|  =>  |d.n| >= TRI_GUARD |d| for every triangle normal n under it (the axis of a cone around
+// those normals, scaled).  A ray may pass the node by exactly when tri_precull would have skipped each of its triangles
+// one by one -- the line misses the hull, hence every box, and no triangle is near-parallel to it -- or, under the same
+// guard, when it enters the hull beyond what the caller still wants (see for_each_object).  A ray for which the guard
+// fails opens the node whatever its box says: the triangles under it take their own tests, as without the node.
+DI bool node_precull(const WorldRay& wr, float4 b0, float4 b1, float4 b2) {
+    const float dn = wr.d.x * b2.x + wr.d.y * b2.y + wr.d.z * b2.z;
+    if (!(fabsf(dn) >= wr.guard)) return false;
+    const float x0 = (b0.x - wr.o.x) * wr.inv.x, x1 = (b1.x - wr.o.x) * wr.inv.x;
+    const float y0 = (b0.y - wr.o.y) * wr.inv.y, y1 = (b1.y - wr.o.y) * wr.inv.y;
+    const float z0 = (b0.z - wr.o.z) * wr.inv.z, z1 = (b1.z - wr.o.z) * wr.inv.z;
+    const float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    const float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    return lo > hi || lo > wr.limit + (b1.w + 1e-4f * fabsf(wr.limit));
+}
 
 #ifdef RTC_NO_SHARED_WALK  // development: a pixel's lanes all walk every leaf, as before for_each_leaf_shared existed
 constexpr bool SHARED_WALK = false;
@@ -1097,7 +1114,14 @@ DI void for_each_leaf_shared(const SceneHdr& H, const SceneSoA& S, WorldRay& wr,
         if (!(r1.w < 0.0f)) {  // a group (see for_each_object): every lane of the pixel takes the same decision
             const uint32_t skip = __float_as_uint(r0.w);
             bool inside = false;
-            if (active) {
+            const RawF4 r2 = ep[2];
+            if (spec_has_tbox(H.has_tbox) && r2.w > 0.0f) {  // wave-uniform: one of the library's own nodes (node_precull)
+                if (active) {
+                    inside = !node_precull(wr, make_float4(r0.x, r0.y, r0.z, r0.w), make_float4(r1.x, r1.y, r1.z, r1.w),
+                                           make_float4(r2.x, r2.y, r2.z, r2.w));
+                    if (!inside) resume = skip;
+                }
+            } else if (active) {
                 float tmin;
                 inside = aabb_hit(wr.o, wr.inv, make_float4(r0.x, r0.y, r0.z, r0.w), make_float4(r1.x, r1.y, r1.z, r1.w), tmin);
                 if (inside && tmin > wr.limit + (r1.w + 1e-4f * fabsf(wr.limit))) inside = false;
@@ -1110,7 +1134,7 @@ DI void for_each_leaf_shared(const SceneHdr& H, const SceneSoA& S, WorldRay& wr,
             if (__any(active)) {
                 const float4* ent = S.trav + (size_t)TRAV_STRIDE * k;
                 if (spec_has_tbox(H.has_tbox) && trav_mesh_run(w)) {  // wave-uniform
-                    const uint32_t obj0 = __float_as_uint(r0.w);  // entry k + m is object obj0 + m
+                    const uint32_t obj0 = __float_as_uint(r0.w);  // the run's first object: all of them share its transform
                     const Obj ob = load_obj_static<true>(S, obj0);
                     const V3 po = obj_point(ob, wr.o), pd = obj_vector(ob, wr.d);
                     uint32_t m = sub;
@@ -1121,7 +1145,7 @@ DI void for_each_leaf_shared(const SceneHdr& H, const SceneSoA& S, WorldRay& wr,
                         float4 n0 = b0, n1 = b1, n2 = b2;
                         if (mn < run) n0 = ent[TRAV_STRIDE * mn], n1 = ent[TRAV_STRIDE * mn + 1u], n2 = ent[TRAV_STRIDE * mn + 2u];
                         if (!tri_precull(wr, b0, b1, b2)) {
-                            const uint32_t i = obj0 + m;
+                            const uint32_t i = __float_as_uint(b0.w);
                             const float4* tr = S.tri + (size_t)3u * i;
                             triangle_intersect(tr[0], tr[1], tr[2], po, pd, [&](float t) { on_tri(i, t); });
                         }
@@ -1170,7 +1194,12 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
             if (!(e1.w < 0.0f)) {  // a group: e1.w is its slack (>= 0, inf or NaN); leaves carry -1
                 const uint32_t skip = __float_as_uint(e0.w);
                 bool inside = false;
-                if (active) {
+                if (spec_has_tbox(H.has_tbox) && e2.w > 0.0f) {  // wave-uniform: one of the library's own nodes (node_precull)
+                    if (active) {
+                        inside = !node_precull(wr, e0, e1, e2);
+                        if (!inside) resume = skip;
+                    }
+                } else if (active) {
                     float tmin;
                     inside = aabb_hit(wr.o, wr.inv, e0, e1, tmin);
                     if (inside && tmin > wr.limit + (e1.w + 1e-4f * fabsf(wr.limit))) inside = false;  // nothing of interest in there
@@ -2545,6 +2574,9 @@ DI void render_body(const RenderArgs& A) {
     const uint32_t tw_log2 = 3u - (sl >> 1), th_log2 = 3u - ((sl + 1u) >> 1);
     const uint32_t x = bx0 + ((wave & 1u) << tw_log2) + (q & ((1u << tw_log2) - 1u));
     Counters cnt = {0u, 0u, sl};
+#ifdef RTC_DEBUG_TIMELINE  // development (tools/wave_timeline.py): the frame holds each wave's start / end / place instead of colours
+    const uint32_t t_start = (uint32_t)wall_clock64();
+#endif
     __shared__ float stash_lds[LDS_SLOTS * 256];
     const LaneStash stash = {stash_lds + threadIdx.x, 256u};
     // A workgroup of the regular grid renders `blocks_y` blocks, one below the other (host: frames whose waves are so
@@ -2595,6 +2627,10 @@ DI void render_body(const RenderArgs& A) {
                 col = color_at<NOBJ, SIMPLE>(H, A.soa, origin, direction, A.depth, y * H.width + x, cnt, stash);
             }
         }
+#ifdef RTC_DEBUG_TIMELINE
+        col = v3(__uint_as_float(t_start), __uint_as_float((uint32_t)wall_clock64()),
+                 __uint_as_float((__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16)));
+#endif
         if (cnt.lead()) {
             float* dst = A.out + ((size_t)yl * H.width + x) * 3;
             dst[0] = col.x;

@@ -500,7 +500,8 @@ def test_lanes_sharing_a_pixel_change_nothing(name, size, kw, share, monkeypatch
 
 
 # ------------------------------------------------- leaf-sharing tree walk + block lists (worlds with divided meshes)
-@pytest.mark.parametrize("variant", ["default", "share0", "share1", "share2", "share3", "blocks_s0", "blocks_s1", "blocks_s3", "no_block_list"])
+@pytest.mark.parametrize("variant", ["default", "share0", "share1", "share2", "share3", "blocks_s0", "blocks_s1", "blocks_s3", "no_block_list",
+                                     "image_order", "glass_s3", "nodes", "nodes_share0", "nodes_of_2_s1", "nodes_of_16_s3"])
 @pytest.mark.parametrize("name,size", [("mesh", (230, 170)), ("here_be_dragons", (250, 100)), ("mesh", (64, 610))])
 def test_lanes_splitting_leaf_runs_change_nothing(name, size, variant, monkeypatch):
     """Worlds whose GroupShapes hold long runs of leaves (the rings divide() leaves around a mesh): the 2^s lanes of a
@@ -511,7 +512,13 @@ def test_lanes_splitting_leaf_runs_change_nothing(name, size, variant, monkeypat
     world, camera, depth = getattr(scenes, name)(*size)
     env = {"default": {}, "share0": {"RTC_AMD_SHARE_LOG2": "0"}, "share1": {"RTC_AMD_SHARE_LOG2": "1"}, "share2": {"RTC_AMD_SHARE_LOG2": "2"},
            "share3": {"RTC_AMD_SHARE_LOG2": "3"}, "blocks_s0": {"RTC_AMD_BLOCK_S": "0"}, "blocks_s1": {"RTC_AMD_BLOCK_S": "1"},
-           "blocks_s3": {"RTC_AMD_BLOCK_S": "3"}, "no_block_list": {"RTC_AMD_BLOCK_LIST": "0"}}[variant]
+           "blocks_s3": {"RTC_AMD_BLOCK_S": "3"}, "no_block_list": {"RTC_AMD_BLOCK_LIST": "0"},
+           "image_order": {"RTC_AMD_BLOCK_ORDER": "0"}, "glass_s3": {"RTC_AMD_BLOCK_S": "1", "RTC_AMD_BLOCK_S_TOP": "3"},
+           # the library's own nodes over the long runs (cluster_leaf_runs; off by default in frames this small)
+           "nodes": {"RTC_AMD_CLUSTERS": "1"}, "nodes_share0": {"RTC_AMD_CLUSTERS": "1", "RTC_AMD_SHARE_LOG2": "0"},
+           "nodes_of_2_s1": {"RTC_AMD_CLUSTERS": "1", "RTC_AMD_CLUSTER_LEAF": "2", "RTC_AMD_CLUSTER_MIN_RUN": "4", "RTC_AMD_CLUSTER_GMAX": "0.99",
+                             "RTC_AMD_BLOCK_S": "1"},
+           "nodes_of_16_s3": {"RTC_AMD_CLUSTERS": "1", "RTC_AMD_CLUSTER_LEAF": "16", "RTC_AMD_BLOCK_S": "3"}}[variant]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     r = Renderer(world, camera, device=0)

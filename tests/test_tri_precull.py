@@ -96,6 +96,17 @@ def test_pre_culling_never_changes_a_ray(monkeypatch):
     off = world.color_at(o, d, 4)
     same = (on.view(np.uint32) == off.view(np.uint32)) | (np.isnan(on) & np.isnan(off))
     assert same.all(), "%d rays differ" % (~same).any(axis=1).sum()
+    # ... and with the library's own nodes over the runs of triangles (cluster_leaf_runs / node_precull: a cone of normals
+    # per node stands for the triangles' plane-angle guards), down to nodes of two and of runs as short as four
+    monkeypatch.setenv("RTC_AMD_TRI_PRECULL", "1")
+    monkeypatch.setenv("RTC_AMD_CLUSTERS", "1")
+    for leaf, min_run, gmax in (("8", "24", "0.85"), ("2", "4", "0.99")):
+        monkeypatch.setenv("RTC_AMD_CLUSTER_LEAF", leaf)
+        monkeypatch.setenv("RTC_AMD_CLUSTER_MIN_RUN", min_run)
+        monkeypatch.setenv("RTC_AMD_CLUSTER_GMAX", gmax)
+        nodes = world.color_at(o, d, 4)
+        same = (nodes.view(np.uint32) == off.view(np.uint32)) | (np.isnan(nodes) & np.isnan(off))
+        assert same.all(), "nodes (leaf %s): %d rays differ" % (leaf, (~same).any(axis=1).sum())
 
 
 @pytest.mark.parametrize("size", [(640, 480)])
@@ -122,7 +133,15 @@ def test_the_adversarial_rays_do_catch_a_naive_cull(monkeypatch):
     off = world.color_at(o, d, 4)
     monkeypatch.setenv("RTC_AMD_TRI_PRECULL", "1")
     monkeypatch.setenv("RTC_AMD_TRI_NAIVE", "1")
+    monkeypatch.setenv("RTC_AMD_CLUSTERS", "0")
     naive = world.color_at(o, d, 4)
     differ = ((naive.view(np.uint32) != off.view(np.uint32)) & ~(np.isnan(naive) & np.isnan(off))).any(axis=1).sum()
     print("rays changed by a naive cull: %d of %d" % (differ, len(o)))
+    assert differ > 0
+    # the nodes with neither guard nor padding (their cone test always passes, their boxes are hulls of unpadded boxes)
+    monkeypatch.setenv("RTC_AMD_CLUSTERS", "1")
+    monkeypatch.setenv("RTC_AMD_CLUSTER_MIN_RUN", "4")
+    naive_nodes = world.color_at(o, d, 4)
+    differ = ((naive_nodes.view(np.uint32) != off.view(np.uint32)) & ~(np.isnan(naive_nodes) & np.isnan(off))).any(axis=1).sum()
+    print("rays changed by naive nodes: %d of %d" % (differ, len(o)))
     assert differ > 0
