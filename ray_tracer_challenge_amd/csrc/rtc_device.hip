@@ -1187,6 +1187,11 @@ rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunct
     // disk cache keyed by the source text, every option, the compiler's version and the ABI the argument block follows
     std::string opt_text;
     for (const auto& o : opts) opt_text += o + "\n";
+    if (env_flag("RTC_AMD_JIT_PRINT", false)) {  // development: the options, one line, as tools/spec_asm.sh takes them
+        std::string line;
+        for (size_t i = 5; i < opts.size(); i++) line += " " + opts[i];
+        std::fprintf(stderr, "librtc_amd: scene kernel options:%s\n", line.c_str());
+    }
     int rtc_major = 0, rtc_minor = 0;
     (void)hiprtcVersion(&rtc_major, &rtc_minor);
     opt_text += "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + " abi " + std::to_string(RTC_ABI_VERSION) +
