@@ -955,6 +955,15 @@ struct Counters {
 };
 constexpr uint32_t CNT_SHADED_MASK = 0xfffu, CNT_CULLED_SHIFT = 12u;
 
+#ifdef RTC_DEBUG_STEPS  // development (tools/walk_steps.py): per lane, what the tree walks did -- the frame holds counts instead of colours
+DI uint32_t* dbg_steps() {
+    __shared__ uint32_t c[256 * 4];
+    return c + threadIdx.x * 4;
+}
+#define RTC_DBG_STEP(j) (dbg_steps()[j]++)
+#else
+#define RTC_DBG_STEP(j) ((void)0)
+#endif
 // cube.rs:90-129 aabb_intersection(..).is_some() for a world-space box: `inv` are the reciprocals Ray::new keeps
 // (ray.rs:16).  fminf / fmaxf return the non-NaN operand, as Rust's f32::min / max do.
 DI bool aabb_hit(V3 o, V3 inv, float4 mn, float4 mx, float& tmin) {
@@ -1111,7 +1120,9 @@ DI void for_each_leaf_shared(const SceneHdr& H, const SceneSoA& S, WorldRay& wr,
         const ConstF4Ptr ep = ((ConstF4Ptr)(unsigned long)S.trav) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(TRAV_STRIDE * k));
         const RawF4 r0 = ep[0], r1 = ep[1];
         const bool active = k >= resume && wr.limit > -RTC_INF;
+        RTC_DBG_STEP(3);
         if (!(r1.w < 0.0f)) {  // a group (see for_each_object): every lane of the pixel takes the same decision
+            if (active) RTC_DBG_STEP(0);
             const uint32_t skip = __float_as_uint(r0.w);
             bool inside = false;
             const RawF4 r2 = ep[2];
@@ -1144,7 +1155,9 @@ DI void for_each_leaf_shared(const SceneHdr& H, const SceneSoA& S, WorldRay& wr,
                         const uint32_t mn = m + stride;
                         float4 n0 = b0, n1 = b1, n2 = b2;
                         if (mn < run) n0 = ent[TRAV_STRIDE * mn], n1 = ent[TRAV_STRIDE * mn + 1u], n2 = ent[TRAV_STRIDE * mn + 2u];
+                        RTC_DBG_STEP(1);
                         if (!tri_precull(wr, b0, b1, b2)) {
+                            RTC_DBG_STEP(2);
                             const uint32_t i = __float_as_uint(b0.w);
                             const float4* tr = S.tri + (size_t)3u * i;
                             triangle_intersect(tr[0], tr[1], tr[2], po, pd, [&](float t) { on_tri(i, t); });
@@ -1156,7 +1169,9 @@ DI void for_each_leaf_shared(const SceneHdr& H, const SceneSoA& S, WorldRay& wr,
                     for (uint32_t m = sub; active && m < run; m += stride) {
                         const float4 b0 = ent[TRAV_STRIDE * m], b1 = ent[TRAV_STRIDE * m + 1u];  // this lane's own entry
                         bool visit = true;
+                        RTC_DBG_STEP(1);
                         if (spec_has_tbox(H.has_tbox) && b1.w == TRAV_BOXED_LEAF_TAG) visit = !tri_precull(wr, b0, b1, ent[TRAV_STRIDE * m + 2u]);
+                        if (visit) RTC_DBG_STEP(2);
                         if (visit) body(__float_as_uint(b0.w));
                     }
                 }
@@ -1191,7 +1206,9 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
             const float4 e0 = make_float4(r0.x, r0.y, r0.z, r0.w), e1 = make_float4(r1.x, r1.y, r1.z, r1.w),
                          e2 = make_float4(r2.x, r2.y, r2.z, r2.w);
             const bool active = k >= resume && wr.limit > -RTC_INF;
+            RTC_DBG_STEP(3);
             if (!(e1.w < 0.0f)) {  // a group: e1.w is its slack (>= 0, inf or NaN); leaves carry -1
+                if (active) RTC_DBG_STEP(0);
                 const uint32_t skip = __float_as_uint(e0.w);
                 bool inside = false;
                 if (spec_has_tbox(H.has_tbox) && e2.w > 0.0f) {  // wave-uniform: one of the library's own nodes (node_precull)
@@ -1217,6 +1234,13 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
                     }
                 const bool c0 = tri_precull(wr, e0, e1, e2), c1 = tri_precull(wr, f[0][0], f[0][1], f[0][2]),
                            c2 = tri_precull(wr, f[1][0], f[1][1], f[1][2]), c3 = tri_precull(wr, f[2][0], f[2][1], f[2][2]);
+#ifdef RTC_DEBUG_STEPS
+                RTC_DBG_STEP(3), RTC_DBG_STEP(3), RTC_DBG_STEP(3);
+                if (active) { RTC_DBG_STEP(1); if (!c0) RTC_DBG_STEP(2); }
+                if (k + 1u >= resume && wr.limit > -RTC_INF) { RTC_DBG_STEP(1); if (!c1) RTC_DBG_STEP(2); }
+                if (k + 2u >= resume && wr.limit > -RTC_INF) { RTC_DBG_STEP(1); if (!c2) RTC_DBG_STEP(2); }
+                if (k + 3u >= resume && wr.limit > -RTC_INF) { RTC_DBG_STEP(1); if (!c3) RTC_DBG_STEP(2); }
+#endif
                 if (active && !c0) body(__float_as_uint(e0.w));
                 if (k + 1u >= resume && wr.limit > -RTC_INF && !c1) body(__float_as_uint(f[0][0].w));
                 if (k + 2u >= resume && wr.limit > -RTC_INF && !c2) body(__float_as_uint(f[1][0].w));
@@ -1230,12 +1254,19 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
                 const float4 f0 = make_float4(q0.x, q0.y, q0.z, q0.w), f1 = make_float4(q1.x, q1.y, q1.z, q1.w),
                              f2 = make_float4(q2.x, q2.y, q2.z, q2.w);
                 const bool cull0 = tri_precull(wr, e0, e1, e2), cull1 = tri_precull(wr, f0, f1, f2);
+#ifdef RTC_DEBUG_STEPS
+                RTC_DBG_STEP(3);
+                if (active) { RTC_DBG_STEP(1); if (!cull0) RTC_DBG_STEP(2); }
+                if (k + 1u >= resume && wr.limit > -RTC_INF) { RTC_DBG_STEP(1); if (!cull1) RTC_DBG_STEP(2); }
+#endif
                 if (active && !cull0) body(__float_as_uint(e0.w));
                 if (k + 1u >= resume && wr.limit > -RTC_INF && !cull1) body(__float_as_uint(f0.w));
                 k += 2u;
             } else {
                 bool visit = active;
+                if (active) RTC_DBG_STEP(1);
                 if (spec_has_tbox(H.has_tbox) && e1.w == TRAV_BOXED_LEAF_TAG) visit = visit && !tri_precull(wr, e0, e1, e2);  // wave-uniform branch
+                if (visit) RTC_DBG_STEP(2);
                 if (visit) body(__float_as_uint(e0.w));
                 k++;
             }
@@ -2577,6 +2608,9 @@ DI void render_body(const RenderArgs& A) {
 #ifdef RTC_DEBUG_TIMELINE  // development (tools/wave_timeline.py): the frame holds each wave's start / end / place instead of colours
     const uint32_t t_start = (uint32_t)wall_clock64();
 #endif
+#ifdef RTC_DEBUG_STEPS
+    dbg_steps()[0] = dbg_steps()[1] = dbg_steps()[2] = dbg_steps()[3] = 0u;
+#endif
     __shared__ float stash_lds[LDS_SLOTS * 256];
     const LaneStash stash = {stash_lds + threadIdx.x, 256u};
     // A workgroup of the regular grid renders `blocks_y` blocks, one below the other (host: frames whose waves are so
@@ -2630,6 +2664,9 @@ DI void render_body(const RenderArgs& A) {
 #ifdef RTC_DEBUG_TIMELINE
         col = v3(__uint_as_float(t_start), __uint_as_float((uint32_t)wall_clock64()),
                  __uint_as_float((__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16)));
+#endif
+#ifdef RTC_DEBUG_STEPS  // group tests | exact tests << 20, leaf box tests, entries the WAVE stepped through
+        col = v3(__uint_as_float(dbg_steps()[0] | dbg_steps()[2] << 20), __uint_as_float(dbg_steps()[1]), __uint_as_float(dbg_steps()[3]));
 #endif
         if (cnt.lead()) {
             float* dst = A.out + ((size_t)yl * H.width + x) * 3;
