@@ -1064,6 +1064,7 @@ struct rtc_ctx {
     uint32_t blocks_for[3] = {0u, 0u, 0u};  // band_rows, n_parts, part
     bool blocks_valid = false;
     float scene_box_coverage = 1.0f;  // share of the image the scene's box projects to (1: unknown / all of it)
+    uint32_t scene_rect[4] = {0u, 0u, 0u, 0u};  // ... and the 16 x 16 tiles it projects to: [x0, x1) x [y0, y1); empty: unknown
     std::string kernel_id;            // rtc_ctx_kernel_id(): names the code object (source + options + compiler), not the scene
     std::string jit_note;             // why spec_fn is null although the policy wanted one (rtc_ctx_jit_status)
     // the scene as last uploaded: an identical one (rtc_render_ex called again for the next frame) is not uploaded twice
@@ -1506,6 +1507,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     // several blocks per workgroup (render_body) where most workgroups see nothing but the sky: the scene's box projects to
     // less than a quarter of the image
     c->scene_box_coverage = 1.0f;
+    c->scene_rect[0] = c->scene_rect[1] = c->scene_rect[2] = c->scene_rect[3] = 0u;
     if (hdr.has_scene_box && camera && env_flag("RTC_AMD_BLOCK_LIST", true)) {
         std::vector<uint8_t> covered;
         uint32_t tw = 0, th = 0;
@@ -1515,6 +1517,11 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         size_t n_cov = 0;
         for (uint8_t b : covered) n_cov += b;
         if (!covered.empty()) c->scene_box_coverage = (float)n_cov / (float)covered.size();
+        uint32_t x0 = tw, x1 = 0, y0 = th, y1 = 0;
+        for (uint32_t ty = 0; ty < th; ty++)
+            for (uint32_t tx = 0; tx < tw; tx++)
+                if (covered[(size_t)ty * tw + tx]) x0 = std::min(x0, tx), x1 = std::max(x1, tx + 1u), y0 = std::min(y0, ty), y1 = std::max(y1, ty + 1u);
+        if (x0 < x1 && y0 < y1) c->scene_rect[0] = x0, c->scene_rect[1] = x1, c->scene_rect[2] = y0, c->scene_rect[3] = y1;
     }
     c->spec_blocks_y = c->scene_box_coverage < 0.25f || std::getenv("RTC_AMD_BLOCKS_Y") != nullptr;
     const std::string share_def = std::string("-DRTC_SPEC_SHARE=") + (c->spec_shares ? "1" : "0");
@@ -1719,13 +1726,6 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         d_tiles = c->d_blocks;
         grid = dim3((uint32_t)c->blocks_host.size(), 1);
     }
-    const size_t n_blocks = (size_t)grid.x * grid.y * 4;  // partial counts: one per wave
-    if (n_blocks > c->block_cap) {  // grow-only workspace (first call / larger image only)
-        if (c->d_block_counts) HIP_TRY(hipFree(c->d_block_counts));
-        c->d_block_counts = nullptr;
-        HIP_TRY(hipMalloc(&c->d_block_counts, n_blocks * sizeof(uint4)));
-        c->block_cap = n_blocks;
-    }
     // traced pixels among this partition's rows: x < w-1, y < h-1
     uint64_t traced_rows = 0;
     {
@@ -1739,6 +1739,62 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     }
     c->last_rows = rows;
     c->last_pixels = traced_rows * (uint64_t)(c->hdr.width - 1);
+    // Scene rectangle: every primary ray outside the rectangle the scene's box projects to (project_heavy_boxes: exact
+    // camera arithmetic in double, 8 pixels of padding, "everything" if the box reaches behind the camera) sees nothing --
+    // black, one ray.  Where that rectangle is under half the frame (C5: a grid of spheres in the middle of 8192^2) the
+    // frame is zero-filled at memory speed and the kernel launched over the rectangle's blocks only; the rays of the
+    // pixels outside are added to the count (sum_counts_kernel).  RTC_AMD_SCENE_RECT=0: the whole grid, as before.
+    uint32_t block_x0 = 0u, block_y0 = 0u;
+    unsigned long long extra_rays = 0ull;
+    bool fill_first = false;
+    if (d_tiles == nullptr && share_log2 == 0u && rows > 0u && c->scene_rect[0] < c->scene_rect[1] && c->scene_box_coverage < 0.5f &&
+        env_flag("RTC_AMD_SCENE_RECT", true)) {
+        // local rows of this partition whose global row lies in the rectangle's rows, and the traced ones among them
+        const uint32_t gy0 = c->scene_rect[2] * 16u, gy1 = std::min(c->hdr.height, c->scene_rect[3] * 16u);
+        uint32_t yl0 = rows, yl1 = 0u, cursor = 0u;
+        const uint32_t n_bands = (c->hdr.height + q.band_rows - 1) / q.band_rows;
+        for (uint32_t b = q.part; b < n_bands; b += q.n_parts) {
+            const uint32_t y0 = b * q.band_rows, y1 = std::min(c->hdr.height, y0 + q.band_rows);
+            const uint32_t lo = std::max(y0, gy0), hi = std::min(y1, gy1);
+            if (lo < hi) yl0 = std::min(yl0, cursor + (lo - y0)), yl1 = std::max(yl1, cursor + (hi - y0));
+            cursor += y1 - y0;
+        }
+        if (yl0 < yl1) {
+            block_x0 = c->scene_rect[0];
+            block_y0 = yl0 / 16u;
+            blocks_y = 1u;  // every workgroup of this launch has work
+            grid = dim3(c->scene_rect[1] - c->scene_rect[0], (yl1 - block_y0 * 16u + 15u) / 16u);
+        } else {
+            grid = dim3(1, 1);  // none of this partition's rows: one block of the rectangle's columns, for the launch's bookkeeping
+            block_x0 = c->scene_rect[0];
+            block_y0 = 0u;
+            blocks_y = 1u;
+        }
+        // traced pixels (x < w - 1, y < h - 1) inside the launched blocks
+        const uint32_t lx0 = block_x0 * 16u, lx1 = std::min(c->hdr.width - 1u, (block_x0 + grid.x) * 16u);
+        const uint32_t ly0 = block_y0 * 16u, ly1 = std::min(rows, (block_y0 + grid.y) * 16u);
+        uint64_t launched_rows = 0;
+        cursor = 0u;
+        for (uint32_t b = q.part; b < n_bands; b += q.n_parts) {
+            const uint32_t y0 = b * q.band_rows, y1 = std::min(c->hdr.height, y0 + q.band_rows);
+            // local rows [cursor, cursor + y1 - y0) of this band that are launched, and traced (global row < h - 1)
+            const uint32_t a = std::max(cursor, ly0), e = std::min(cursor + (y1 - y0), ly1);
+            if (a < e) {
+                const uint32_t ga = y0 + (a - cursor), ge = y0 + (e - cursor), lim = c->hdr.height - 1u;
+                launched_rows += std::min(ge, lim) - std::min(ga, lim);
+            }
+            cursor += y1 - y0;
+        }
+        extra_rays = c->last_pixels - launched_rows * (uint64_t)(lx1 > lx0 ? lx1 - lx0 : 0u);
+        fill_first = true;
+    }
+    const size_t n_blocks = (size_t)grid.x * grid.y * 4;  // partial counts: one per wave
+    if (n_blocks > c->block_cap) {  // grow-only workspace (first call / larger image only)
+        if (c->d_block_counts) HIP_TRY(hipFree(c->d_block_counts));
+        c->d_block_counts = nullptr;
+        HIP_TRY(hipMalloc(&c->d_block_counts, n_blocks * sizeof(uint4)));
+        c->block_cap = n_blocks;
+    }
     if (rows == 0) {  // nothing to launch: the slot's counters read zero
         HIP_TRY(hipMemsetAsync(c->d_total + 3 * (size_t)slot, 0, 3 * sizeof(unsigned long long), stream));
         if (slot == 0) c->rendered = false;
@@ -1758,6 +1814,8 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     a.share_log2 = share_log2;
     a.tiles = d_tiles;
     a.blocks_y = blocks_y;
+    a.block_x0 = block_x0;
+    a.block_y0 = block_y0;
     if (c->events_used == c->events.size()) {
         if (c->events.size() >= 4096) {
             c->events_used = 0;  // nobody is reading the timings: recycle
@@ -1770,6 +1828,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     }
     auto& ev = c->events[c->events_used++];
     HIP_TRY(hipEventRecord(ev.first, stream));
+    if (fill_first) HIP_TRY(hipMemsetAsync(d_out_rgb, 0, (size_t)rows * c->hdr.width * 3 * sizeof(float), stream));
     // instantiation: <= 4 / <= 8 objects get fully unrolled object loops (SIMPLE: all of them
     // scale+translate-only, no cylinder); anything larger takes the generic loop
     if (c->spec_fn) {
@@ -1783,7 +1842,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, 0, stream, a);
     HIP_TRY(hipEventRecord(ev.second, stream));
     hipLaunchKernelGGL(sum_counts_kernel, dim3((uint32_t)((n_blocks + SUM_COUNTS_SLICE - 1) / SUM_COUNTS_SLICE)), dim3(1024), 0, stream,
-                       c->d_block_counts, (uint32_t)n_blocks, c->d_total + 3 * (size_t)slot);
+                       c->d_block_counts, (uint32_t)n_blocks, c->d_total + 3 * (size_t)slot, extra_rays);
     HIP_TRY(hipGetLastError());
     c->rendered = true;
     return RTC_OK;

@@ -2576,6 +2576,9 @@ struct RenderArgs {
     // such a frame's time is that of its slowest waves, so those start first and are cut into eight.  nullptr: regular grid.
     const uint32_t* tiles;
     uint32_t blocks_y;  // regular grid: blocks rendered by one workgroup, stacked vertically (>= 1)
+    // regular grid: the launch covers the blocks from (block_x0, block_y0) on -- a frame whose scene projects to a small
+    // rectangle is zero-filled by the host and only that rectangle rendered (rtc_device.hip: scene rectangle)
+    uint32_t block_x0, block_y0;
 };
 
 // Camera::render (camera.rs:76-91): one lane per pixel, 8x8 pixel tile per
@@ -2598,8 +2601,8 @@ DI void render_body(const RenderArgs& A) {
         bx0 = ((t >> 16) & 0x3fffu) << 2;
         by0 = (t & 0xffffu) << 2;
     } else {
-        bx0 = blockIdx.x << (4u - (sl >> 1));
-        by0 = blockIdx.y << (4u - ((sl + 1u) >> 1));
+        bx0 = (blockIdx.x + A.block_x0) << (4u - (sl >> 1));
+        by0 = (blockIdx.y + A.block_y0) << (4u - ((sl + 1u) >> 1));
     }
     const uint32_t q = lane >> sl;  // q: the pixel's slot in the wave's tile
     const uint32_t tw_log2 = 3u - (sl >> 1), th_log2 = 3u - ((sl + 1u) >> 1);
@@ -2623,7 +2626,7 @@ DI void render_body(const RenderArgs& A) {
     constexpr uint32_t blocks_y = 1u;
 #endif
     for (uint32_t rep = 0; rep < blocks_y; rep++) {
-    const uint32_t yl = (A.tiles != nullptr ? by0 : (blockIdx.y * blocks_y + rep) << (4u - ((sl + 1u) >> 1))) + ((wave >> 1) << th_log2) + (q >> tw_log2);
+    const uint32_t yl = (A.tiles != nullptr ? by0 : (blockIdx.y * blocks_y + rep + A.block_y0) << (4u - ((sl + 1u) >> 1))) + ((wave >> 1) << th_log2) + (q >> tw_log2);
     if (x < H.width && yl < A.rows) {
         // compact local row -> global row of the image
         const uint32_t band = yl / A.band_rows;
@@ -2707,9 +2710,10 @@ __global__ __launch_bounds__(256, RTC_WAVES_PER_SIMD) void render_kernel(RenderA
 // Workgroup b sums entries [b * SUM_COUNTS_SLICE, (b + 1) * SUM_COUNTS_SLICE) and adds its result to `total`, which the
 // render kernel left zeroed (one workgroup took 62 us for the 262 144 partials of an 8192^2 frame).
 constexpr uint32_t SUM_COUNTS_SLICE = 8192;
+// `extra_rays`: rays of pixels the launch did not cover (each such pixel misses the scene's box: one ray, no hit).
 __global__ __launch_bounds__(1024) void sum_counts_kernel(const uint4* __restrict__ block_counts, uint32_t n_all,
-                                                          unsigned long long* __restrict__ total) {
-    unsigned long long rays = 0, shaded = 0, culled = 0;
+                                                          unsigned long long* __restrict__ total, unsigned long long extra_rays) {
+    unsigned long long rays = (blockIdx.x == 0 && threadIdx.x == 0) ? extra_rays : 0ull, shaded = 0, culled = 0;
     const uint32_t n = min(n_all, (blockIdx.x + 1u) * SUM_COUNTS_SLICE);
     uint32_t i = blockIdx.x * SUM_COUNTS_SLICE + threadIdx.x;
     for (; i + 3 * 1024 < n; i += 4 * 1024) {  // four independent loads in flight per lane

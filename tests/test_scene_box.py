@@ -1,0 +1,105 @@
+"""Two shortcuts for primary rays of fully bounded scenes (rtc_device.hip / render_body): the SCENE BOX -- a ray that
+misses the padded box around everything is black after one counted ray, without the exact normalisation and the walk --
+and the SCENE RECTANGLE -- where that box projects to under half the frame, the frame is zero-filled and only the
+rectangle's blocks are launched, the rays of the pixels outside added to the count.  Neither is part of the reference's
+semantics (camera.rs:76-91 traces every pixel the same way): every pixel, the ray count and the shaded-hit count must
+equal the oracle's and those of a render with the shortcut switched off -- whole frames, ragged sizes, cameras that put
+the scene at an edge, partly outside or behind, and the band partitions of the multi-GPU split."""
+import numpy as np
+import pytest
+
+import ray_tracer_challenge_amd as P
+from ray_tracer_challenge_amd.renderer import Renderer
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def _world(n=5, mirror=True):
+    objs = []
+    rng = np.random.default_rng(n)
+    for i in range(n):
+        m = P.Material(color=tuple(map(float, rng.uniform(0.2, 1.0, 3))), reflective=0.4 if (mirror and i % 2) else 0.0)
+        shape = P.Cube if i % 3 == 2 else P.Sphere
+        objs.append(shape(P.chain(P.translation(float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1, 1)), float(rng.uniform(-1.5, 1.5))),
+                                  P.scaling(*map(float, rng.uniform(0.3, 0.7, 3)))), m))
+    return P.World(objs, P.PointLight(P.point(-6, 8, -9), P.color(1, 1, 1)))
+
+
+CAMERAS = {
+    # (size, from, to, field of view): where the scene's rectangle falls
+    "centre": ((401, 297), (0, 1, -14), (0, 0, 0), np.pi / 3),
+    "corner": ((390, 310), (0, 1, -14), (6.5, -4.5, 0), np.pi / 3),          # the scene in the upper left corner, cut by the frame
+    "edge_strip": ((640, 130), (0, 0.5, -20), (9.0, 0, 0), np.pi / 2.5),     # a wide frame, the scene at its left edge
+    "tiny": ((333, 333), (0, 2, -60), (0, 0, 0), np.pi / 4),                 # a few tiles in the middle
+    "inside": ((200, 150), (0.1, 0.2, 0.0), (1, 0.3, 1), np.pi / 2),         # the camera inside the box: no rectangle
+    "looking_away": ((260, 200), (0, 1, -6), (0, 1, -20), np.pi / 3),        # everything behind the camera: all black
+}
+
+
+def _render(world, camera, depth, env, monkeypatch, parts=None):
+    for k in ("RTC_AMD_SCENE_BOX", "RTC_AMD_SCENE_RECT"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r = Renderer(world, camera, device=0)
+    if parts is None:
+        img = r.render(depth).cpu().numpy()
+        st = r.stats()
+        counts = (st["rays"], st["shaded_hits"])
+    else:
+        n, band = parts
+        img = np.zeros((camera.height, camera.width, 3), f32)
+        rays = shaded = 0
+        for p in range(n):
+            got = r.render(depth, part=Renderer.partition(band, n, p)).cpu().numpy()
+            st = r.stats()
+            rays += st["rays"]
+            shaded += st["shaded_hits"]
+            cursor = 0
+            for b in range(p, (camera.height + band - 1) // band, n):
+                y0, y1 = b * band, min((b + 1) * band, camera.height)
+                img[y0:y1] = got[cursor:cursor + (y1 - y0)]
+                cursor += y1 - y0
+        counts = (rays, shaded)
+    r.close()
+    return img, counts
+
+
+@pytest.mark.parametrize("specialise", ["0", "1"])
+@pytest.mark.parametrize("cam", sorted(CAMERAS))
+def test_scene_box_and_rectangle_change_nothing(cam, specialise, monkeypatch):
+    (w, h), frm, to, fov = CAMERAS[cam]
+    world = _world()
+    camera = P.Camera(w, h, float(fov), P.view_transform(P.point(*frm), P.point(*to), P.vector(0, 1, 0)))
+    monkeypatch.setenv("RTC_AMD_SPECIALIZE", specialise)
+    exp, rays = H.oracle_camera(camera).render(H.oracle_world(world), 3, threads=8)
+    base, base_counts = _render(world, camera, 3, {"RTC_AMD_SCENE_BOX": "0", "RTC_AMD_SCENE_RECT": "0"}, monkeypatch)
+    H.assert_images_equal(base, exp, "%s: no shortcuts" % cam)
+    assert base_counts[0] == rays
+    for name, env in (("box only", {"RTC_AMD_SCENE_RECT": "0"}), ("default", {})):
+        img, counts = _render(world, camera, 3, env, monkeypatch)
+        H.assert_images_equal(img, exp, "%s: %s" % (cam, name))
+        assert counts == base_counts, (cam, name)
+    # the multi-GPU split: rows dealt out in bands, every part launches its own share of the rectangle
+    for parts in ((3, 16), (2, 64), (5, 48)):
+        img, counts = _render(world, camera, 3, {}, monkeypatch, parts=parts)
+        H.assert_images_equal(img, exp, "%s: %d parts of %d-row bands" % ((cam,) + parts))
+        assert counts == base_counts, (cam, parts)
+
+
+def test_rectangle_with_the_librarys_own_hierarchy(monkeypatch):
+    """C5's shape at a ragged size: 64 spheres (flat world, internal hierarchy, scene box, scene rectangle) from far away."""
+    from ray_tracer_challenge_amd import scenes
+    world, _, depth = scenes.sphere_grid(64, 64)
+    camera = P.Camera(517, 389, float(np.pi / 3), P.view_transform(P.point(0, 30, -40), P.point(4, 0, 7), P.vector(0, 1, 0)))
+    exp, rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=8)
+    off, off_counts = _render(world, camera, depth, {"RTC_AMD_SCENE_RECT": "0"}, monkeypatch)
+    on, on_counts = _render(world, camera, depth, {}, monkeypatch)
+    H.assert_images_equal(off, exp, "whole grid")
+    H.assert_images_equal(on, exp, "rectangle")
+    assert on_counts == off_counts and on_counts[0] == rays
+    img, counts = _render(world, camera, depth, {}, monkeypatch, parts=(4, 32))
+    H.assert_images_equal(img, exp, "rectangle, 4 parts")
+    assert counts == on_counts

@@ -41,6 +41,8 @@ def main(args):
     st = r.stats()
     px = out.cpu().numpy().view(np.uint32).reshape(h, w, 3)
     flat = px.reshape(-1, 3)
+    written = np.nonzero((flat[:, 0] != 0) | (flat[:, 1] != 0))[0]  # (pixels no wave wrote: the zero-filled part of a scene-rectangle frame)
+    flat = flat[written]
     key = flat[:, 0].astype(np.uint64) << np.uint64(32) | flat[:, 2].astype(np.uint64)
     _, first, npix = np.unique(key, return_index=True, return_counts=True)
     start = flat[first, 0].astype(np.int64)
@@ -68,7 +70,7 @@ def main(args):
     order = np.argsort(-dur)[:12]
     print("longest waves: start ms, length ms, first pixel (x, y), pixels, xcc/se/cu/simd")
     for i in order:
-        y, x = divmod(int(first[i]), w)
+        y, x = divmod(int(written[first[i]]), w)
         v = int(hw[i])
         print("  %.3f  %.3f  (%d, %d)  %d  xcc %d se %d cu %d simd %d" % (start[i] / 1e5, dur[i] / 1e5, x, y, npix[i], v >> 16, (v >> 13) & 7, (v >> 8) & 15, (v >> 4) & 3))
     # per-SIMD busy: sum of wave lengths per (xcc, se, cu, simd)
