@@ -13,6 +13,7 @@
 #include <cerrno>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -619,8 +620,15 @@ static rtc_status pack_uv_pattern(const rtc_uv_pattern& u, std::vector<float4>* 
 
 // `heavy_boxes` (optional): world-space boxes, 6 floats each, of the top-level GroupShapes that hold long runs of leaves
 // (divided meshes) -- where a frame's slow waves are (rtc_ctx_render: block list).
+// What a primary ray can see at all, for the scene rectangle (rtc_ctx_set_scene): known when every top-level entry is
+// bounded -- their padded union is `box` -- or a plane, seen only by rays that point towards it.
+struct SceneRegion {
+    bool known = false, has_box = false;
+    double box[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<std::array<double, 4>> planes;  // the plane's object-space y of a world point p: r[0] p.x + r[1] p.y + r[2] p.z + r[3]
+};
 static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHdr* hdr, std::vector<float4>* soa,
-                          std::vector<float>* texels, std::vector<float>* heavy_boxes = nullptr) {
+                          std::vector<float>* texels, std::vector<float>* heavy_boxes = nullptr, SceneRegion* region = nullptr) {
     std::vector<float4> uvrec;
     std::vector<std::pair<const float*, size_t>> seen_images;
     if (!scene) return fail(RTC_ERR_INVALID_ARG, "scene is NULL");
@@ -898,31 +906,38 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
             double lo[3], hi[3];
             bool group;
         };
-        std::vector<Entry> entries;
-        bool bounded = true;
+        std::vector<Entry> entries;  // the bounded ones
+        std::vector<std::array<double, 4>> planes;
+        bool known = true;  // every entry is bounded or a plane
         uint32_t i = 0, g = 0;
-        while (i < n && bounded) {
+        while (i < n && known) {
             while (g < scene->n_groups && (scene->groups[g].n_objects == 0 || scene->groups[g].first_object < i)) g++;  // nested / empty
             if (g < scene->n_groups && scene->groups[g].first_object == i) {
                 const rtc_group& grp = scene->groups[g];
                 Entry e;
                 e.group = true;
                 for (int a = 0; a < 3; a++) {
-                    bounded = bounded && std::isfinite(grp.bounds_min[a]) && std::isfinite(grp.bounds_max[a]);
+                    known = known && std::isfinite(grp.bounds_min[a]) && std::isfinite(grp.bounds_max[a]);
                     e.lo[a] = grp.bounds_min[a], e.hi[a] = grp.bounds_max[a];
                 }
                 entries.push_back(e);
                 i = grp.first_object + grp.n_objects;
             } else {
                 const rtc_object& o = scene->objects[i];
-                Entry e;
-                e.group = false;
-                bounded = bounded && (o.kind == RTC_SPHERE || o.kind == RTC_CUBE || o.kind == RTC_CYLINDER) && world_extent(o, e.lo, e.hi);
-                entries.push_back(e);
+                if (o.kind == RTC_PLANE) {
+                    planes.push_back({(double)o.inv[4], (double)o.inv[5], (double)o.inv[6], (double)o.inv[7]});
+                    known = known && std::isfinite(o.inv[4]) && std::isfinite(o.inv[5]) && std::isfinite(o.inv[6]) && std::isfinite(o.inv[7]);
+                } else {
+                    Entry e;
+                    e.group = false;
+                    known = known && (o.kind == RTC_SPHERE || o.kind == RTC_CUBE || o.kind == RTC_CYLINDER) && world_extent(o, e.lo, e.hi);
+                    entries.push_back(e);
+                }
                 i++;
             }
         }
-        if (bounded && env_flag("RTC_AMD_SCENE_BOX", true)) {
+        const bool bounded = known && planes.empty();
+        if (known && !entries.empty()) {
             float org[4];
             const float zero[4] = {0.0f, 0.0f, 0.0f, 1.0f};
             mat_vec4(cam->inv, zero, org);
@@ -940,12 +955,25 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
                     lo[a] = std::fmin(lo[a], e.lo[a] - pad), hi[a] = std::fmax(hi[a], e.hi[a] + pad);
                 }
             bool ok = std::isfinite(far);
+            float box[6];
             for (int a = 0; a < 3 && ok; a++) {
-                hdr->scene_box[a] = (float)lo[a];
-                hdr->scene_box[3 + a] = (float)hi[a];
-                ok = std::isfinite(hdr->scene_box[a]) && std::isfinite(hdr->scene_box[3 + a]);
+                box[a] = (float)lo[a];
+                box[3 + a] = (float)hi[a];
+                ok = std::isfinite(box[a]) && std::isfinite(box[3 + a]);
             }
-            hdr->has_scene_box = ok ? 1u : 0u;
+            if (ok && bounded && env_flag("RTC_AMD_SCENE_BOX", true)) {
+                for (int a = 0; a < 6; a++) hdr->scene_box[a] = box[a];
+                hdr->has_scene_box = 1u;
+            }
+            if (region && ok) {
+                region->has_box = true;
+                for (int a = 0; a < 6; a++) region->box[a] = box[a];
+            }
+            known = known && ok;
+        }
+        if (region) {
+            region->known = known;
+            region->planes = planes;
         }
     }
     const rtc_light& l = *scene->light;
@@ -1064,7 +1092,8 @@ struct rtc_ctx {
     uint32_t blocks_for[3] = {0u, 0u, 0u};  // band_rows, n_parts, part
     bool blocks_valid = false;
     float scene_box_coverage = 1.0f;  // share of the image the scene's box projects to (1: unknown / all of it)
-    uint32_t scene_rect[4] = {0u, 0u, 0u, 0u};  // ... and the 16 x 16 tiles it projects to: [x0, x1) x [y0, y1); empty: unknown
+    uint32_t scene_rect[4] = {0u, 0u, 0u, 0u};  // the 16 x 16 tiles outside which no primary ray sees anything: [x0, x1) x [y0, y1); empty: unknown
+    float scene_rect_coverage = 1.0f;           // ... and its share of the frame
     std::string kernel_id;            // rtc_ctx_kernel_id(): names the code object (source + options + compiler), not the scene
     std::string jit_note;             // why spec_fn is null although the policy wanted one (rtc_ctx_jit_status)
     // the scene as last uploaded: an identical one (rtc_render_ex called again for the next frame) is not uploaded twice
@@ -1386,6 +1415,44 @@ static void project_heavy_boxes(const std::vector<float>& boxes, const rtc_camer
     }
 }
 
+// A top-level plane (plane.rs:45-56) is hit by a primary ray only if the ray points towards it: with y_o the plane's
+// object-space height of the camera and y_d that of the direction, t = -y_o / y_d >= 0 needs y_d of the other sign.  The
+// direction through pixel (px, py) is linear in (px, py) (ray_for_pixel, camera.rs:60-74), hence so is y_d: the pixels that can
+// see the plane are one side of a straight line -- the horizon -- taken here with 8 pixels to spare, and marked as the 16 x 16
+// tiles of their bounding rectangle (the launch is a rectangle anyway).  A camera in the plane, or not finite: everything.
+static void mark_plane_side(const std::array<double, 4>& row, const rtc_camera* cam, std::vector<uint8_t>* tiles, uint32_t tw, uint32_t th) {
+    const float* m = cam->inv;
+    const double org[3] = {m[3], m[7], m[11]};
+    const double y_o = row[0] * org[0] + row[1] * org[1] + row[2] * org[2] + row[3];
+    // y_d(px, py) = row . M3 (half_w - (px + 0.5) s, half_h - (py + 0.5) s, -1) = a px + b py + c0
+    double col[3];  // row . (columns of the camera matrix's linear part)
+    for (int k = 0; k < 3; k++) col[k] = row[0] * m[k] + row[1] * m[4 + k] + row[2] * m[8 + k];
+    const double sz = cam->pixel_size, a = -col[0] * sz, b = -col[1] * sz;
+    const double c0 = col[0] * (cam->half_width - 0.5 * sz) + col[1] * (cam->half_height - 0.5 * sz) - col[2];
+    auto all = [&]() { std::fill(tiles->begin(), tiles->end(), (uint8_t)1); };
+    if (!std::isfinite(y_o) || !std::isfinite(a) || !std::isfinite(b) || !std::isfinite(c0) || y_o == 0.0) return all();
+    // visible where sign(y_o) * y_d < 0; keep everything with g(px, py) = sign(y_o) * y_d - margin < 0
+    const double sgn = y_o > 0.0 ? 1.0 : -1.0, margin = 8.0 * (std::fabs(a) + std::fabs(b));
+    auto g = [&](double px, double py) { return sgn * (a * px + b * py + c0) - margin; };
+    const double W = cam->width, Hh = cam->height;
+    const double cx[4] = {0.0, W, W, 0.0}, cy[4] = {0.0, 0.0, Hh, Hh};
+    double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+    for (int k = 0; k < 4; k++) {
+        const int n = (k + 1) & 3;
+        const double gk = g(cx[k], cy[k]), gn = g(cx[n], cy[n]);
+        if (gk < 0.0) x0 = std::fmin(x0, cx[k]), x1 = std::fmax(x1, cx[k]), y0 = std::fmin(y0, cy[k]), y1 = std::fmax(y1, cy[k]);
+        if ((gk < 0.0) != (gn < 0.0)) {  // the line crosses this edge of the image
+            const double t = gk / (gk - gn), ex = cx[k] + t * (cx[n] - cx[k]), ey = cy[k] + t * (cy[n] - cy[k]);
+            x0 = std::fmin(x0, ex), x1 = std::fmax(x1, ex), y0 = std::fmin(y0, ey), y1 = std::fmax(y1, ey);
+        }
+    }
+    if (!(x0 <= x1) || !(y0 <= y1)) return;  // the plane is behind every pixel's ray
+    const long tx0 = std::max(0L, (long)std::floor(x0 / 16.0) - 1), tx1 = std::min((long)tw - 1, (long)std::floor(x1 / 16.0) + 1);
+    const long ty0 = std::max(0L, (long)std::floor(y0 / 16.0) - 1), ty1 = std::min((long)th - 1, (long)std::floor(y1 / 16.0) + 1);
+    for (long ty = ty0; ty <= ty1; ty++)
+        for (long tx = tx0; tx <= tx1; tx++) (*tiles)[(size_t)ty * tw + tx] = 1;
+}
+
 // The block list of one partition (RenderArgs::tiles): the 16 x 16 tiles of the partition's compact rows, those a mesh
 // projects to first and cut into blocks of 2^mesh_share_log2 lanes per pixel (8 x 8 or 8 x 4 pixels), the others after
 // them, whole, one lane per pixel.
@@ -1451,7 +1518,8 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     std::vector<float4> soa;
     std::vector<float> texels;
     std::vector<float> heavy_boxes;
-    rtc_status st = flatten(scene, camera, &hdr, &soa, &texels, &heavy_boxes);
+    SceneRegion region;
+    rtc_status st = flatten(scene, camera, &hdr, &soa, &texels, &heavy_boxes, &region);
     if (st != RTC_OK) return st;
     HIP_TRY(hipSetDevice(c->device));
     if (c->has_scene && std::memcmp(&hdr, &c->hdr, sizeof(hdr)) == 0 && soa.size() == c->soa_host.size() &&
@@ -1517,11 +1585,31 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         size_t n_cov = 0;
         for (uint8_t b : covered) n_cov += b;
         if (!covered.empty()) c->scene_box_coverage = (float)n_cov / (float)covered.size();
+    }
+    // The scene rectangle (rtc_ctx_render): the 16 x 16 tiles in which a primary ray can see anything at all -- the padded
+    // box of the bounded top-level entries, projected, and for every top-level plane the side of its horizon on which rays
+    // point towards it.
+    c->scene_rect_coverage = 1.0f;
+    if (region.known && camera && env_flag("RTC_AMD_BLOCK_LIST", true)) {
+        std::vector<uint8_t> covered;
+        uint32_t tw = (camera->width + 15u) / 16u, th = (camera->height + 15u) / 16u;
+        if (region.has_box) {
+            std::vector<float> box(region.box, region.box + 6);
+            box.push_back(1.0f);
+            project_heavy_boxes(box, camera, &covered, &tw, &th);
+        }
+        if (covered.empty()) covered.assign((size_t)tw * th, 0);
+        for (const auto& pl : region.planes) mark_plane_side(pl, camera, &covered, tw, th);
+        size_t n_cov = 0;
         uint32_t x0 = tw, x1 = 0, y0 = th, y1 = 0;
         for (uint32_t ty = 0; ty < th; ty++)
             for (uint32_t tx = 0; tx < tw; tx++)
-                if (covered[(size_t)ty * tw + tx]) x0 = std::min(x0, tx), x1 = std::max(x1, tx + 1u), y0 = std::min(y0, ty), y1 = std::max(y1, ty + 1u);
-        if (x0 < x1 && y0 < y1) c->scene_rect[0] = x0, c->scene_rect[1] = x1, c->scene_rect[2] = y0, c->scene_rect[3] = y1;
+                if (covered[(size_t)ty * tw + tx])
+                    n_cov++, x0 = std::min(x0, tx), x1 = std::max(x1, tx + 1u), y0 = std::min(y0, ty), y1 = std::max(y1, ty + 1u);
+        if (x0 < x1 && y0 < y1) {
+            c->scene_rect[0] = x0, c->scene_rect[1] = x1, c->scene_rect[2] = y0, c->scene_rect[3] = y1;
+            c->scene_rect_coverage = (float)((double)(x1 - x0) * (y1 - y0) / ((double)tw * th));
+        }
     }
     c->spec_blocks_y = c->scene_box_coverage < 0.25f || std::getenv("RTC_AMD_BLOCKS_Y") != nullptr;
     const std::string share_def = std::string("-DRTC_SPEC_SHARE=") + (c->spec_shares ? "1" : "0");
@@ -1742,12 +1830,13 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     // Scene rectangle: every primary ray outside the rectangle the scene's box projects to (project_heavy_boxes: exact
     // camera arithmetic in double, 8 pixels of padding, "everything" if the box reaches behind the camera) sees nothing --
     // black, one ray.  Where that rectangle is under half the frame (C5: a grid of spheres in the middle of 8192^2) the
-    // frame is zero-filled at memory speed and the kernel launched over the rectangle's blocks only; the rays of the
-    // pixels outside are added to the count (sum_counts_kernel).  RTC_AMD_SCENE_RECT=0: the whole grid, as before.
+    // kernel is launched over the rectangle's blocks only, preceded by workgroups that zero-fill the rest at memory speed
+    // while the others render; the rays of the pixels outside are added to the count (sum_counts_kernel).
+    // RTC_AMD_SCENE_RECT=0: the whole grid, as before.
     uint32_t block_x0 = 0u, block_y0 = 0u;
     unsigned long long extra_rays = 0ull;
-    bool fill_first = false;
-    if (d_tiles == nullptr && share_log2 == 0u && rows > 0u && c->scene_rect[0] < c->scene_rect[1] && c->scene_box_coverage < 0.5f &&
+    uint32_t fill_wg_rows = 0u, fill_rows = 0u, fill_period = 1u, fill_rect[4] = {0u, 0u, 0u, 0u};
+    if (d_tiles == nullptr && share_log2 == 0u && rows > 0u && c->scene_rect[0] < c->scene_rect[1] && c->scene_rect_coverage < 0.9f &&
         env_flag("RTC_AMD_SCENE_RECT", true)) {
         // local rows of this partition whose global row lies in the rectangle's rows, and the traced ones among them
         const uint32_t gy0 = c->scene_rect[2] * 16u, gy1 = std::min(c->hdr.height, c->scene_rect[3] * 16u);
@@ -1789,7 +1878,16 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             cursor += y1 - y0;
         }
         extra_rays = c->last_pixels - launched_rows * (uint64_t)(lx1 > lx0 ? lx1 - lx0 : 0u);
-        fill_first = true;
+        // what the launched blocks do not cover is zero-filled by the launch's first workgroups (the kernel's fill_outside):
+        // about a thousand of them, a share of the rows each
+        fill_rect[0] = block_x0 * 16u, fill_rect[1] = std::min(c->hdr.width, (block_x0 + grid.x) * 16u);
+        fill_rect[2] = ly0, fill_rect[3] = ly1;
+        uint32_t fill_wgs = 4096u;  // C5: 0.350 / 0.329 / 0.313 / 0.329 ms with 256 / 2048 / 4096 / 16384 (RTC_AMD_FILL_WGS: development)
+        if (const char* e = std::getenv("RTC_AMD_FILL_WGS")) fill_wgs = std::max(1u, (uint32_t)std::atoi(e));
+        fill_wg_rows = std::max(1u, (fill_wgs + grid.x - 1u) / grid.x);
+        fill_rows = (rows + fill_wg_rows * grid.x - 1u) / (fill_wg_rows * grid.x);
+        fill_period = std::max(1u, (grid.y + fill_wg_rows) / fill_wg_rows);  // spread among the rendering rows: the fill shares the memory system with them
+        grid.y += fill_wg_rows;
     }
     const size_t n_blocks = (size_t)grid.x * grid.y * 4;  // partial counts: one per wave
     if (n_blocks > c->block_cap) {  // grow-only workspace (first call / larger image only)
@@ -1819,6 +1917,8 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     a.blocks_y = blocks_y;
     a.block_x0 = block_x0;
     a.block_y0 = block_y0;
+    a.fill_wg_rows = fill_wg_rows, a.fill_rows = fill_rows, a.fill_period = fill_period;
+    a.fill_x0 = fill_rect[0], a.fill_x1 = fill_rect[1], a.fill_y0 = fill_rect[2], a.fill_y1 = fill_rect[3];
     if (c->events_used == c->events.size()) {
         if (c->events.size() >= 4096) {
             c->events_used = 0;  // nobody is reading the timings: recycle
@@ -1831,7 +1931,6 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     }
     auto& ev = c->events[c->events_used++];
     HIP_TRY(hipEventRecord(ev.first, stream));
-    if (fill_first) HIP_TRY(hipMemsetAsync(d_out_rgb, 0, (size_t)rows * c->hdr.width * 3 * sizeof(float), stream));
     // instantiation: <= 4 / <= 8 objects get fully unrolled object loops (SIMPLE: all of them
     // scale+translate-only, no cylinder); anything larger takes the generic loop
     if (c->spec_fn) {

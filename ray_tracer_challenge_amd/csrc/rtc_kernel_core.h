@@ -2576,10 +2576,37 @@ struct RenderArgs {
     // such a frame's time is that of its slowest waves, so those start first and are cut into eight.  nullptr: regular grid.
     const uint32_t* tiles;
     uint32_t blocks_y;  // regular grid: blocks rendered by one workgroup, stacked vertically (>= 1)
-    // regular grid: the launch covers the blocks from (block_x0, block_y0) on -- a frame whose scene projects to a small
-    // rectangle is zero-filled by the host and only that rectangle rendered (rtc_device.hip: scene rectangle)
+    // regular grid: the launch covers the blocks from (block_x0, block_y0) on -- of a frame whose scene can only be seen
+    // inside a rectangle of pixel columns [fill_x0, fill_x1) x local rows [fill_y0, fill_y1) only that rectangle is rendered
+    // (rtc_device.hip: scene rectangle); fill_wg_rows rows of the grid, spread evenly among the rendering ones, are
+    // workgroups that zero-fill everything outside it instead, fill_rows local rows each.
     uint32_t block_x0, block_y0;
+    uint32_t fill_wg_rows, fill_rows, fill_x0, fill_x1, fill_y0, fill_y1;
+    uint32_t fill_period;  // row j * fill_period of the grid is the j-th row of filling workgroups (j < fill_wg_rows), the others render
 };
+
+// One of the launch's first workgroups (render_body): zero the part outside the scene rectangle of its share of the rows.
+// Memory-bound work running beside the arithmetic-bound rendering; 16-byte stores where rows and segments are aligned to
+// that (widths that are multiples of 4; the rectangle's columns are multiples of 16 pixels).
+DI void fill_outside(const RenderArgs& A, uint32_t fill_row) {
+    const uint32_t w = fill_row * gridDim.x + blockIdx.x, W3 = A.hdr.width * 3u;
+    const uint32_t r0 = w * A.fill_rows, r1 = min(A.rows, r0 + A.fill_rows);
+    const bool wide = (A.hdr.width & 3u) == 0u && ((unsigned long)A.out & 15ul) == 0ul;  // wave-uniform
+    for (uint32_t row = r0; row < r1; row++) {
+        float* dst = A.out + (size_t)row * W3;
+        const bool beside = row >= A.fill_y0 && row < A.fill_y1;  // a row the rectangle crosses: what is left and right of it
+        const uint32_t e0 = (beside ? A.fill_x0 : A.hdr.width) * 3u, b1 = (beside ? min(A.fill_x1, A.hdr.width) : A.hdr.width) * 3u;
+        if (wide) {
+            float4* d4 = (float4*)dst;
+            const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (uint32_t i = threadIdx.x; i < e0 / 4u; i += 256u) d4[i] = z;
+            for (uint32_t i = b1 / 4u + threadIdx.x; i < W3 / 4u; i += 256u) d4[i] = z;
+        } else {
+            for (uint32_t i = threadIdx.x; i < e0; i += 256u) dst[i] = 0.0f;
+            for (uint32_t i = b1 + threadIdx.x; i < W3; i += 256u) dst[i] = 0.0f;
+        }
+    }
+}
 
 // Camera::render (camera.rs:76-91): one lane per pixel, 8x8 pixel tile per
 // wave, 2x2 waves per 256-thread workgroup.  NOBJ: see for_each_object.
@@ -2604,6 +2631,17 @@ DI void render_body(const RenderArgs& A) {
         bx0 = (blockIdx.x + A.block_x0) << (4u - (sl >> 1));
         by0 = (blockIdx.y + A.block_y0) << (4u - ((sl + 1u) >> 1));
     }
+    // wave-uniform: is this one of the workgroups that zero-fill (it renders nothing), and which row of the rendering
+    // grid is it otherwise?
+    bool fills = false;
+    uint32_t grid_y = blockIdx.y;
+    if (A.tiles == nullptr && A.fill_wg_rows != 0u) {
+        const uint32_t j = blockIdx.y / A.fill_period;
+        fills = j < A.fill_wg_rows && blockIdx.y == j * A.fill_period;
+        if (fills) grid_y = j;
+        else grid_y = blockIdx.y - min(A.fill_wg_rows, j + 1u);
+        by0 = (grid_y + A.block_y0) << (4u - ((sl + 1u) >> 1));
+    }
     const uint32_t q = lane >> sl;  // q: the pixel's slot in the wave's tile
     const uint32_t tw_log2 = 3u - (sl >> 1), th_log2 = 3u - ((sl + 1u) >> 1);
     const uint32_t x = bx0 + ((wave & 1u) << tw_log2) + (q & ((1u << tw_log2) - 1u));
@@ -2625,9 +2663,10 @@ DI void render_body(const RenderArgs& A) {
 #else
     constexpr uint32_t blocks_y = 1u;
 #endif
+    if (fills) fill_outside(A, grid_y);
     for (uint32_t rep = 0; rep < blocks_y; rep++) {
-    const uint32_t yl = (A.tiles != nullptr ? by0 : (blockIdx.y * blocks_y + rep + A.block_y0) << (4u - ((sl + 1u) >> 1))) + ((wave >> 1) << th_log2) + (q >> tw_log2);
-    if (x < H.width && yl < A.rows) {
+    const uint32_t yl = (A.tiles != nullptr ? by0 : (grid_y * blocks_y + rep + A.block_y0) << (4u - ((sl + 1u) >> 1))) + ((wave >> 1) << th_log2) + (q >> tw_log2);
+    if (!fills && x < H.width && yl < A.rows) {
         // compact local row -> global row of the image
         const uint32_t band = yl / A.band_rows;
         const uint32_t y = (band * A.n_parts + A.part) * A.band_rows + (yl - band * A.band_rows);

@@ -1,7 +1,8 @@
 """Two shortcuts for primary rays of fully bounded scenes (rtc_device.hip / render_body): the SCENE BOX -- a ray that
 misses the padded box around everything is black after one counted ray, without the exact normalisation and the walk --
-and the SCENE RECTANGLE -- where that box projects to under half the frame, the frame is zero-filled and only the
-rectangle's blocks are launched, the rays of the pixels outside added to the count.  Neither is part of the reference's
+and the SCENE RECTANGLE -- where the pixels that can see anything (that box, and the near side of every top-level plane's
+horizon) lie within a rectangle smaller than the frame, only that rectangle's blocks are rendered, other workgroups of the
+same launch zero-fill the rest, and the rays of the pixels outside are added to the count.  Neither is part of the reference's
 semantics (camera.rs:76-91 traces every pixel the same way): every pixel, the ray count and the shaded-hit count must
 equal the oracle's and those of a render with the shortcut switched off -- whole frames, ragged sizes, cameras that put
 the scene at an edge, partly outside or behind, and the band partitions of the multi-GPU split."""
@@ -87,6 +88,44 @@ def test_scene_box_and_rectangle_change_nothing(cam, specialise, monkeypatch):
         img, counts = _render(world, camera, 3, {}, monkeypatch, parts=parts)
         H.assert_images_equal(img, exp, "%s: %d parts of %d-row bands" % ((cam,) + parts))
         assert counts == base_counts, (cam, parts)
+
+
+PLANE_CAMERAS = {
+    # (size, from, to, up, field of view) over a floor (and for some a wall) plane: where the horizon falls
+    "horizon_mid": ((402, 300), (0, 2, -10), (0, 1.5, 0), (0, 1, 0), np.pi / 3),
+    "rolled": ((391, 283), (0, 2, -10), (0, 1.0, 0), (0.5, 1, 0.1), np.pi / 3),        # the horizon is a slanted line
+    "looking_up": ((300, 220), (0, 1, -6), (0, 9, 0), (0, 1, 0), np.pi / 4),          # the floor below the frame: only the box
+    "looking_down": ((280, 260), (0, 8, -3), (0, 0, 0), (0, 0, 1), np.pi / 3),        # floor everywhere
+    "under_the_floor": ((260, 200), (0, -3, -8), (0, 2, 0), (0, 1, 0), np.pi / 3),    # camera on the floor's other side
+    "grazing": ((420, 120), (0, 0.02, -10), (0, 0.02, 0), (0, 1, 0), np.pi / 2.2),    # eye almost in the plane
+}
+
+
+@pytest.mark.parametrize("wall", [False, True])
+@pytest.mark.parametrize("cam", sorted(PLANE_CAMERAS))
+def test_rectangle_with_planes_changes_nothing(cam, wall, monkeypatch):
+    """Top-level planes: a primary ray sees a plane only on one side of its horizon, so the scene rectangle is the box of
+    the bounded objects plus that side (mark_plane_side).  A rolled camera, a camera under the floor, one that looks away
+    from it, one almost in it; a second plane (a tilted wall) whose horizon crosses the first's."""
+    (w, h), frm, to, up, fov = PLANE_CAMERAS[cam]
+    world = _world(4)
+    objs = list(world.objects)
+    objs.insert(1, P.Plane(P.identity_4x4(), P.Material(color=(0.7, 0.7, 0.6), reflective=0.3)))
+    if wall:
+        objs.append(P.Plane(P.chain(P.translation(0, 0, 6), P.rotation_y(f32(0.4)), P.rotation_x(f32(np.pi / 2.3))), P.Material(color=(0.3, 0.5, 0.8))))
+    world = P.World(objs, world.light)
+    camera = P.Camera(w, h, float(fov), P.view_transform(P.point(*frm), P.point(*to), P.vector(*up)))
+    exp, rays = H.oracle_camera(camera).render(H.oracle_world(world), 3, threads=8)
+    off, off_counts = _render(world, camera, 3, {"RTC_AMD_SCENE_RECT": "0"}, monkeypatch)
+    H.assert_images_equal(off, exp, "%s: whole grid" % cam)
+    assert off_counts[0] == rays
+    on, on_counts = _render(world, camera, 3, {}, monkeypatch)
+    H.assert_images_equal(on, exp, "%s: rectangle" % cam)
+    assert on_counts == off_counts
+    for parts in ((3, 16), (2, 64)):
+        img, counts = _render(world, camera, 3, {}, monkeypatch, parts=parts)
+        H.assert_images_equal(img, exp, "%s: %d parts of %d-row bands" % ((cam,) + parts))
+        assert counts == off_counts, (cam, parts)
 
 
 def test_rectangle_with_the_librarys_own_hierarchy(monkeypatch):
