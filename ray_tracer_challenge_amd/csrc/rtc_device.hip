@@ -268,6 +268,14 @@ static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows) {
     return s;
 }
 
+// The share of the frame below which a scene's rectangle is launched instead of the whole grid (rtc_ctx_render).
+// RTC_AMD_SCENE_RECT=0: never; =2: whenever there is a rectangle (tests: every shape of it, whatever it is worth).
+static float scene_rect_threshold() {
+    const char* e = std::getenv("RTC_AMD_SCENE_RECT");
+    if (e && e[0] == '0') return 0.0f;
+    if (e && e[0] == '2') return 1.01f;
+    return 0.5f;
+}
 static bool env_flag(const char* name, bool dflt) {
     const char* e = std::getenv(name);
     return (e && *e) ? e[0] != '0' : dflt;
@@ -1080,6 +1088,7 @@ struct rtc_ctx {
     size_t ppm_rows_cap = 0, ppm_bits_cap = 0;
     bool spec_shares = false;         // spec_fn was compiled with -DRTC_SPEC_SHARE=1
     bool spec_blocks_y = false;       // ... with -DRTC_SPEC_BLOCKS_Y=1 (several blocks per workgroup)
+    bool spec_rect = false;           // ... with -DRTC_SPEC_RECT=1 (scene rectangle launches: block offsets, zero-filling workgroups)
     hipFunction_t spec_fn = nullptr;  // scene-specialised kernel (hiprtc), or null: ahead-of-time kernels
     std::string kernel_name;          // what rtc_ctx_render launches, for rtc_ctx_kernel_name()
     // Block list of the current scene (RenderArgs::tiles): which 16 x 16 pixel tiles of the image a mesh projects to
@@ -1610,10 +1619,18 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
             c->scene_rect[0] = x0, c->scene_rect[1] = x1, c->scene_rect[2] = y0, c->scene_rect[3] = y1;
             c->scene_rect_coverage = (float)((double)(x1 - x0) * (y1 - y0) / ((double)tw * th));
         }
+        if (env_flag("RTC_AMD_JIT_PRINT", false))
+            std::fprintf(stderr, "librtc_amd: scene rectangle tiles [%u, %u) x [%u, %u) of %u x %u: %.3f of the frame\n", x0, x1, y0, y1, tw, th,
+                         c->scene_rect_coverage);
     }
     c->spec_blocks_y = c->scene_box_coverage < 0.25f || std::getenv("RTC_AMD_BLOCKS_Y") != nullptr;
     const std::string share_def = std::string("-DRTC_SPEC_SHARE=") + (c->spec_shares ? "1" : "0");
+    // Scene rectangle launches need a few more argument loads and operations in front of every wave, which cost frames of
+    // short waves 6 - 10 % (first_plane, first_patterns; C4 0.610 -> 0.648 ms, more than the 3 % its sky rows are worth): only
+    // where the rectangle is under half the frame (C5, single_sphere) is the scene's kernel compiled with them.
+    c->spec_rect = c->scene_rect[0] < c->scene_rect[1] && c->scene_rect_coverage < scene_rect_threshold();
     const std::string blocks_def = std::string("-DRTC_SPEC_BLOCKS_Y=") + (c->spec_blocks_y ? "1" : "0");
+    const std::string rect_def = std::string("-DRTC_SPEC_RECT=") + (c->spec_rect ? "1" : "0");
     // Material facts (rtc_kernel_core.h): does any material reflect / transmit at all (a scene without either carries no
     // recursion code), does any need powf for a highlight, and how many levels of the recursion stack the kernel keeps in
     // registers (FrameStack).  Register levels were built to take the 2.5 GB of frame traffic out of the glass-and-mirror
@@ -1671,6 +1688,8 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
                                              std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
             defs.push_back(share_def);
             defs.push_back(blocks_def);
+        defs.push_back(rect_def);
+            defs.push_back(rect_def);
             defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
             rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
             if (jst != RTC_OK) {
@@ -1703,6 +1722,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         defs.push_back(std::string("-DRTC_SPEC_GATES=") + (hdr.n_gates ? "1" : "0"));
         defs.push_back(share_def);
         defs.push_back(blocks_def);
+        defs.push_back(rect_def);
         defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
         if (reg_waves) defs.push_back(reg_waves);
         // A point light has no sample loop to keep registers free for: cold state stays in VGPRs instead of being parked
@@ -1746,6 +1766,8 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
                                              std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
             defs.push_back(share_def);
             defs.push_back(blocks_def);
+        defs.push_back(rect_def);
+            defs.push_back(rect_def);
             if (reg_waves) defs.push_back(reg_waves);
             defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
             rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
@@ -1836,8 +1858,8 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     uint32_t block_x0 = 0u, block_y0 = 0u;
     unsigned long long extra_rays = 0ull;
     uint32_t fill_wg_rows = 0u, fill_rows = 0u, fill_period = 1u, fill_rect[4] = {0u, 0u, 0u, 0u};
-    if (d_tiles == nullptr && share_log2 == 0u && rows > 0u && c->scene_rect[0] < c->scene_rect[1] && c->scene_rect_coverage < 0.9f &&
-        env_flag("RTC_AMD_SCENE_RECT", true)) {
+    if (d_tiles == nullptr && share_log2 == 0u && rows > 0u && c->scene_rect[0] < c->scene_rect[1] && c->scene_rect_coverage < scene_rect_threshold() &&
+        (c->spec_fn == nullptr || c->spec_rect)) {
         // local rows of this partition whose global row lies in the rectangle's rows, and the traced ones among them
         const uint32_t gy0 = c->scene_rect[2] * 16u, gy1 = std::min(c->hdr.height, c->scene_rect[3] * 16u);
         uint32_t yl0 = rows, yl1 = 0u, cursor = 0u;

@@ -2628,19 +2628,32 @@ DI void render_body(const RenderArgs& A) {
         bx0 = ((t >> 16) & 0x3fffu) << 2;
         by0 = (t & 0xffffu) << 2;
     } else {
-        bx0 = (blockIdx.x + A.block_x0) << (4u - (sl >> 1));
-        by0 = (blockIdx.y + A.block_y0) << (4u - ((sl + 1u) >> 1));
+        bx0 = blockIdx.x << (4u - (sl >> 1));
+        by0 = blockIdx.y << (4u - ((sl + 1u) >> 1));
     }
-    // wave-uniform: is this one of the workgroups that zero-fill (it renders nothing), and which row of the rendering
-    // grid is it otherwise?
+    // Scene rectangle launches (the ahead-of-time kernels, and scene kernels compiled with -DRTC_SPEC_RECT=1: the few
+    // extra argument loads and operations in front of every wave cost the frames of very short waves 6 - 10 % --
+    // first_plane, first_patterns -- so kernels of scenes that have no use for it do not carry them): is this one of the
+    // workgroups that zero-fill (wave-uniform; it renders nothing), and which block of the rendering grid is it otherwise?
+#if !defined(RTC_SPEC_LIST) || (defined(RTC_SPEC_RECT) && RTC_SPEC_RECT)
+    constexpr bool RECT_LAUNCH = true;
+#else
+    constexpr bool RECT_LAUNCH = false;
+#endif
     bool fills = false;
-    uint32_t grid_y = blockIdx.y;
-    if (A.tiles == nullptr && A.fill_wg_rows != 0u) {
-        const uint32_t j = blockIdx.y / A.fill_period;
-        fills = j < A.fill_wg_rows && blockIdx.y == j * A.fill_period;
-        if (fills) grid_y = j;
-        else grid_y = blockIdx.y - min(A.fill_wg_rows, j + 1u);
-        by0 = (grid_y + A.block_y0) << (4u - ((sl + 1u) >> 1));
+    uint32_t grid_y = blockIdx.y, block_y0 = 0u;
+    if constexpr (RECT_LAUNCH) {
+        if (A.tiles == nullptr) {
+            block_y0 = A.block_y0;
+            if (A.fill_wg_rows != 0u) {
+                const uint32_t j = blockIdx.y / A.fill_period;
+                fills = j < A.fill_wg_rows && blockIdx.y == j * A.fill_period;
+                if (fills) grid_y = j;
+                else grid_y = blockIdx.y - min(A.fill_wg_rows, j + 1u);
+            }
+            bx0 = (blockIdx.x + A.block_x0) << (4u - (sl >> 1));
+            by0 = (grid_y + block_y0) << (4u - ((sl + 1u) >> 1));
+        }
     }
     const uint32_t q = lane >> sl;  // q: the pixel's slot in the wave's tile
     const uint32_t tw_log2 = 3u - (sl >> 1), th_log2 = 3u - ((sl + 1u) >> 1);
@@ -2663,10 +2676,12 @@ DI void render_body(const RenderArgs& A) {
 #else
     constexpr uint32_t blocks_y = 1u;
 #endif
-    if (fills) fill_outside(A, grid_y);
+    if constexpr (RECT_LAUNCH) {
+        if (fills) fill_outside(A, grid_y);
+    }
     for (uint32_t rep = 0; rep < blocks_y; rep++) {
-    const uint32_t yl = (A.tiles != nullptr ? by0 : (grid_y * blocks_y + rep + A.block_y0) << (4u - ((sl + 1u) >> 1))) + ((wave >> 1) << th_log2) + (q >> tw_log2);
-    if (!fills && x < H.width && yl < A.rows) {
+    const uint32_t yl = (A.tiles != nullptr ? by0 : (grid_y * blocks_y + rep + block_y0) << (4u - ((sl + 1u) >> 1))) + ((wave >> 1) << th_log2) + (q >> tw_log2);
+    if ((!RECT_LAUNCH || !fills) && x < H.width && yl < A.rows) {
         // compact local row -> global row of the image
         const uint32_t band = yl / A.band_rows;
         const uint32_t y = (band * A.n_parts + A.part) * A.band_rows + (yl - band * A.band_rows);

@@ -79,13 +79,13 @@ def test_scene_box_and_rectangle_change_nothing(cam, specialise, monkeypatch):
     base, base_counts = _render(world, camera, 3, {"RTC_AMD_SCENE_BOX": "0", "RTC_AMD_SCENE_RECT": "0"}, monkeypatch)
     H.assert_images_equal(base, exp, "%s: no shortcuts" % cam)
     assert base_counts[0] == rays
-    for name, env in (("box only", {"RTC_AMD_SCENE_RECT": "0"}), ("default", {})):
+    for name, env in (("box only", {"RTC_AMD_SCENE_RECT": "0"}), ("default", {}), ("rectangle whatever its size", {"RTC_AMD_SCENE_RECT": "2"})):
         img, counts = _render(world, camera, 3, env, monkeypatch)
         H.assert_images_equal(img, exp, "%s: %s" % (cam, name))
         assert counts == base_counts, (cam, name)
     # the multi-GPU split: rows dealt out in bands, every part launches its own share of the rectangle
     for parts in ((3, 16), (2, 64), (5, 48)):
-        img, counts = _render(world, camera, 3, {}, monkeypatch, parts=parts)
+        img, counts = _render(world, camera, 3, {"RTC_AMD_SCENE_RECT": "2"}, monkeypatch, parts=parts)
         H.assert_images_equal(img, exp, "%s: %d parts of %d-row bands" % ((cam,) + parts))
         assert counts == base_counts, (cam, parts)
 
@@ -119,11 +119,13 @@ def test_rectangle_with_planes_changes_nothing(cam, wall, monkeypatch):
     off, off_counts = _render(world, camera, 3, {"RTC_AMD_SCENE_RECT": "0"}, monkeypatch)
     H.assert_images_equal(off, exp, "%s: whole grid" % cam)
     assert off_counts[0] == rays
-    on, on_counts = _render(world, camera, 3, {}, monkeypatch)
-    H.assert_images_equal(on, exp, "%s: rectangle" % cam)
-    assert on_counts == off_counts
+    # (RTC_AMD_SCENE_RECT=2: the rectangle is launched whatever its share of the frame -- by default only under half of it)
+    for env in ({}, {"RTC_AMD_SCENE_RECT": "2"}):
+        on, on_counts = _render(world, camera, 3, env, monkeypatch)
+        H.assert_images_equal(on, exp, "%s: rectangle %s" % (cam, env))
+        assert on_counts == off_counts
     for parts in ((3, 16), (2, 64)):
-        img, counts = _render(world, camera, 3, {}, monkeypatch, parts=parts)
+        img, counts = _render(world, camera, 3, {"RTC_AMD_SCENE_RECT": "2"}, monkeypatch, parts=parts)
         H.assert_images_equal(img, exp, "%s: %d parts of %d-row bands" % ((cam,) + parts))
         assert counts == off_counts, (cam, parts)
 
