@@ -875,6 +875,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         const bool clusters_pay = cam && choose_share_log2_runs(((uint64_t)cam->width * cam->height + 63) / 64) <= 1u;
         if (hdr->has_tbox && (hdr->max_leaf_run >= 24u || std::getenv("RTC_AMD_CLUSTER_MIN_RUN")) && env_flag("RTC_AMD_CLUSTERS", clusters_pay)) {
             cluster_leaf_runs(&trav, (double)hdr->tri_guard);
+            hdr->has_tbox = 2;  // ... and the walks look for nodes among the group entries (spec_has_nodes)
             mark_pairs();
             (void)mark_leaf_runs(&trav, scene);  // (max_leaf_run keeps the length of the reference's runs: what the launch policy goes by)
         }
@@ -1682,7 +1683,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
                                              uniform ? std::string("-DRTC_SPEC_UNIFORM_BITS=") + b : std::string("-DRTC_SPEC_RUNTIME_BITS=1"),
                                              "-DRTC_SPEC_NOBJ=-1", "-DRTC_SPEC_SIMPLE=0",
                                              reg_waves ? std::string(reg_waves) : "-DRTC_WAVES_PER_SIMD=" + tree_jit_waves(),
-                                             std::string("-DRTC_SPEC_TBOX=") + (hdr.has_tbox ? "1" : "0"),
+                                             std::string("-DRTC_SPEC_TBOX=") + std::to_string(hdr.has_tbox),
                                              "-DRTC_SPEC_LIGHT_KIND=" + std::to_string(hdr.light_kind),
                                              "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
                                              std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
@@ -1904,7 +1905,10 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         // about a thousand of them, a share of the rows each
         fill_rect[0] = block_x0 * 16u, fill_rect[1] = std::min(c->hdr.width, (block_x0 + grid.x) * 16u);
         fill_rect[2] = ly0, fill_rect[3] = ly1;
-        uint32_t fill_wgs = 4096u;  // C5: 0.350 / 0.329 / 0.313 / 0.329 ms with 256 / 2048 / 4096 / 16384 (RTC_AMD_FILL_WGS: development)
+        // about 160 KB of zeros per workgroup -- C5 (805 MB): 0.350 / 0.329 / 0.313 / 0.329 ms with 256 / 2048 / 4096 / 16384 of
+        // them; a frame of 4096 blocks must not get as many again (RTC_AMD_FILL_WGS: development)
+        const uint64_t frame_bytes = (uint64_t)rows * c->hdr.width * 12u;
+        uint32_t fill_wgs = (uint32_t)std::min<uint64_t>(4096u, std::max<uint64_t>(16u, frame_bytes / (160u << 10)));
         if (const char* e = std::getenv("RTC_AMD_FILL_WGS")) fill_wgs = std::max(1u, (uint32_t)std::atoi(e));
         fill_wg_rows = std::max(1u, (fill_wgs + grid.x - 1u) / grid.x);
         fill_rows = (rows + fill_wg_rows * grid.x - 1u) / (fill_wg_rows * grid.x);

@@ -599,8 +599,10 @@ DI int32_t spec_jitter_mode(int32_t) { return RTC_SPEC_JITTER; }
 DI bool spec_has_patterns(uint32_t) { return RTC_SPEC_PATTERNS != 0; }
 #ifdef RTC_SPEC_TBOX
 DI bool spec_has_tbox(uint32_t) { return RTC_SPEC_TBOX != 0; }  // the scene has pre-culling boxes (tree walks)
+DI bool spec_has_nodes(uint32_t) { return RTC_SPEC_TBOX >= 2; }  // ... and nodes of the library's own among its entries (has_tbox == 2)
 #else
 DI bool spec_has_tbox(uint32_t h) { return h != 0; }
+DI bool spec_has_nodes(uint32_t h) { return h >= 2u; }
 #endif
 #ifdef RTC_SPEC_GATES
 DI bool spec_has_gates(uint32_t) { return RTC_SPEC_GATES != 0; }
@@ -614,6 +616,7 @@ DI int32_t spec_jitter_mode(int32_t m) { return m; }
 DI bool spec_has_patterns(uint32_t h) { return h != 0; }
 DI bool spec_has_gates(uint32_t n) { return n != 0; }
 DI bool spec_has_tbox(uint32_t h) { return h != 0; }
+DI bool spec_has_nodes(uint32_t h) { return h >= 2u; }
 #endif
 
 // Scene facts a scene-compiled kernel knows (hiprtc, -DRTC_SPEC_ANY_REFL / _ANY_REFR / _REG_LEVELS): whether any material
@@ -1125,8 +1128,8 @@ DI void for_each_leaf_shared(const SceneHdr& H, const SceneSoA& S, WorldRay& wr,
             if (active) RTC_DBG_STEP(0);
             const uint32_t skip = __float_as_uint(r0.w);
             bool inside = false;
-            const RawF4 r2 = ep[2];
-            if (spec_has_tbox(H.has_tbox) && r2.w > 0.0f) {  // wave-uniform: one of the library's own nodes (node_precull)
+            if (spec_has_nodes(H.has_tbox) && ep[2].w > 0.0f) {  // wave-uniform: one of the library's own nodes (node_precull)
+                const RawF4 r2 = ep[2];
                 if (active) {
                     inside = !node_precull(wr, make_float4(r0.x, r0.y, r0.z, r0.w), make_float4(r1.x, r1.y, r1.z, r1.w),
                                            make_float4(r2.x, r2.y, r2.z, r2.w));
@@ -1211,7 +1214,7 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
                 if (active) RTC_DBG_STEP(0);
                 const uint32_t skip = __float_as_uint(e0.w);
                 bool inside = false;
-                if (spec_has_tbox(H.has_tbox) && e2.w > 0.0f) {  // wave-uniform: one of the library's own nodes (node_precull)
+                if (spec_has_nodes(H.has_tbox) && e2.w > 0.0f) {  // wave-uniform: one of the library's own nodes (node_precull)
                     if (active) {
                         inside = !node_precull(wr, e0, e1, e2);
                         if (!inside) resume = skip;
