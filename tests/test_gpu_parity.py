@@ -541,3 +541,30 @@ def test_lanes_splitting_leaf_runs_change_nothing(name, size, variant, monkeypat
         cursor[p] += y1 - y0
     assert np.array_equal(got, img)
     r.close()
+
+
+@pytest.mark.parametrize("name", ["mesh", "here_be_dragons"])
+def test_nodes_at_a_frame_size_that_builds_them_by_default(name, monkeypatch):
+    """Frames of more than 40 k waves are traced by two lanes per pixel in the mesh tiles and get the library's own nodes
+    over their long triangle runs by default (rtc_device.hip: clusters_pay).  The small frames above force them on and
+    compare with the oracle; here the default policy itself runs and is compared with the same frame without nodes."""
+    from ray_tracer_challenge_amd.renderer import Renderer
+    world, camera, depth = getattr(scenes, name)(2048, 1296)
+    out = {}
+    for mode in ("default", "0"):
+        if mode == "default":
+            monkeypatch.delenv("RTC_AMD_CLUSTERS", raising=False)
+        else:
+            monkeypatch.setenv("RTC_AMD_CLUSTERS", mode)
+        r = Renderer(world, camera, device=0)
+        img = r.render(depth).cpu().numpy()
+        st = r.stats()
+        out[mode] = (img, st["rays"], st["shaded_hits"])
+        r.close()
+    assert np.array_equal(out["default"][0].view(np.uint32), out["0"][0].view(np.uint32))
+    assert out["default"][1:] == out["0"][1:]
+    # row ranges against the oracle (through the middle of the meshes, and the frame's edges)
+    oc, ow = H.oracle_camera(camera), H.oracle_world(world)
+    for y0, y1 in ((0, 4), (560, 572), (700, 708), (1290, 1296)):
+        exp, _ = oc.render(ow, depth, threads=8, rows=(y0, y1))
+        H.assert_images_equal(out["default"][0][y0:y1], exp[y0:y1], "%s rows %d..%d" % (name, y0, y1))
