@@ -263,9 +263,11 @@ static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows) {
     // waves) 1.33 / 0.93 / 0.77, 2000 x 800 (25 k) 1.61 / 1.41 / 1.50, 4000 x 1600 (100 k) 3.25 / 3.57 / 4.80; mesh 512 x 384
     // (3 k) 3.81 / 2.54 / 2.05, 1024^2 (16 k) 3.12 / 2.58 / 3.13, 2048^2 (65 k) 3.65 / 4.37 / 5.86, 4096^2 (262 k) 8.5 / 11.1 / 16.8
     if (runs) return choose_share_log2_runs(waves);
-    uint32_t s = 0;
-    while (s < 3u && (waves << s) < 24576u) s++;
-    return s;
+    // area lights, measured on soft_shadows (ms with 1 / 2 / 4 / 8 lanes per pixel): 512^2 (4 k waves) - / - / 0.119 / 0.084;
+    // 1000 x 400 (6 k) - / 0.193 / 0.134 / 0.145; 700^2 (8 k) 0.396 / 0.242 / 0.158 / 0.130; 1024^2 (16 k) 0.317 / 0.204 / 0.150 / -;
+    // 1536^2 (37 k) 0.346 / 0.248 / 0.308 / 0.49; 2048^2 (66 k) 0.366 / 0.38 / 0.50 / 0.81: a frame's time is its throughput or
+    // its longest wave, whichever is longer, and a wave of 64 pixels x 100 samples is long
+    return waves < 6144u ? 3u : waves < 24000u ? 2u : waves < 50000u ? 1u : 0u;
 }
 
 // The share of the frame below which a scene's rectangle is launched instead of the whole grid (rtc_ctx_render).
