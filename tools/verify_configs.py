@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Every timed configuration, whole frame, against the CPU oracle on all host threads (one-off check; the test suite
+compares the BASELINE configurations at full size and the demo scenes at small sizes).  Prints one line per scene."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ray_tracer_challenge_amd import scenes
+from ray_tracer_challenge_amd.renderer import Renderer
+from tests import helpers as H
+
+CASES = [("soft_shadows", (1000, 400)), ("single_sphere", (1024, 1024)), ("soft_shadows", (4096, 4096)), ("glass_and_mirror", (4096, 4096)),
+         ("sphere_grid", (8192, 8192)), ("first_scene", (4096, 2048)), ("first_plane", (4096, 2048)), ("first_patterns", (4096, 2048)),
+         ("reflect_refract", (4096, 2048)), ("hexagons", (4096, 2048)), ("first_textures", (4096, 2048)), ("skybox", (4096, 2048)),
+         ("grouped_grid", (4096, 4096)), ("mesh", (2048, 2048)), ("mesh", (512, 384)), ("here_be_dragons", (1000, 400)),
+         ("here_be_dragons", (4000, 1600)), ("soft_shadows", (1024, 1024)), ("soft_shadows", (1536, 1536))]
+only = sys.argv[1:]
+threads = os.cpu_count() or 8
+bad = 0
+for name, size in CASES:
+    if only and name not in only:
+        continue
+    world, camera, depth = getattr(scenes, name)(*size)
+    r = Renderer(world, camera, device=0)
+    img = r.render(depth).cpu().numpy()
+    st = r.stats()
+    r.close()
+    t0 = time.time()
+    exp, rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=threads)
+    dt = time.time() - t0
+    same = np.array_equal(img.view(np.uint32), exp.view(np.uint32)) or bool(((img == exp) | (np.isnan(img) & np.isnan(exp))).all())
+    ok = same and st["rays"] == rays
+    bad += not ok
+    print("%-18s %5dx%-5d %s  rays %d %s  (oracle %.1f s on %d threads)" % (
+        name, size[0], size[1], "every pixel equal" if same else "PIXELS DIFFER: %d" % int((img != exp).any(axis=2).sum()), st["rays"],
+        "==" if st["rays"] == rays else "!= %d" % rays, dt, threads), flush=True)
+print("%d scene(s) differ" % bad)
+sys.exit(1 if bad else 0)
