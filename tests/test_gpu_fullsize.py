@@ -235,3 +235,20 @@ def test_device_ppm_formatter(torch):
     assert text == ref
     assert text.startswith(b"P3\n4096 4096\n255\n") and len(text) > 100_000_000
     print("\nto_ppm 4096^2: device formatter + D2H %.3f s, host writer %.3f s, %d bytes" % (t_dev, t_host, len(text)))
+
+
+@pytest.mark.parametrize("name,size", [("first_scene", (4096, 2048)), ("first_plane", (4096, 2048)), ("first_patterns", (4096, 2048)),
+                                       ("reflect_refract", (4096, 2048)), ("hexagons", (4096, 2048)), ("first_textures", (4096, 2048)),
+                                       ("skybox", (4096, 2048)), ("grouped_grid", (4096, 4096)), ("mesh", (2048, 2048)),
+                                       ("here_be_dragons", (4000, 1600)), ("soft_shadows", (1536, 1536))])
+def test_demo_scenes_whole_frame_at_the_sizes_they_are_timed_at(torch, name, size):
+    """DESIGN.md section 8 quotes a kernel time for each of these frames: the frame that was timed equals the reference's,
+    pixel for pixel and ray for ray -- with whatever kernel family, lanes per pixel, block list, nodes, scene rectangle
+    the library's default policy picks at that size (the small-frame tests pick those by switches)."""
+    world, camera, depth = getattr(scenes, name)(*size)
+    r = _renderer(world, camera)
+    image = r.render(depth).cpu().numpy()
+    st = r.stats()
+    r.close()
+    assert not np.isnan(image).any()
+    _check_whole_frame(image, st["rays"], world, camera, depth, "%s %dx%d" % ((name,) + size))
