@@ -36,14 +36,26 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # 78.6: one non-FMA f32 lane-op per SIMD lane per cycle at the 2.4 GHz peak clock
 
 
-def parse():
+# BASELINE.json's configurations by name (C1 .. C5) -> (scene function, width, height)
+WORKLOADS = {
+    "C1": ("soft_shadows", 1000, 400),       # the demo at its default resolution
+    "C2": ("single_sphere", 1024, 1024),     # one sphere, point light: primary + shadow rays only
+    "C3": ("soft_shadows", 4096, 4096),      # the metric configuration
+    "C4": ("glass_and_mirror", 4096, 4096),  # glass sphere on a mirror plane, depth 5
+    "C5": ("sphere_grid", 8192, 8192),       # 64 spheres, 8192^2: the configuration BASELINE tiles over 8 GPUs
+}
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", type=int, default=4096, help="image edge in pixels (metric config: 4096)")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="a BASELINE.json configuration by name "
+                    "(default C3, the metric configuration); --scene / --size / --height select anything else")
+    ap.add_argument("--size", type=int, default=0, help="image edge in pixels (metric config: 4096)")
     ap.add_argument("--height", type=int, default=0, help="image height if not square (profiling other scenes: 1000x400 demos)")
-    ap.add_argument("--scene", default="soft_shadows", help="scene function in ray_tracer_challenge_amd.scenes")
+    ap.add_argument("--scene", default=None, help="scene function in ray_tracer_challenge_amd.scenes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU oracle sample (0 = skip)")
     ap.add_argument("--no-verify", action="store_true", help="skip the sampled-row parity check before timing")
     ap.add_argument("--no-one-shot", action="store_true", help="skip timing the one-call seam (rtc_render_ex)")
@@ -51,7 +63,78 @@ def parse():
                     "(N+E)-way band split; -1 = from the measured gather/render ratio, 0 = even split")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank code path on a box with fewer GPUs than ranks)")
-    return ap.parse_args()
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N>1 started without a launcher: seconds the "
+                    "parent waits for its ranks before ending them")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    # the workload: a named BASELINE configuration, overridden field by field by --scene / --size / --height
+    scene, width, height = WORKLOADS[args.workload or "C3"]
+    if args.scene is not None and args.workload is None and args.scene != scene:
+        width = height = 4096  # (a scene chosen by name alone keeps the metric size, as before)
+    if args.scene is not None:
+        scene = args.scene
+    if args.size:
+        width = height = args.size
+    if args.height:
+        height = args.height
+    args.scene, args.width, args.height_px = scene, width, height
+    args.workload_name = next((k for k, v in WORKLOADS.items() if v == (scene, width, height)), None)
+    return args
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it (no WORLD_SIZE / RANK in the environment): start the N
+    ranks ourselves -- one child process per GPU, rendezvous on 127.0.0.1 -- and wait for them.  The parent makes NO GPU
+    call (it imports neither torch nor the render library: a process that has initialised the GPU must not hand its
+    work to children it then execs or outlives), relays nothing but what the children print themselves (rank 0 prints the
+    JSON line on the stdout they inherit), and exits non-zero if any rank does -- ending the others first.
+    The launcher-provided form (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) is untouched."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n = args.gpus
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RTC_BENCH_SELF_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    deadline = time.monotonic() + args.launch_timeout
+    code = 0
+    try:
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0 and code == 0:
+                    code = rc if rc > 0 else 1
+                    print("bench.py: rank %d exited with %d; ending the other ranks" % (r, rc), file=sys.stderr, flush=True)
+            if code != 0 or time.monotonic() > deadline:
+                if code == 0:
+                    code = 124
+                    print("bench.py: ranks still running after %.0f s; ending them" % args.launch_timeout, file=sys.stderr, flush=True)
+                break
+            if live:
+                time.sleep(0.05)
+    finally:
+        for p in procs:  # exactly the processes started here, by pid
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return code
 
 
 def cpu_baseline(world, camera, depth, budget_s):
@@ -88,8 +171,12 @@ def cpu_baseline(world, camera, depth, budget_s):
     }
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # no launcher around us: be the launcher (before anything that could touch a GPU is even imported)
+        raise SystemExit(launch_ranks(args, argv))
     import torch
     import torch.distributed as dist
 
@@ -102,8 +189,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if world_size != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world_size, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start `python bench.py --gpus %d` without a launcher (it starts its own "
+                         "ranks) or with torch.distributed.run --nproc-per-node %d" % (args.gpus, world_size, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     n_dev = torch.cuda.device_count()
@@ -119,7 +206,7 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    world, camera, depth = getattr(scenes, args.scene)(args.size, args.height or args.size)
+    world, camera, depth = getattr(scenes, args.scene)(args.width, args.height_px)
     renderers = {}  # one context per part this rank renders: each keeps the counters and event timings of its own launches
 
     def renderer_for(p):
@@ -278,9 +365,7 @@ def main():
             "mpixels_per_s": round(pixels / (elapsed / args.steps) / 1e6, 3),
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3: soft_shadows demo scene (10x10 area light, 4 objects, depth 5), %dx%d, hashed "
-                                   "jitter seed 0x5EED5EED" % (args.size, args.size) if args.scene == "soft_shadows"
-                       else "%s %dx%d" % (args.scene, camera.width, camera.height),
+            "config": {"workload": workload_text(args, camera),
                        "workload_key": workload_key(args.scene, camera.width, camera.height),
                        "rays_per_frame": rays, "shaded_hits_per_frame": shaded, "pixels_per_frame": pixels,
                        # of rays_per_frame: area-light shadow rays whose answer followed from the conservative
@@ -323,6 +408,13 @@ def main():
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def workload_text(args, camera):
+    if args.scene == "soft_shadows":
+        return "%ssoft_shadows demo scene (10x10 area light, 4 objects, depth 5), %dx%d, hashed jitter seed 0x5EED5EED" % (
+            (args.workload_name + ": ") if args.workload_name else "", camera.width, camera.height)
+    return "%s%s %dx%d" % ((args.workload_name + ": ") if args.workload_name else "", args.scene, camera.width, camera.height)
 
 
 def workload_key(scene, width, height):

@@ -1,0 +1,44 @@
+"""bench.py itself on the GPU box: the one-GPU line, and the N > 1 path started the way the driver starts it --
+`python bench.py --gpus N` with no launcher -- rehearsed with two gloo ranks sharing the one GPU (RCCL needs a device per
+rank; everything else -- the self-launch, the band split, the pipelined gather, the calibration, the parity rows -- is the
+code an 8-GPU node runs)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench(args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_one_gpu_line_and_self_launched_two_rank_line_agree():
+    one = _bench(["--size", "512", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-one-shot"])
+    assert one["n_gpus"] == 1 and one["unit"] == "Mrays/s" and one["scaling"] == "strong" and one["dtype"] == "f32"
+    assert one["parity_check"]["rows_checked_bit_exact_vs_oracle"]
+    two = _bench(["--gpus", "2", "--backend", "gloo", "--size", "512", "--steps", "3", "--warmup", "1"])
+    assert two["n_gpus"] == 2 and two["steps"] == 3 and two["value"] > 0 and two["ms_per_step"] > 0
+    # the job is one image whatever N is: same rays, same shaded hits, same pixels
+    for key in ("rays_per_frame", "shaded_hits_per_frame", "pixels_per_frame", "shadow_rays_resolved_by_light_cone_cull"):
+        assert two["config"][key] == one["config"][key], key
+    assert two["parity_check"]["rows_checked_bit_exact_vs_oracle"]  # rows of the GATHERED frame against the oracle
+    mg = two["multi_gpu"]
+    assert mg["calibration"]["render_ms_even_share"] > 0 and mg["calibration"]["gather_ms_even_share_unoverlapped"] > 0
+    assert mg["wire_format_gather"]["equals_quantised_f32_frame"] is True
+    assert two["cpu_baseline"] is None and "one_shot" not in two
+
+
+def test_workload_selector_runs_c5_by_name():
+    line = _bench(["--workload", "C5", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-one-shot"])
+    assert line["config"]["workload"].startswith("C5: sphere_grid 8192x8192") and line["config"]["pixels_per_frame"] == 8191 * 8191
+    assert line["parity_check"]["rows_checked_bit_exact_vs_oracle"]
