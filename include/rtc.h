@@ -31,8 +31,14 @@ extern "C" {
 #endif
 
 #define RTC_ABI_VERSION 7
-/* maximum reflection_recursion_depth accepted (reference default: 5, constants.rs:4) */
-#define RTC_MAX_DEPTH 8
+/* reflection_recursion_depth (camera.rs:76: any i16; reference default 5, constants.rs:4; its author renders
+ * reflect_refract at 20).  Accepted: 0 .. RTC_MAX_DEPTH.  The kernels keep one frame per suspended shade_hit
+ * (world.rs:62-86); up to RTC_STACK_DEPTH_BASE levels every kernel has them, above that the scene's kernel is compiled
+ * once more, on first use, with a stack of 16 / 32 / ... levels in per-lane scratch (a second or so; cached like every
+ * scene kernel).  Beyond RTC_MAX_DEPTH the call is refused -- the reference would be recursing that deep on its own
+ * call stack.  rtc_color_at (a batched test entry point) stops at RTC_STACK_DEPTH_BASE. */
+#define RTC_MAX_DEPTH 255
+#define RTC_STACK_DEPTH_BASE 8
 
 typedef enum rtc_status {
     RTC_OK = 0,

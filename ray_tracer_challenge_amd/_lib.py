@@ -21,7 +21,8 @@ RTC_UV_CHECKERS, RTC_UV_ALIGN_CHECK, RTC_UV_IMAGE = 1, 2, 3
 RTC_MAP_SPHERICAL, RTC_MAP_PLANAR, RTC_MAP_CYLINDRICAL = 1, 2, 3
 RTC_LIGHT_POINT, RTC_LIGHT_RECT = 0, 1
 RTC_JITTER_CONSTANT, RTC_JITTER_HASHED = 0, 2
-RTC_MAX_DEPTH = 8
+RTC_MAX_DEPTH = 255        # accepted by rtc_render / rtc_ctx_render (above RTC_STACK_DEPTH_BASE: a scene kernel with a longer stack)
+RTC_STACK_DEPTH_BASE = 8   # ... and by rtc_color_at
 
 FP = C.POINTER(C.c_float)
 
@@ -173,9 +174,13 @@ EXTRA = {"rtc_powf_host": (None, [FP, FP, C.c_uint32, FP]),
          "rtc_atan2f_host": (None, [FP, FP, C.c_uint32, FP]),
          "rtc_acosf_host": (None, [FP, C.c_uint32, FP]),
          # device self-test of the range-checked exact sqrt/divide cores against sqrtf and '/'
-         "rtc_selftest_fastmath": (C.c_int, [FP, C.c_uint32, C.c_int32, C.POINTER(C.c_uint32)])}
+         "rtc_selftest_fastmath": (C.c_int, [FP, C.c_uint32, C.c_int32, C.POINTER(C.c_uint32)]),
+         # 1 in librtc_amd_dev.so (built with -DRTC_DEV_SWITCHES), 0 in the library that ships
+         "rtc_dev_switches": (C.c_int32, [])}
 
 _lib = None
+_loaded = {}  # path -> CDLL
+DEV_LIB_PATH = os.path.join(HERE, "librtc_amd_dev.so")
 
 
 class RtcError(RuntimeError):
@@ -208,23 +213,53 @@ def _preload_torch_hip_runtime():
             pass
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def load(path):
+    """The library at `path`, with every signature declared (loaded once per path)."""
+    path = os.path.abspath(path)
+    if path not in _loaded:
+        if not os.path.exists(path):
             raise ImportError(
-                "%s is missing: build it with `python -m ray_tracer_challenge_amd.build` "
-                "(there is no CPU/Python fallback for the render path)" % LIB_PATH)
+                "%s is missing: build it with `python -m ray_tracer_challenge_amd.build%s` "
+                "(there is no CPU/Python fallback for the render path)" % (path, " --dev" if path.endswith("_dev.so") else ""))
         _preload_torch_hip_runtime()
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in list(SIGNATURES.items()) + list(EXTRA.items()):
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = L
+        _loaded[path] = L
+    return _loaded[path]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load(LIB_PATH)
     return _lib
 
 
-def check(status):
+class use_library:
+    """with use_library(path): ... -- every call of this package goes to that library inside the block (tests: the
+    development build next to the one that ships).  Contexts remember the library that made them (Renderer)."""
+
+    def __init__(self, path):
+        self.path, self.prev = path, None
+
+    def __enter__(self):
+        global _lib
+        self.prev = lib()
+        _lib = load(self.path)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        try:
+            _lib.rtc_render_release()  # what the one-call seam keeps between calls belongs to the library left behind
+        finally:
+            _lib = self.prev
+        return False
+
+
+def check(status, library=None):
     if status != RTC_OK:
-        raise RtcError(status, lib().rtc_last_error().decode(errors="replace"))
+        raise RtcError(status, (library or lib()).rtc_last_error().decode(errors="replace"))

@@ -577,6 +577,7 @@ class GroupShape:
         self._t_inverse = identity_4x4()  # BaseShape::default(): not an inversion
         self.children = []
         self._cached_box = None           # cached_bounding_box (:15): filled on first use, never invalidated
+        self.casts_shadow = True          # the group's own BaseShape flag (base_shape.rs:31): settable, never consulted
 
     @staticmethod
     def with_children(children):
@@ -613,8 +614,14 @@ class GroupShape:
         for c in self.children:
             c.set_material(m.copy())
 
+    def casts_shadow_flag(self):
+        return self.casts_shadow
+
     def set_casts_shadow(self, flag):
-        raise NotImplementedError("GroupShape has no shadow flag of its own; set it on the leaves")
+        """shape.rs:45-47 on a group: sets the flag of the GROUP's own BaseShape, which nothing ever reads -- intersections
+        carry the leaf that was hit (group.rs:119-133), and World::is_shadowed asks that leaf (world.rs:117).  The
+        children keep their own flags; a no-op for rendering, as in the reference."""
+        self.casts_shadow = bool(flag)
 
     def bounding_box(self):
         """group.rs:138-151"""
@@ -891,9 +898,12 @@ class Camera:
         devs = [int(device)] if devices is None else [int(d) for d in devices]
         dtype = np.uint8 if quantize else f32
         img = np.zeros((self.height, self.width, 3), dtype=dtype) if out is None else out
-        assert img.dtype == dtype and img.shape == (self.height, self.width, 3) and img.flags["C_CONTIGUOUS"]
+        if not isinstance(img, np.ndarray) or img.dtype != dtype or img.shape != (self.height, self.width, 3) or not img.flags["C_CONTIGUOUS"]:
+            # (an explicit check, not an assert: the raw pointer goes to native code, which writes height * width * 3 values)
+            raise ValueError("out must be a C-contiguous (%d, %d, 3) array of %s" % (self.height, self.width, np.dtype(dtype).name))
         stats = L.rtc_stats()
         cs = world._c()
+        _seam_follows_environment()
         arr = (C.c_int32 * len(devs))(*devs)
         opts = L.rtc_opts(arr, len(devs), int(band_rows), 1 if quantize else 0, 0)
         L.check(L.lib().rtc_render_ex(C.byref(cs.scene), C.byref(self._cam), int(reflection_recursion_depth), C.byref(opts),
@@ -903,6 +913,22 @@ class Camera:
                            "culled_shadow_rays": int(stats.culled_shadow_rays), "launches": int(stats.launches),
                            "call_ms": float(stats.gather_ms), "flags": int(stats.flags)}
         return img if quantize else Canvas(self.width, self.height, img)
+
+
+_seam_env = {}
+
+
+def _seam_follows_environment():
+    """The library reads its RTC_AMD_* switches once, when a context is created, and rtc_render_ex keeps its contexts
+    between calls (rtc_render_release drops them).  Scripts and tests flip a switch between two renders of one process and
+    expect the second to see it: this mirror drops the seam's contexts whenever the process's RTC_AMD_* environment
+    differs from what it was at its previous render.  (A C caller does the same with rtc_render_release.)"""
+    import os
+    lib = L.lib()
+    env = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("RTC_AMD_")))
+    if _seam_env.get(id(lib), env) != env:
+        lib.rtc_render_release()
+    _seam_env[id(lib)] = env
 
 
 def powf(x, y, device=0):

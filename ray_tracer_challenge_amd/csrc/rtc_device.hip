@@ -241,23 +241,84 @@ static void triangle_box(const rtc_object& o, const float4 tri[3], double d_worl
     rec[1] = make_float4((float)(hi[0] + pad), (float)(hi[1] + pad), (float)(hi[2] + pad), 0.0f);
     rec[2] = make_float4((float)(nrm[0] / nl), (float)(nrm[1] / nl), (float)(nrm[2] / nl), 0.0f);
 }
-// occupancy target of a specialised traversal kernel (RTC_AMD_TREE_WAVES: development override)
-static std::string tree_jit_waves() {
-    const char* e = std::getenv("RTC_AMD_TREE_WAVES");
-    return (e && *e >= '1' && *e <= '8' && !e[1]) ? std::string(e) : std::string("6");
-}
+// ---- environment switches --------------------------------------------------------------------------------------------
+// Every switch the library takes from the environment, read ONCE -- when a context is created (rtc_ctx_create; the
+// stateless batched entry points read them per call) -- and kept with the context: a switch changed later does not reach
+// a context that exists, and nothing on the launch path calls getenv.  Two classes:
+//   * policy switches (always compiled in): on / off of a shortcut or a choice the library makes by itself.  None of them
+//     can change an image -- every one has a whole-frame on / off test -- only how fast it is produced;
+//   * development switches (RTC_DEV_ENV: compiled in only with -DRTC_DEV_SWITCHES, i.e. into librtc_amd_dev.so, which the
+//     tools and a few tests load): substitute kernel source or compiler flags, pin tuning constants, or -- RTC_AMD_TRI_NAIVE --
+//     deliberately break a guarantee so that a test can show it notices.  The shipped library does not even hold their names.
+#ifdef RTC_DEV_SWITCHES
+#define RTC_DEV_ENV(name) std::getenv(name)
+#else
+#define RTC_DEV_ENV(name) ((const char*)nullptr)
+#endif
+struct Policy {
+    int specialise = 2;  // RTC_AMD_SPECIALIZE: 0 never, 1 always (a failed compile is an error), 2 by frame size
+    bool light_cull = true, dark = true, fast_shadow = true;  // RTC_AMD_LIGHT_CULL / _DARK / _FAST_SHADOW (SceneHdr::cull_flags)
+    bool bvh = true, scene_box = true, gates = true, tri_precull = true, block_list = true, quiet = false;
+    int clusters = -1;    // RTC_AMD_CLUSTERS: nodes over long triangle runs -- 0 never, 1 always, -1 by frame size
+    int share_log2 = -1;  // RTC_AMD_SHARE_LOG2 = 0..3: lanes per pixel (log2) pinned for every frame; -1: by frame size
+    int scene_rect = 1;   // RTC_AMD_SCENE_RECT: 0 never launch the scene's rectangle only, 2 whenever there is one, 1 under half the frame
+    std::string jit_cache;  // RTC_AMD_JIT_CACHE=<dir>; "0" / "off": compiled kernels stay in memory; empty: <library dir>/jit_cache
+    // development
+    std::string jit_source, jit_flags;  // RTC_AMD_JIT_SOURCE=<path of rtc_kernel_core.h>, RTC_AMD_JIT_FLAGS="-D... -m..."
+    bool jit_print = false, cluster_stats = false, tri_naive = false, block_order = true;
+    int tree_waves = 6, reg_levels = 0, blocks_y = 0, block_s = -1, block_s_top = -1;  // (0 / -1: the library's own choice)
+    uint32_t fill_wgs = 0u, cluster_min_run = 0u, cluster_leaf = 0u;
+    double cluster_gmax = -1.0;
+
+    static Policy from_env() {
+        Policy p;
+        auto flag = [](const char* e, bool dflt) { return (e && *e) ? e[0] != '0' : dflt; };
+        auto digit = [](const char* e, int lo, int hi, int dflt) { return (e && e[0] >= '0' + lo && e[0] <= '0' + hi && !e[1]) ? e[0] - '0' : dflt; };
+        if (const char* e = std::getenv("RTC_AMD_SPECIALIZE")) p.specialise = !*e ? 2 : e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;
+        p.light_cull = flag(std::getenv("RTC_AMD_LIGHT_CULL"), true);
+        p.dark = flag(std::getenv("RTC_AMD_DARK"), true);
+        p.fast_shadow = flag(std::getenv("RTC_AMD_FAST_SHADOW"), true);
+        p.bvh = flag(std::getenv("RTC_AMD_BVH"), true);
+        p.scene_box = flag(std::getenv("RTC_AMD_SCENE_BOX"), true);
+        p.gates = flag(std::getenv("RTC_AMD_GATES"), true);
+        p.tri_precull = flag(std::getenv("RTC_AMD_TRI_PRECULL"), true);
+        p.block_list = flag(std::getenv("RTC_AMD_BLOCK_LIST"), true);
+        p.quiet = flag(std::getenv("RTC_AMD_QUIET"), false);
+        if (const char* e = std::getenv("RTC_AMD_CLUSTERS")) p.clusters = *e ? (e[0] != '0' ? 1 : 0) : -1;
+        p.share_log2 = digit(std::getenv("RTC_AMD_SHARE_LOG2"), 0, 3, -1);
+        if (const char* e = std::getenv("RTC_AMD_SCENE_RECT")) p.scene_rect = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
+        if (const char* e = std::getenv("RTC_AMD_JIT_CACHE")) p.jit_cache = e;
+        if (const char* e = RTC_DEV_ENV("RTC_AMD_JIT_SOURCE")) p.jit_source = e;
+        if (const char* e = RTC_DEV_ENV("RTC_AMD_JIT_FLAGS")) p.jit_flags = e;
+        p.jit_print = flag(RTC_DEV_ENV("RTC_AMD_JIT_PRINT"), false);
+        p.cluster_stats = flag(RTC_DEV_ENV("RTC_AMD_CLUSTER_STATS"), false);
+        p.tri_naive = flag(RTC_DEV_ENV("RTC_AMD_TRI_NAIVE"), false);
+        p.block_order = flag(RTC_DEV_ENV("RTC_AMD_BLOCK_ORDER"), true);
+        p.tree_waves = digit(RTC_DEV_ENV("RTC_AMD_TREE_WAVES"), 1, 8, 6);
+        p.reg_levels = digit(RTC_DEV_ENV("RTC_AMD_REG_LEVELS"), 0, 8, 0);
+        p.blocks_y = digit(RTC_DEV_ENV("RTC_AMD_BLOCKS_Y"), 1, 8, 0);
+        p.block_s = digit(RTC_DEV_ENV("RTC_AMD_BLOCK_S"), 0, 3, -1);
+        p.block_s_top = digit(RTC_DEV_ENV("RTC_AMD_BLOCK_S_TOP"), 0, 3, -1);
+        if (const char* e = RTC_DEV_ENV("RTC_AMD_FILL_WGS")) p.fill_wgs = std::max(1u, (uint32_t)std::atoi(e));
+        if (const char* e = RTC_DEV_ENV("RTC_AMD_CLUSTER_MIN_RUN")) p.cluster_min_run = std::max(3u, (uint32_t)std::atoi(e));
+        if (const char* e = RTC_DEV_ENV("RTC_AMD_CLUSTER_LEAF")) p.cluster_leaf = std::min(64u, std::max(2u, (uint32_t)std::atoi(e)));
+        if (const char* e = RTC_DEV_ENV("RTC_AMD_CLUSTER_GMAX")) p.cluster_gmax = std::atof(e);
+        return p;
+    }
+    // The share of the frame below which a scene's rectangle is launched instead of the whole grid (rtc_ctx_render).
+    float scene_rect_threshold() const { return scene_rect == 0 ? 0.0f : scene_rect == 2 ? 1.01f : 0.5f; }
+};
 
 // Lanes per pixel (RenderArgs::share_log2).  Two kinds of work can be shared between the lanes of a pixel: an area light's
 // cells (intensity_at), while the frame would otherwise be fewer than ~4 waves per SIMD; and, in a tree walk, the long
 // runs of leaves a divided mesh leaves at every level (for_each_leaf_shared) -- there a frame's time is that of its
 // slowest wave, whatever the frame's size.  RTC_AMD_SHARE_LOG2=0..3 overrides.
 static uint32_t choose_share_log2_runs(uint64_t waves) { return waves <= 12000u ? 3u : waves <= 40000u ? 2u : 1u; }
-static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows) {
+static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows, const Policy& P) {
     const bool area = hdr.light_kind == RTC_LIGHT_RECT && hdr.u_steps * hdr.v_steps >= 8;
     const bool runs = hdr.n_trav != 0u && hdr.max_leaf_run >= 16u && !area;
     if (!area && !runs) return 0u;
-    if (const char* e = std::getenv("RTC_AMD_SHARE_LOG2"))
-        if (e[0] >= '0' && e[0] <= '3' && !e[1]) return (uint32_t)(e[0] - '0');
+    if (P.share_log2 >= 0) return (uint32_t)P.share_log2;
     const uint64_t waves = ((uint64_t)hdr.width * rows + 63) / 64;
     // measured (tools/sweep_block_s.sh), ms with 2 / 4 / 8 lanes per pixel in the mesh tiles: here_be_dragons 1000 x 400 (6 k
     // waves) 1.33 / 0.93 / 0.77, 2000 x 800 (25 k) 1.61 / 1.41 / 1.50, 4000 x 1600 (100 k) 3.25 / 3.57 / 4.80; mesh 512 x 384
@@ -268,19 +329,6 @@ static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows) {
     // 1536^2 (37 k) 0.346 / 0.248 / 0.308 / 0.49; 2048^2 (66 k) 0.366 / 0.38 / 0.50 / 0.81: a frame's time is its throughput or
     // its longest wave, whichever is longer, and a wave of 64 pixels x 100 samples is long
     return waves < 6144u ? 3u : waves < 24000u ? 2u : waves < 50000u ? 1u : 0u;
-}
-
-// The share of the frame below which a scene's rectangle is launched instead of the whole grid (rtc_ctx_render).
-// RTC_AMD_SCENE_RECT=0: never; =2: whenever there is a rectangle (tests: every shape of it, whatever it is worth).
-static float scene_rect_threshold() {
-    const char* e = std::getenv("RTC_AMD_SCENE_RECT");
-    if (e && e[0] == '0') return 0.0f;
-    if (e && e[0] == '2') return 1.01f;
-    return 0.5f;
-}
-static bool env_flag(const char* name, bool dflt) {
-    const char* e = std::getenv(name);
-    return (e && *e) ? e[0] != '0' : dflt;
 }
 
 // An internal bounding-volume hierarchy for FLAT worlds (World.objects without GroupShapes) of many bounded objects:
@@ -378,13 +426,11 @@ static bool build_flat_bvh(const rtc_scene* scene, const float cam_origin[4], st
 // asin(TRI_GUARD)) |d| implies |d.n| >= TRI_GUARD |d| for every n within phi of +-a).  The run's leaves are re-ordered
 // (median splits of their boxes' centres): the tree kernels resolve equal distances by object index, not by position.
 // `trav` must carry the run lengths of mark_leaf_runs; the caller marks the new list again.
-static void cluster_leaf_runs(std::vector<float4>* trav, double tri_guard) {
-    uint32_t MIN_RUN = 24;  // (RTC_AMD_CLUSTER_MIN_RUN, _LEAF, _GMAX: development and tests)
-    uint32_t LEAF = 8;      // triangles under a node of the lowest level, at most
-    if (const char* e = std::getenv("RTC_AMD_CLUSTER_MIN_RUN")) MIN_RUN = std::max(3u, (uint32_t)std::atoi(e));
-    double g_max = 0.85;   // a node whose cone lets fewer than ~15 % of all directions pass is not worth its test
-    if (const char* e = std::getenv("RTC_AMD_CLUSTER_LEAF")) LEAF = std::min(64u, std::max(2u, (uint32_t)std::atoi(e)));
-    if (const char* e = std::getenv("RTC_AMD_CLUSTER_GMAX")) g_max = std::atof(e);
+static void cluster_leaf_runs(std::vector<float4>* trav, double tri_guard, const Policy& P) {
+    // (RTC_AMD_CLUSTER_MIN_RUN, _LEAF, _GMAX: development and tests)
+    const uint32_t MIN_RUN = P.cluster_min_run ? P.cluster_min_run : 24u;
+    const uint32_t LEAF = P.cluster_leaf ? P.cluster_leaf : 8u;  // triangles under a node of the lowest level, at most
+    const double g_max = P.cluster_gmax >= 0.0 ? P.cluster_gmax : 0.85;  // a node whose cone lets fewer than ~15 % of all directions pass is not worth its test
     const size_t ne = trav->size() / TRAV_STRIDE;
     const std::vector<float4>& in = *trav;
     std::vector<float4> out;
@@ -486,7 +532,7 @@ static void cluster_leaf_runs(std::vector<float4>* trav, double tri_guard) {
         e = end;
     }
     new_index[ne] = (uint32_t)(out.size() / TRAV_STRIDE);
-    if (env_flag("RTC_AMD_CLUSTER_STATS", false)) {  // development
+    if (P.cluster_stats) {  // development
         size_t leaves = 0, nodes = 0, in_nodes = 0;
         double gsum = 0.0;
         for (size_t e = 0; e < out.size() / TRAV_STRIDE; e++) {
@@ -628,7 +674,7 @@ static rtc_status pack_uv_pattern(const rtc_uv_pattern& u, std::vector<float4>* 
     return RTC_OK;
 }
 
-// `heavy_boxes` (optional): world-space boxes, 6 floats each, of the top-level GroupShapes that hold long runs of leaves
+// `heavy_boxes` (optional): world-space boxes, 7 floats each (min, max, rank), of the top-level GroupShapes that hold long runs of leaves
 // (divided meshes) -- where a frame's slow waves are (rtc_ctx_render: block list).
 // What a primary ray can see at all, for the scene rectangle (rtc_ctx_set_scene): known when every top-level entry is
 // bounded -- their padded union is `box` -- or a plane, seen only by rays that point towards it.
@@ -637,7 +683,7 @@ struct SceneRegion {
     double box[6] = {0, 0, 0, 0, 0, 0};
     std::vector<std::array<double, 4>> planes;  // the plane's object-space y of a world point p: r[0] p.x + r[1] p.y + r[2] p.z + r[3]
 };
-static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHdr* hdr, std::vector<float4>* soa,
+static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_camera* cam, SceneHdr* hdr, std::vector<float4>* soa,
                           std::vector<float>* texels, std::vector<float>* heavy_boxes = nullptr, SceneRegion* region = nullptr) {
     std::vector<float4> uvrec;
     std::vector<std::pair<const float*, size_t>> seen_images;
@@ -712,7 +758,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     // Triangles met by tree walks get a pre-culling box (tri_precull): the ball around everything bounded (and the camera)
     // bounds the distance between a ray's origin and a triangle; rays that start outside it do not pre-cull
     std::vector<float4> tbox;  // 3 records per object: { box.min, usable }, { box.max, 0 }, { unit normal, 0 }, world space
-    if (scene->n_groups && env_flag("RTC_AMD_TRI_PRECULL", true)) {
+    if (scene->n_groups && P.tri_precull) {
         bool any_triangle = false;
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (uint32_t i = 0; i < n; i++) {
@@ -733,7 +779,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         if (any_triangle && std::isfinite(r2) && r2 > 0.0) {
             const double radius = 1.05 * std::sqrt(r2);  // a little room: hit points are computed, not exact
             // RTC_AMD_TRI_NAIVE=1 (tests only): no angle guard, no padding -- what tests/test_tri_precull.py must catch
-            const bool naive = env_flag("RTC_AMD_TRI_NAIVE", false);
+            const bool naive = P.tri_naive;
             hdr->tri_guard = naive ? 0.0f : TRI_GUARD;
             hdr->has_tbox = 1;
             for (int a = 0; a < 3; a++) hdr->cull_c[a] = (float)(0.5 * (lo[a] + hi[a]));
@@ -747,7 +793,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         }
     }
     // A flat world of many bounded objects gets a bounding-volume hierarchy of the library's own (see build_flat_bvh)
-    if (!scene->n_groups && cam && n >= 16 && env_flag("RTC_AMD_BVH", true)) {
+    if (!scene->n_groups && cam && n >= 16 && P.bvh) {
         std::vector<float4> trav;
         float cam_origin[4];
         const float zero[4] = {0.0f, 0.0f, 0.0f, 1.0f};
@@ -875,8 +921,8 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         // whose time is that of their slowest wave) the nodes cut the runs into pieces of a lane's share and every piece
         // ends in a round of shuffles: here_be_dragons 1000 x 400 0.79 -> 0.98 ms, 2000 x 800 1.41 -> 1.49; 4000 x 1600 3.25 -> 2.92.
         const bool clusters_pay = cam && choose_share_log2_runs(((uint64_t)cam->width * cam->height + 63) / 64) <= 1u;
-        if (hdr->has_tbox && (hdr->max_leaf_run >= 24u || std::getenv("RTC_AMD_CLUSTER_MIN_RUN")) && env_flag("RTC_AMD_CLUSTERS", clusters_pay)) {
-            cluster_leaf_runs(&trav, (double)hdr->tri_guard);
+        if (hdr->has_tbox && (hdr->max_leaf_run >= 24u || P.cluster_min_run != 0u) && (P.clusters < 0 ? clusters_pay : P.clusters != 0)) {
+            cluster_leaf_runs(&trav, (double)hdr->tri_guard, P);
             hdr->has_tbox = 2;  // ... and the walks look for nodes among the group entries (spec_has_nodes)
             mark_pairs();
             (void)mark_leaf_runs(&trav, scene);  // (max_leaf_run keeps the length of the reference's runs: what the launch policy goes by)
@@ -887,7 +933,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
         uint32_t n_gates = 0;
         for (uint32_t g = 0; g < scene->n_groups; g++) n_gates += scene->groups[g].n_objects != 0;
         // (render path only: the batched entry points run the any-count loop for flat worlds, which has no gates)
-        if (cam && any && n <= 8 && n_gates <= RTC_MAX_GATES && env_flag("RTC_AMD_GATES", true)) {
+        if (cam && any && n <= 8 && n_gates <= RTC_MAX_GATES && P.gates) {
             uint32_t k = 0;
             for (uint32_t g = 0; g < scene->n_groups; g++) {
                 const rtc_group& grp = scene->groups[g];
@@ -972,7 +1018,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
                 box[3 + a] = (float)hi[a];
                 ok = std::isfinite(box[a]) && std::isfinite(box[3 + a]);
             }
-            if (ok && bounded && env_flag("RTC_AMD_SCENE_BOX", true)) {
+            if (ok && bounded && P.scene_box) {
                 for (int a = 0; a < 6; a++) hdr->scene_box[a] = box[a];
                 hdr->has_scene_box = 1u;
             }
@@ -1045,8 +1091,7 @@ static rtc_status flatten(const rtc_scene* scene, const rtc_camera* cam, SceneHd
     hdr->all_cast = 1;
     for (uint32_t i = 0; i < n; i++)
         if (!scene->objects[i].casts_shadow) hdr->all_cast = 0;
-    hdr->cull_flags = (env_flag("RTC_AMD_LIGHT_CULL", true) ? CULL_ENABLED : 0u) | (env_flag("RTC_AMD_DARK", true) ? CULL_DARK : 0u) |
-                      (env_flag("RTC_AMD_FAST_SHADOW", true) ? CULL_FAST_SHADOW : 0u);
+    hdr->cull_flags = (P.light_cull ? CULL_ENABLED : 0u) | (P.dark ? CULL_DARK : 0u) | (P.fast_shadow ? CULL_FAST_SHADOW : 0u);
     hdr->uvrec_off = (uint32_t)soa->size();
     soa->insert(soa->end(), uvrec.begin(), uvrec.end());
     if (cam) {
@@ -1075,8 +1120,13 @@ struct rtc_ctx_tiles {
     const uint8_t* bits;
     uint32_t w, h;
 };
+struct BlockList {  // RenderArgs::tiles of one partition (build_block_list), resident on the device
+    uint32_t* d = nullptr;
+    size_t n = 0;
+};
 struct rtc_ctx {
     int device = 0;
+    Policy policy;  // the environment's switches as they were when the context was created
     SceneHdr hdr;
     bool has_scene = false;
     float4* d_soa = nullptr;
@@ -1093,16 +1143,18 @@ struct rtc_ctx {
     bool spec_blocks_y = false;       // ... with -DRTC_SPEC_BLOCKS_Y=1 (several blocks per workgroup)
     bool spec_rect = false;           // ... with -DRTC_SPEC_RECT=1 (scene rectangle launches: block offsets, zero-filling workgroups)
     hipFunction_t spec_fn = nullptr;  // scene-specialised kernel (hiprtc), or null: ahead-of-time kernels
+    // Recursion deeper than RTC_AOT_MAX_DEPTH (ctx_render_slot): the scene's kernel compiled once more with a longer frame
+    // stack (-DRTC_SPEC_MAX_DEPTH=16 / 32 / ...), on first use; spec_defs: the options of this scene's kernel (empty when
+    // the policy left the scene to the ahead-of-time kernels -- deep_defs() then writes the options from scratch)
+    std::vector<std::string> spec_defs;
+    std::string spec_name;
+    std::map<int, hipFunction_t> deep_fn;
     std::string kernel_name;          // what rtc_ctx_render launches, for rtc_ctx_kernel_name()
     // Block list of the current scene (RenderArgs::tiles): which 16 x 16 pixel tiles of the image a mesh projects to
     // (row-major bitmap, empty: no block list), and the list last built -- for the partition it was built for
     std::vector<uint8_t> heavy_tiles;
     uint32_t heavy_w = 0, heavy_h = 0;
-    std::vector<uint32_t> blocks_host;
-    uint32_t* d_blocks = nullptr;
-    size_t blocks_cap = 0;
-    uint32_t blocks_for[3] = {0u, 0u, 0u};  // band_rows, n_parts, part
-    bool blocks_valid = false;
+    std::map<std::array<uint32_t, 4>, BlockList> block_lists;  // key: band_rows, n_parts, part, lanes per pixel (log2)
     float scene_box_coverage = 1.0f;  // share of the image the scene's box projects to (1: unknown / all of it)
     uint32_t scene_rect[4] = {0u, 0u, 0u, 0u};  // the 16 x 16 tiles outside which no primary ray sees anything: [x0, x1) x [y0, y1); empty: unknown
     float scene_rect_coverage = 1.0f;           // ... and its share of the frame
@@ -1177,12 +1229,6 @@ bool read_file(const std::string& path, std::string* out) {
     return true;
 }
 
-int specialise_policy() {  // 0 never, 1 always, 2 auto
-    const char* e = std::getenv("RTC_AMD_SPECIALIZE");
-    if (!e || !*e) return 2;
-    return e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;
-}
-
 // The kernel source travels inside the library: rtc_kernel_core_embed.inc is rtc_kernel_core.h as a string literal,
 // written by ray_tracer_challenge_amd/build.py before every compile (under hiprtc the header needs no other file).  A
 // deployment is librtc_amd.so alone -- no csrc/ or include/ beside it.  RTC_AMD_JIT_SOURCE=<path> (development) reads
@@ -1191,16 +1237,16 @@ const char k_core_src[] =
 #include "rtc_kernel_core_embed.inc"
     ;
 
-std::string jit_cache_dir() {  // RTC_AMD_JIT_CACHE=<dir>, or 0 / off to keep compiled kernels in memory only; default <lib dir>/jit_cache
-    const char* e = std::getenv("RTC_AMD_JIT_CACHE");
-    if (e && *e) return (std::strcmp(e, "0") == 0 || std::strcmp(e, "off") == 0) ? std::string() : std::string(e);
+std::string jit_cache_dir(const Policy& P) {  // RTC_AMD_JIT_CACHE=<dir>, or 0 / off to keep compiled kernels in memory only; default <lib dir>/jit_cache
+    if (!P.jit_cache.empty()) return (P.jit_cache == "0" || P.jit_cache == "off") ? std::string() : P.jit_cache;
     return lib_dir() + "/jit_cache";
 }
 
 // Compiles (or fetches) the specialised kernel for `defines` on the current device.
-rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunction_t* out, std::string* id) {
+rtc_status jit_get(const Policy& P, int device, const std::vector<std::string>& defines, hipFunction_t* out, std::string* id) {
     std::string key = std::to_string(device) + "|";
     for (const auto& d : defines) key += d + " ";
+    key += "|" + P.jit_source + "|" + P.jit_flags;  // (development builds: another source or other flags are another kernel)
     std::lock_guard<std::mutex> lock(g_jit_mutex);
     auto it = g_jit_cache.find(key);
     if (it != g_jit_cache.end()) {
@@ -1210,8 +1256,8 @@ rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunct
     }
     std::string core_file;
     const char* core = k_core_src;
-    if (const char* src_path = std::getenv("RTC_AMD_JIT_SOURCE")) {
-        if (!read_file(src_path, &core_file)) return fail(RTC_ERR_DEVICE, "scene specialisation: cannot read RTC_AMD_JIT_SOURCE=%s", src_path);
+    if (!P.jit_source.empty()) {  // development builds only (Policy)
+        if (!read_file(P.jit_source, &core_file)) return fail(RTC_ERR_DEVICE, "scene specialisation: cannot read the kernel source %s", P.jit_source.c_str());
         core = core_file.c_str();
     }
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
@@ -1221,15 +1267,15 @@ rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunct
     bool waves_given = false;
     for (const auto& d : defines) waves_given = waves_given || d.rfind("-DRTC_WAVES_PER_SIMD=", 0) == 0;
     if (!waves_given) opts.push_back("-DRTC_WAVES_PER_SIMD=7");
-    if (const char* extra = std::getenv("RTC_AMD_JIT_FLAGS")) {  // development: extra -D / -m flags, space separated
-        std::istringstream ss(extra);
+    if (!P.jit_flags.empty()) {  // development builds only: extra -D / -m flags, space separated
+        std::istringstream ss(P.jit_flags);
         std::string tok;
         while (ss >> tok) opts.push_back(tok);
     }
     // disk cache keyed by the source text, every option, the compiler's version and the ABI the argument block follows
     std::string opt_text;
     for (const auto& o : opts) opt_text += o + "\n";
-    if (env_flag("RTC_AMD_JIT_PRINT", false)) {  // development: the options, one line, as tools/spec_asm.sh takes them
+    if (P.jit_print) {  // development: the options, one line, as tools/spec_asm.sh takes them
         std::string line;
         for (size_t i = 5; i < opts.size(); i++) line += " " + opts[i];
         std::fprintf(stderr, "librtc_amd: scene kernel options:%s\n", line.c_str());
@@ -1240,7 +1286,7 @@ rtc_status jit_get(int device, const std::vector<std::string>& defines, hipFunct
                 " args " + std::to_string(sizeof(RenderArgs)) + "\n";
     char name[64];
     snprintf(name, sizeof(name), "spec_%016llx.hsaco", (unsigned long long)fnv1a(opt_text, fnv1a(core)));
-    const std::string cache_dir = jit_cache_dir(), cache_path = cache_dir + "/" + name;
+    const std::string cache_dir = jit_cache_dir(P), cache_path = cache_dir + "/" + name;
     auto compile = [&](std::string* code) -> rtc_status {
         hiprtcProgram prog;
         const char* src = "#include \"rtc_kernel_core.h\"\n";
@@ -1351,11 +1397,20 @@ extern "C" {
 
 int32_t rtc_device_count(void) { return usable_devices(); }
 
+// Diagnostic (not in rtc.h): was this library built with the development switches (Policy, -DRTC_DEV_SWITCHES)?
+int32_t rtc_dev_switches(void) {
+#ifdef RTC_DEV_SWITCHES
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 rtc_status rtc_scene_validate(const rtc_scene* scene, const rtc_camera* camera) {
     SceneHdr hdr;
     std::vector<float4> soa;
     std::vector<float> texels;
-    return flatten(scene, camera, &hdr, &soa, &texels);
+    return flatten(Policy::from_env(), scene, camera, &hdr, &soa, &texels);
 }
 
 rtc_status rtc_ctx_create(int32_t device, rtc_ctx** out) {
@@ -1366,6 +1421,7 @@ rtc_status rtc_ctx_create(int32_t device, rtc_ctx** out) {
     HIP_TRY(hipSetDevice(device));
     rtc_ctx* c = new rtc_ctx();
     c->device = device;
+    c->policy = Policy::from_env();  // the one place a context looks at the environment
     HIP_TRY(hipMalloc(&c->d_total, 3 * CTX_TOTAL_SLOTS * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->d_total, 0, 3 * CTX_TOTAL_SLOTS * sizeof(unsigned long long)));
     *out = c;
@@ -1381,7 +1437,8 @@ void rtc_ctx_destroy(rtc_ctx* c) {
     if (c->d_total) (void)hipFree(c->d_total);
     if (c->d_ppm_rows) (void)hipFree(c->d_ppm_rows);
     if (c->d_ppm_bits) (void)hipFree(c->d_ppm_bits);
-    if (c->d_blocks) (void)hipFree(c->d_blocks);
+    for (auto& bl : c->block_lists)
+        if (bl.second.d) (void)hipFree(bl.second.d);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -1394,10 +1451,10 @@ void rtc_ctx_destroy(rtc_ctx* c) {
 // point maps to camera space through the inverse of Camera.transform_inverse.  Performance only -- which blocks start
 // first and with how many lanes per pixel -- so generous padding and "everything" when a box reaches behind the camera.
 constexpr size_t HEAVY_BOX_FLOATS = 7;  // min, max, rank (1 .. 3: project_heavy_boxes keeps a tile's highest)
-static void project_heavy_boxes(const std::vector<float>& boxes, const rtc_camera* cam, std::vector<uint8_t>* tiles, uint32_t* tw, uint32_t* th) {
+static void project_heavy_boxes(const Policy& P, const std::vector<float>& boxes, const rtc_camera* cam, std::vector<uint8_t>* tiles, uint32_t* tw, uint32_t* th) {
     tiles->clear();
     *tw = *th = 0;
-    if (boxes.empty() || !cam || !env_flag("RTC_AMD_BLOCK_LIST", true)) return;
+    if (boxes.empty() || !cam || !P.block_list) return;
     float view[16];
     inverse4(cam->inv, view);
     const uint32_t w = (cam->width + 15u) / 16u, h = (cam->height + 15u) / 16u;
@@ -1468,18 +1525,16 @@ static void mark_plane_side(const std::array<double, 4>& row, const rtc_camera* 
 // The block list of one partition (RenderArgs::tiles): the 16 x 16 tiles of the partition's compact rows, those a mesh
 // projects to first and cut into blocks of 2^mesh_share_log2 lanes per pixel (8 x 8 or 8 x 4 pixels), the others after
 // them, whole, one lane per pixel.
-static void build_block_list(const rtc_ctx_tiles& T, uint32_t width, uint32_t mesh_share_log2, uint32_t rows, const Partition& q, std::vector<uint32_t>* out) {
+static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t width, uint32_t mesh_share_log2, uint32_t rows, const Partition& q, std::vector<uint32_t>* out) {
     out->clear();
     std::vector<uint32_t> light;
     uint32_t hs = mesh_share_log2;  // lanes per pixel (log2) in the mesh tiles; RTC_AMD_BLOCK_S=0..3: development
-    if (const char* e = std::getenv("RTC_AMD_BLOCK_S"))
-        if (e[0] >= '0' && e[0] <= '3' && !e[1]) hs = (uint32_t)(e[0] - '0');
+    if (P.block_s >= 0) hs = (uint32_t)P.block_s;
     // the dearest tiles first (rank 3: glass that also reflects), or the frame ends waiting for a few waves that started
     // late (RTC_AMD_BLOCK_ORDER=0: image order; RTC_AMD_BLOCK_S_TOP=0..3: lanes per pixel of rank 3 alone -- development)
-    const bool ordered = env_flag("RTC_AMD_BLOCK_ORDER", true);
+    const bool ordered = P.block_order;
     uint32_t hs_top = hs;
-    if (const char* e = std::getenv("RTC_AMD_BLOCK_S_TOP"))
-        if (e[0] >= '0' && e[0] <= '3' && !e[1]) hs_top = (uint32_t)(e[0] - '0');
+    if (P.block_s_top >= 0) hs_top = (uint32_t)P.block_s_top;
     for (uint32_t rank = 3u; rank >= 1u; rank--) {
         const uint32_t s = rank == 3u ? hs_top : hs;
         const uint32_t hbw = 16u >> (s >> 1), hbh = 16u >> ((s + 1u) >> 1);
@@ -1516,7 +1571,7 @@ static rtc_status jit_failed(rtc_ctx* c, int policy, rtc_status jst) {
         return jst;
     }
     static bool warned = false;
-    if (!warned && !env_flag("RTC_AMD_QUIET", false)) {
+    if (!warned && !c->policy.quiet) {
         warned = true;
         std::fprintf(stderr, "librtc_amd: scene specialisation unavailable, rendering with the slower ahead-of-time kernel %s: %.300s\n",
                      c->kernel_name.c_str(), c->jit_note.c_str());
@@ -1531,13 +1586,14 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     std::vector<float> texels;
     std::vector<float> heavy_boxes;
     SceneRegion region;
-    rtc_status st = flatten(scene, camera, &hdr, &soa, &texels, &heavy_boxes, &region);
+    const Policy& P = c->policy;
+    rtc_status st = flatten(P, scene, camera, &hdr, &soa, &texels, &heavy_boxes, &region);
     if (st != RTC_OK) return st;
     HIP_TRY(hipSetDevice(c->device));
     if (c->has_scene && std::memcmp(&hdr, &c->hdr, sizeof(hdr)) == 0 && soa.size() == c->soa_host.size() &&
         texels.size() == c->texels_host.size() && std::memcmp(soa.data(), c->soa_host.data(), soa.size() * sizeof(float4)) == 0 &&
         (texels.empty() || std::memcmp(texels.data(), c->texels_host.data(), texels.size() * sizeof(float)) == 0))
-        return RTC_OK;  // the very scene that is resident (records, camera, light, switches): nothing to replace
+        return RTC_OK;  // the very scene that is resident (records, camera, light; the switches are the context's for life): nothing to replace
     // Renders are asynchronous on caller streams (torch's are non-blocking: the null-stream copies below do not order
     // against them), and a render still in flight reads the records and the counters this call replaces.  Wait for
     // everything the context has launched before touching them.  (rtc.h: one stream at a time per context.)
@@ -1577,23 +1633,27 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     c->has_scene = true;
     c->soa_host = soa;
     c->texels_host = texels;
-    c->blocks_valid = false;
-    project_heavy_boxes(heavy_boxes, camera, &c->heavy_tiles, &c->heavy_w, &c->heavy_h);
+    for (auto& bl : c->block_lists)  // (nothing is in flight any more: the synchronisation above)
+        if (bl.second.d) (void)hipFree(bl.second.d);
+    c->block_lists.clear();
+    c->deep_fn.clear();
+    c->spec_defs.clear();
+    project_heavy_boxes(P, heavy_boxes, camera, &c->heavy_tiles, &c->heavy_w, &c->heavy_h);
 
     // which kernel will render this scene
     c->spec_fn = nullptr;
     // sample-parallel rendering (render_body): compiled in when this frame is small enough to want it
-    c->spec_shares = choose_share_log2(hdr, hdr.height) != 0u;
+    c->spec_shares = choose_share_log2(hdr, hdr.height, P) != 0u;
     // several blocks per workgroup (render_body) where most workgroups see nothing but the sky: the scene's box projects to
     // less than a quarter of the image
     c->scene_box_coverage = 1.0f;
     c->scene_rect[0] = c->scene_rect[1] = c->scene_rect[2] = c->scene_rect[3] = 0u;
-    if (hdr.has_scene_box && camera && env_flag("RTC_AMD_BLOCK_LIST", true)) {
+    if (hdr.has_scene_box && camera && P.block_list) {
         std::vector<uint8_t> covered;
         uint32_t tw = 0, th = 0;
         std::vector<float> box(hdr.scene_box, hdr.scene_box + 6);
         box.push_back(1.0f);
-        project_heavy_boxes(box, camera, &covered, &tw, &th);
+        project_heavy_boxes(P, box, camera, &covered, &tw, &th);
         size_t n_cov = 0;
         for (uint8_t b : covered) n_cov += b;
         if (!covered.empty()) c->scene_box_coverage = (float)n_cov / (float)covered.size();
@@ -1602,13 +1662,13 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     // box of the bounded top-level entries, projected, and for every top-level plane the side of its horizon on which rays
     // point towards it.
     c->scene_rect_coverage = 1.0f;
-    if (region.known && camera && env_flag("RTC_AMD_BLOCK_LIST", true)) {
+    if (region.known && camera && P.block_list) {
         std::vector<uint8_t> covered;
         uint32_t tw = (camera->width + 15u) / 16u, th = (camera->height + 15u) / 16u;
         if (region.has_box) {
             std::vector<float> box(region.box, region.box + 6);
             box.push_back(1.0f);
-            project_heavy_boxes(box, camera, &covered, &tw, &th);
+            project_heavy_boxes(P, box, camera, &covered, &tw, &th);
         }
         if (covered.empty()) covered.assign((size_t)tw * th, 0);
         for (const auto& pl : region.planes) mark_plane_side(pl, camera, &covered, tw, th);
@@ -1622,16 +1682,16 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
             c->scene_rect[0] = x0, c->scene_rect[1] = x1, c->scene_rect[2] = y0, c->scene_rect[3] = y1;
             c->scene_rect_coverage = (float)((double)(x1 - x0) * (y1 - y0) / ((double)tw * th));
         }
-        if (env_flag("RTC_AMD_JIT_PRINT", false))
+        if (P.jit_print)
             std::fprintf(stderr, "librtc_amd: scene rectangle tiles [%u, %u) x [%u, %u) of %u x %u: %.3f of the frame\n", x0, x1, y0, y1, tw, th,
                          c->scene_rect_coverage);
     }
-    c->spec_blocks_y = c->scene_box_coverage < 0.25f || std::getenv("RTC_AMD_BLOCKS_Y") != nullptr;
+    c->spec_blocks_y = c->scene_box_coverage < 0.25f || P.blocks_y != 0;
     const std::string share_def = std::string("-DRTC_SPEC_SHARE=") + (c->spec_shares ? "1" : "0");
     // Scene rectangle launches need a few more argument loads and operations in front of every wave, which cost frames of
     // short waves 6 - 10 % (first_plane, first_patterns; C4 0.610 -> 0.648 ms, more than the 3 % its sky rows are worth): only
     // where the rectangle is under half the frame (C5, single_sphere) is the scene's kernel compiled with them.
-    c->spec_rect = c->scene_rect[0] < c->scene_rect[1] && c->scene_rect_coverage < scene_rect_threshold();
+    c->spec_rect = c->scene_rect[0] < c->scene_rect[1] && c->scene_rect_coverage < P.scene_rect_threshold();
     const std::string blocks_def = std::string("-DRTC_SPEC_BLOCKS_Y=") + (c->spec_blocks_y ? "1" : "0");
     const std::string rect_def = std::string("-DRTC_SPEC_RECT=") + (c->spec_rect ? "1" : "0");
     // Material facts (rtc_kernel_core.h): does any material reflect / transmit at all (a scene without either carries no
@@ -1647,9 +1707,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         any_refr = any_refr || !(m.transparency == 0.0f);
         any_specular = any_specular || !(m.specular == 0.0f && m.shininess >= 0.0f && m.shininess <= 1e6f);  // phong: needs powf
     }
-    int reg_levels = 0;
-    if (const char* e = std::getenv("RTC_AMD_REG_LEVELS"))
-        if (e[0] >= '0' && e[0] <= '8' && !e[1]) reg_levels = e[0] - '0';
+    int reg_levels = P.reg_levels;
     if (!any_refl && !any_refr) reg_levels = 0;
     std::vector<std::string> recursion_defs = {std::string("-DRTC_SPEC_ANY_REFL=") + (any_refl ? "1" : "0"),
                                                std::string("-DRTC_SPEC_ANY_REFR=") + (any_refr ? "1" : "0"),
@@ -1662,52 +1720,49 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     snprintf(nm, sizeof(nm), "render_kernel<%d,%s>", n <= 4 ? 4 : n <= 8 ? 8 : 0, (n <= 8 && c->simple) ? "simple" : "general");
     c->kernel_name = nm;
     c->kernel_id = aot_kernel_id();
+    // The options of this scene's kernel are written down whatever the policy says (deep_kernel may need them later);
+    // `compile_now`: does the policy want the scene-compiled kernel for ordinary depths.
+    std::vector<std::string> defs;
+    std::string spec_name;
+    bool compile_now = false;
+    const int policy = P.specialise;
+    const uint64_t pixels = (uint64_t)hdr.width * hdr.height;
+    auto uniform_bits = [&](uint32_t* first) {
+        std::memcpy(first, &soa[0].w, 4);
+        for (uint32_t i = 1; i < n; i++) {
+            uint32_t bits;
+            std::memcpy(&bits, &soa[i].w, 4);
+            if (bits != *first) return false;
+        }
+        return n > 0;
+    };
     if (hdr.n_trav) {  // a traversal stream (GroupShapes, or the library's own hierarchy): packet walk, compiled per scene like the flat kernels
         const std::string how = scene->n_groups ? "tree" : "tree,bvh";
         c->kernel_name = "render_kernel<" + how + ">";
-        const int policy = specialise_policy();
         // (worlds with divided meshes are compiled whatever the frame's size: the ahead-of-time walk has neither the
         // triangle pre-culling specialisation nor the leaf-sharing lanes -- mesh 512 x 384: 7.9 ms)
-        if (policy == 1 || (policy == 2 && ((uint64_t)hdr.width * hdr.height >= (1ull << 18) || hdr.max_leaf_run >= 16u))) {
-            // the traversal kernel compiled for this scene's light kind / jitter mode / pattern use and, when every object
-            // shares one kind / flags word (a triangle mesh, a grid of spheres), for that word as well
-            uint32_t first;
-            std::memcpy(&first, &soa[0].w, 4);
-            bool uniform = true;
-            for (uint32_t i = 1; i < n && uniform; i++) {
-                uint32_t bits;
-                std::memcpy(&bits, &soa[i].w, 4);
-                uniform = bits == first;
-            }
-            char b[16];
-            snprintf(b, sizeof(b), "0x%x", first);
-            std::vector<std::string> defs = {std::string("-DRTC_SPEC_LIST=") + b,
-                                             uniform ? std::string("-DRTC_SPEC_UNIFORM_BITS=") + b : std::string("-DRTC_SPEC_RUNTIME_BITS=1"),
-                                             "-DRTC_SPEC_NOBJ=-1", "-DRTC_SPEC_SIMPLE=0",
-                                             reg_waves ? std::string(reg_waves) : "-DRTC_WAVES_PER_SIMD=" + tree_jit_waves(),
-                                             std::string("-DRTC_SPEC_TBOX=") + std::to_string(hdr.has_tbox),
-                                             "-DRTC_SPEC_LIGHT_KIND=" + std::to_string(hdr.light_kind),
-                                             "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
-                                             std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
-            defs.push_back(share_def);
-            defs.push_back(blocks_def);
+        compile_now = policy == 1 || (policy == 2 && (pixels >= (1ull << 18) || hdr.max_leaf_run >= 16u));
+        // the traversal kernel compiled for this scene's light kind / jitter mode / pattern use and, when every object
+        // shares one kind / flags word (a triangle mesh, a grid of spheres), for that word as well
+        uint32_t first = 0u;
+        const bool uniform = uniform_bits(&first);
+        char b[16];
+        snprintf(b, sizeof(b), "0x%x", first);
+        defs = {std::string("-DRTC_SPEC_LIST=") + b,
+                uniform ? std::string("-DRTC_SPEC_UNIFORM_BITS=") + b : std::string("-DRTC_SPEC_RUNTIME_BITS=1"),
+                "-DRTC_SPEC_NOBJ=-1", "-DRTC_SPEC_SIMPLE=0",
+                reg_waves ? std::string(reg_waves) : "-DRTC_WAVES_PER_SIMD=" + std::to_string(P.tree_waves),
+                std::string("-DRTC_SPEC_TBOX=") + std::to_string(hdr.has_tbox),
+                "-DRTC_SPEC_LIGHT_KIND=" + std::to_string(hdr.light_kind),
+                "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
+                std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
+        defs.push_back(share_def);
+        defs.push_back(blocks_def);
         defs.push_back(rect_def);
-            defs.push_back(rect_def);
-            defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
-            rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
-            if (jst != RTC_OK) {
-                if ((jst = jit_failed(c, policy, jst)) != RTC_OK) return jst;
-            } else {
-                c->kernel_name = std::string("render_kernel_spec[") + how + (uniform ? std::string(";all ") + b : std::string()) +
-                                 (hdr.has_patterns ? ";patterns" : "") + "]";
-            }
-        }
-        return RTC_OK;
-    }
-    const int policy = specialise_policy();
-    const uint64_t pixels = (uint64_t)hdr.width * hdr.height;
-    if (n >= 1 && n <= 8 && (policy == 1 || (policy == 2 && pixels >= (1ull << 18)))) {
-        std::vector<std::string> defs;
+        defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
+        spec_name = std::string("render_kernel_spec[") + how + (uniform ? std::string(";all ") + b : std::string()) + (hdr.has_patterns ? ";patterns" : "") + "]";
+    } else if (n >= 1 && n <= 8) {
+        compile_now = policy == 1 || (policy == 2 && pixels >= (1ull << 18));
         std::string list = "-DRTC_SPEC_LIST=";
         for (uint32_t i = 0; i < n; i++) {
             uint32_t bits;
@@ -1741,50 +1796,70 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
             if (n <= 2) defs.push_back("-DRTC_SPEC_SELECT=1");  // (4 - 6 objects: the selects cost more than the gathers, +13 ... +30 %)
             defs.push_back("-DRTC_WAVES_PER_SIMD=6");
         }
-        rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
+        spec_name = "render_kernel_spec[" + list.substr(16) + (c->simple ? ";simple" : "") + (hdr.has_patterns ? ";patterns" : "") + (hdr.n_gates ? ";gates" : "") + "]";
+    } else if (n > 8) {
+        // many objects: the any-count loop.  When they all share one kind / flags word (C5: 64 scale+translate spheres) that
+        // word is a compile-time constant -- no per-object kind switch, two 16-byte records per object -- and the policy
+        // compiles the scene's kernel; a mixed list is left to the ahead-of-time loop (and compiled with run-time words
+        // only when the recursion is deeper than that kernel's stack)
+        uint32_t first = 0u;
+        const bool uniform = uniform_bits(&first);
+        compile_now = uniform && (policy == 1 || (policy == 2 && pixels >= (1ull << 18)));
+        char b[16];
+        snprintf(b, sizeof(b), "0x%x", first);
+        defs = {std::string("-DRTC_SPEC_LIST=") + b, uniform ? std::string("-DRTC_SPEC_UNIFORM_BITS=") + b : std::string("-DRTC_SPEC_RUNTIME_BITS=1"),
+                "-DRTC_SPEC_NOBJ=0", "-DRTC_SPEC_SIMPLE=0",
+                "-DRTC_SPEC_LIGHT_KIND=" + std::to_string(hdr.light_kind),
+                "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
+                std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
+        defs.push_back(share_def);
+        defs.push_back(blocks_def);
+        defs.push_back(rect_def);
+        if (reg_waves) defs.push_back(reg_waves);
+        defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
+        spec_name = std::string("render_kernel_spec[") + (uniform ? std::string("all ") + b : std::string("any")) + (hdr.has_patterns ? ";patterns" : "") + "]";
+    }
+    c->spec_defs = defs;
+    c->spec_name = spec_name;
+    if (compile_now && !defs.empty()) {
+        rtc_status jst = jit_get(P, c->device, defs, &c->spec_fn, &c->kernel_id);
         if (jst != RTC_OK) {
             if ((jst = jit_failed(c, policy, jst)) != RTC_OK) return jst;
         } else {
-            c->kernel_name = "render_kernel_spec[" + list.substr(16) + (c->simple ? ";simple" : "") + (hdr.has_patterns ? ";patterns" : "") +
-                             (hdr.n_gates ? ";gates" : "") + "]";
-        }
-    } else if (n > 8 && (policy == 1 || (policy == 2 && pixels >= (1ull << 18)))) {
-        // many objects that all share one kind / flags word (C5: 64 scale+translate spheres): the any-count loop with
-        // that word as a compile-time constant -- no per-object kind switch, two 16-byte records per object
-        uint32_t first;
-        std::memcpy(&first, &soa[0].w, 4);
-        bool uniform = true;
-        for (uint32_t i = 1; i < n && uniform; i++) {
-            uint32_t bits;
-            std::memcpy(&bits, &soa[i].w, 4);
-            uniform = bits == first;
-        }
-        if (uniform) {
-            char b[16];
-            snprintf(b, sizeof(b), "0x%x", first);
-            std::vector<std::string> defs = {std::string("-DRTC_SPEC_LIST=") + b, std::string("-DRTC_SPEC_UNIFORM_BITS=") + b,
-                                             "-DRTC_SPEC_NOBJ=0", "-DRTC_SPEC_SIMPLE=0",
-                                             "-DRTC_SPEC_LIGHT_KIND=" + std::to_string(hdr.light_kind),
-                                             "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
-                                             std::string("-DRTC_SPEC_PATTERNS=") + (hdr.has_patterns ? "1" : "0")};
-            defs.push_back(share_def);
-            defs.push_back(blocks_def);
-        defs.push_back(rect_def);
-            defs.push_back(rect_def);
-            if (reg_waves) defs.push_back(reg_waves);
-            defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
-            rtc_status jst = jit_get(c->device, defs, &c->spec_fn, &c->kernel_id);
-            if (jst != RTC_OK) {
-                if ((jst = jit_failed(c, policy, jst)) != RTC_OK) return jst;
-            } else {
-                c->kernel_name = std::string("render_kernel_spec[all ") + b + (hdr.has_patterns ? ";patterns" : "") + "]";
-            }
+            c->kernel_name = spec_name;
         }
     }
     return RTC_OK;
 }
 
 }  // extern "C"
+
+// The scene's kernel with a frame stack of at least `depth` levels (ctx_render_slot).  The options are the scene's own
+// (rtc_ctx_set_scene wrote them down) plus -DRTC_SPEC_MAX_DEPTH; the recursion frames of such a kernel all live in per-lane
+// scratch -- the LDS placement of the first levels (a tuning of the depth-5 glass-and-mirror frame) is not carried over.
+// Always a scene-compiled kernel, whatever RTC_AMD_SPECIALIZE says: the ahead-of-time kernels stop at RTC_STACK_DEPTH_BASE.
+static rtc_status deep_kernel(rtc_ctx* c, int32_t depth, hipFunction_t* out) {
+    int cap = 2 * RTC_STACK_DEPTH_BASE;
+    while (cap < depth) cap *= 2;
+    if (cap > RTC_MAX_DEPTH) cap = RTC_MAX_DEPTH;
+    auto it = c->deep_fn.find(cap);
+    if (it != c->deep_fn.end()) {
+        *out = it->second;
+        return RTC_OK;
+    }
+    if (c->spec_defs.empty()) return fail(RTC_ERR_INVALID_ARG, "depth %d: no kernel options recorded for this scene", depth);
+    std::vector<std::string> defs;
+    for (const auto& d : c->spec_defs)
+        if (d.rfind("-DRTC_SPEC_LDS_FRAMES=", 0) != 0) defs.push_back(d);
+    defs.push_back("-DRTC_SPEC_MAX_DEPTH=" + std::to_string(cap));
+    hipFunction_t fn = nullptr;
+    std::string id;
+    rtc_status st = jit_get(c->policy, c->device, defs, &fn, &id);
+    if (st != RTC_OK) return st;  // (the message is hiprtc's)
+    c->deep_fn[cap] = fn;
+    *out = fn;
+    return RTC_OK;
+}
 
 // rtc_ctx_render with a counter slot of the caller's choosing (rtc_internal.h)
 rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* part, void* d_out_rgb, void* stream_, uint32_t slot) {
@@ -1800,15 +1875,24 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     const uint32_t rows = partition_rows(c->hdr.height, part);
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(c->device));
-    const uint32_t share_log2 = (c->spec_fn && c->spec_shares) ? choose_share_log2(c->hdr, rows) : 0u;  // only kernels compiled for it share lanes
+    const Policy& P = c->policy;
+    // camera.rs:76 takes any depth; the kernels' frame stack (one suspended shade_hit per level, world.rs:62-86) holds
+    // RTC_STACK_DEPTH_BASE levels.  Deeper than that, the scene's kernel is compiled once more with a longer stack -- 16, 32,
+    // ... RTC_MAX_DEPTH levels of per-lane scratch -- on first use, and kept with the context.
+    hipFunction_t spec_fn = c->spec_fn;
+    if (depth > RTC_STACK_DEPTH_BASE && rows > 0u) {
+        rtc_status dst = deep_kernel(c, depth, &spec_fn);
+        if (dst != RTC_OK) return dst;
+    }
+    const uint32_t share_log2 = (spec_fn && c->spec_shares) ? choose_share_log2(c->hdr, rows, P) : 0u;  // only kernels compiled for it share lanes
     const uint32_t bw = 16u >> (share_log2 >> 1), bh = 16u >> ((share_log2 + 1u) >> 1);  // pixels per workgroup (2x2 wave tiles)
     dim3 grid((c->hdr.width + bw - 1) / bw, (rows + bh - 1) / bh), block(256);
     // Frames of very many very short waves: several blocks per workgroup (RTC_AMD_BLOCKS_Y=1..8 overrides)
     uint32_t blocks_y = 1u;
-    if (!(c->spec_fn && c->spec_blocks_y)) {
+    if (!(spec_fn && c->spec_blocks_y)) {
         // (only kernels compiled for it loop over blocks)
-    } else if (const char* e = std::getenv("RTC_AMD_BLOCKS_Y")) {
-        if (e[0] >= '1' && e[0] <= '8' && !e[1]) blocks_y = (uint32_t)(e[0] - '0');
+    } else if (P.blocks_y != 0) {
+        blocks_y = (uint32_t)P.blocks_y;
     } else if ((uint64_t)grid.x * grid.y >= (1u << 15)) {
         // most workgroups see nothing but the sky: C5 8192^2 0.51 -> 0.43 ms, single_sphere 4096^2 0.088 -> 0.061 ms.  (Where the
         // waves have work -- hexagons, grouped_grid, whose boxes fill the frame -- four blocks per workgroup cost 8 ... 17 %.)
@@ -1818,26 +1902,36 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     // Tree worlds with meshes: a block list instead of the regular grid -- the tiles a mesh projects to first, eight
     // lanes per pixel there and one elsewhere (build_block_list).  Not when RTC_AMD_SHARE_LOG2 pins one value for all.
     const uint32_t* d_tiles = nullptr;
-    if (c->spec_fn && c->spec_shares && !c->heavy_tiles.empty() && c->hdr.light_kind == RTC_LIGHT_POINT && !std::getenv("RTC_AMD_SHARE_LOG2") &&
+    if (spec_fn && c->spec_shares && !c->heavy_tiles.empty() && c->hdr.light_kind == RTC_LIGHT_POINT && P.share_log2 < 0 &&
         c->hdr.width <= 65532u && rows <= 262140u && rows > 0u) {
-        if (!c->blocks_valid || c->blocks_for[0] != q.band_rows || c->blocks_for[1] != q.n_parts || c->blocks_for[2] != q.part) {
-            const rtc_ctx_tiles T = {c->heavy_tiles.data(), c->heavy_w, c->heavy_h};
-            // the previous list may still be read by a launch in flight
-            HIP_TRY(hipDeviceSynchronize());
-            build_block_list(T, c->hdr.width, share_log2, rows, q, &c->blocks_host);
-            if (c->blocks_host.size() > c->blocks_cap) {
-                if (c->d_blocks) (void)hipFree(c->d_blocks);
-                c->d_blocks = nullptr;
-                c->blocks_cap = 0;
-                HIP_TRY(hipMalloc(&c->d_blocks, c->blocks_host.size() * sizeof(uint32_t)));
-                c->blocks_cap = c->blocks_host.size();
+        // one list per partition, built on first use and kept until the scene changes: rtc_render_ex renders a frame as
+        // several partitions of one context, frame after frame (a single cached list meant a device synchronisation, a
+        // rebuild and a blocking copy per chunk launch)
+        const std::array<uint32_t, 4> key = {q.band_rows, q.n_parts, q.part, share_log2};
+        auto it = c->block_lists.find(key);
+        if (it == c->block_lists.end()) {
+            if (c->block_lists.size() >= 256u) {  // a caller cycling through partitions without end: start over (nothing may be in flight)
+                HIP_TRY(hipDeviceSynchronize());
+                for (auto& bl : c->block_lists)
+                    if (bl.second.d) (void)hipFree(bl.second.d);
+                c->block_lists.clear();
             }
-            HIP_TRY(hipMemcpy(c->d_blocks, c->blocks_host.data(), c->blocks_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-            c->blocks_for[0] = q.band_rows, c->blocks_for[1] = q.n_parts, c->blocks_for[2] = q.part;
-            c->blocks_valid = true;
+            const rtc_ctx_tiles T = {c->heavy_tiles.data(), c->heavy_w, c->heavy_h};
+            std::vector<uint32_t> host;
+            build_block_list(P, T, c->hdr.width, share_log2, rows, q, &host);
+            BlockList bl;
+            bl.n = host.size();
+            HIP_TRY(hipMalloc(&bl.d, std::max<size_t>(1, host.size()) * sizeof(uint32_t)));
+            // (a new buffer: no launch in flight can be reading it; the copy is complete when the call returns)
+            hipError_t ce = hipMemcpy(bl.d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (ce != hipSuccess) {
+                (void)hipFree(bl.d);
+                return fail(RTC_ERR_DEVICE, "block list upload failed: %s", hipGetErrorString(ce));
+            }
+            it = c->block_lists.emplace(key, bl).first;
         }
-        d_tiles = c->d_blocks;
-        grid = dim3((uint32_t)c->blocks_host.size(), 1);
+        d_tiles = it->second.d;
+        grid = dim3((uint32_t)it->second.n, 1);
     }
     // traced pixels among this partition's rows: x < w-1, y < h-1
     uint64_t traced_rows = 0;
@@ -1861,8 +1955,8 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     uint32_t block_x0 = 0u, block_y0 = 0u;
     unsigned long long extra_rays = 0ull;
     uint32_t fill_wg_rows = 0u, fill_rows = 0u, fill_period = 1u, fill_rect[4] = {0u, 0u, 0u, 0u};
-    if (d_tiles == nullptr && share_log2 == 0u && rows > 0u && c->scene_rect[0] < c->scene_rect[1] && c->scene_rect_coverage < scene_rect_threshold() &&
-        (c->spec_fn == nullptr || c->spec_rect)) {
+    if (d_tiles == nullptr && share_log2 == 0u && rows > 0u && c->scene_rect[0] < c->scene_rect[1] && c->scene_rect_coverage < P.scene_rect_threshold() &&
+        (spec_fn == nullptr || c->spec_rect)) {
         // local rows of this partition whose global row lies in the rectangle's rows, and the traced ones among them
         const uint32_t gy0 = c->scene_rect[2] * 16u, gy1 = std::min(c->hdr.height, c->scene_rect[3] * 16u);
         uint32_t yl0 = rows, yl1 = 0u, cursor = 0u;
@@ -1879,7 +1973,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             // every workgroup of this launch has work: one block each unless told otherwise (C5 0.395 / 0.407 / 0.427 / 0.46 ms
             // with 1 / 2 / 4 / 8 blocks per workgroup)
             const uint32_t block_rows = (yl1 - block_y0 * 16u + 15u) / 16u;
-            if (!std::getenv("RTC_AMD_BLOCKS_Y")) blocks_y = 1u;
+            if (P.blocks_y == 0) blocks_y = 1u;
             grid = dim3(c->scene_rect[1] - c->scene_rect[0], (block_rows + blocks_y - 1u) / blocks_y);
         } else {
             grid = dim3(1, 1);  // none of this partition's rows: one block of the rectangle's columns, for the launch's bookkeeping
@@ -1911,7 +2005,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         // them; a frame of 4096 blocks must not get as many again (RTC_AMD_FILL_WGS: development)
         const uint64_t frame_bytes = (uint64_t)rows * c->hdr.width * 12u;
         uint32_t fill_wgs = (uint32_t)std::min<uint64_t>(4096u, std::max<uint64_t>(16u, frame_bytes / (160u << 10)));
-        if (const char* e = std::getenv("RTC_AMD_FILL_WGS")) fill_wgs = std::max(1u, (uint32_t)std::atoi(e));
+        if (P.fill_wgs != 0u) fill_wgs = P.fill_wgs;
         fill_wg_rows = std::max(1u, (fill_wgs + grid.x - 1u) / grid.x);
         fill_rows = (rows + fill_wg_rows * grid.x - 1u) / (fill_wg_rows * grid.x);
         fill_period = std::max(1u, (grid.y + fill_wg_rows) / fill_wg_rows);  // spread among the rendering rows: the fill shares the memory system with them
@@ -1961,9 +2055,9 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     HIP_TRY(hipEventRecord(ev.first, stream));
     // instantiation: <= 4 / <= 8 objects get fully unrolled object loops (SIMPLE: all of them
     // scale+translate-only, no cylinder); anything larger takes the generic loop
-    if (c->spec_fn) {
+    if (spec_fn) {
         void* params[] = {&a};
-        HIP_TRY(hipModuleLaunchKernel(c->spec_fn, grid.x, grid.y, 1, block.x, 1, 1, 0, stream, params, nullptr));
+        HIP_TRY(hipModuleLaunchKernel(spec_fn, grid.x, grid.y, 1, block.x, 1, 1, 0, stream, params, nullptr));
     } else if (c->hdr.n_trav) hipLaunchKernelGGL((render_kernel<-1, false>), grid, block, 0, stream, a);
     else if (c->n_objects <= 4 && c->simple) hipLaunchKernelGGL((render_kernel<4, true>), grid, block, 0, stream, a);
     else if (c->n_objects <= 4) hipLaunchKernelGGL((render_kernel<4, false>), grid, block, 0, stream, a);
@@ -2111,7 +2205,7 @@ rtc_status begin_batch(const rtc_scene* scene, int32_t device, SceneHdr* hdr, De
     if (device < 0 || device >= n) return fail(RTC_ERR_INVALID_ARG, "device %d out of range (have %d)", device, n);
     std::vector<float4> soa;
     std::vector<float> texels;
-    rtc_status st = flatten(scene, nullptr, hdr, &soa, &texels);
+    rtc_status st = flatten(Policy::from_env(), scene, nullptr, hdr, &soa, &texels);
     if (st != RTC_OK) return st;
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(soa_buf->alloc(soa.size() * sizeof(float4)));
@@ -2125,7 +2219,7 @@ rtc_status begin_batch(const rtc_scene* scene, int32_t device, SceneHdr* hdr, De
 rtc_status rtc_color_at(const rtc_scene* scene, const float* origins, const float* directions, uint32_t n,
                         int32_t depth, int32_t device, float* out_rgb) {
     if (!origins || !directions || !out_rgb) return fail(RTC_ERR_INVALID_ARG, "rtc_color_at: null argument");
-    if (depth < 0 || depth > RTC_MAX_DEPTH) return fail(RTC_ERR_INVALID_ARG, "depth %d outside [0, %d]", depth, RTC_MAX_DEPTH);
+    if (depth < 0 || depth > RTC_STACK_DEPTH_BASE) return fail(RTC_ERR_INVALID_ARG, "rtc_color_at: depth %d outside [0, %d]", depth, RTC_STACK_DEPTH_BASE);
     if (n == 0) return RTC_OK;
     for (uint32_t i = 0; i < n; i++) {
         if (origins[i * 4 + 3] != 1.0f || directions[i * 4 + 3] != 0.0f)

@@ -42,7 +42,7 @@ typedef unsigned long size_t;
 #define RTC_HOSTDEV __device__
 // rtc.h needs <stddef.h>/<stdint.h>, which hiprtc does not ship: restate the few constants the device
 // code uses (the ahead-of-time build below static_asserts that they agree with rtc.h).
-#define RTC_MAX_DEPTH 8
+#define RTC_STACK_DEPTH_BASE 8
 enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3, RTC_CONE = 4, RTC_TRIANGLE = 5 };
 enum { RTC_PATTERN_NONE = 0, RTC_PATTERN_STRIPES = 1, RTC_PATTERN_GRADIENT = 2, RTC_PATTERN_RINGS = 3,
        RTC_PATTERN_CHECKERS = 4, RTC_PATTERN_SINE2D = 5, RTC_PATTERN_TEXTURE_MAP = 6, RTC_PATTERN_CUBE_MAP = 7 };
@@ -57,7 +57,7 @@ enum { RTC_JITTER_CONSTANT = 0, RTC_JITTER_HASHED = 2 };
 
 #include "rtc.h"
 #define RTC_HOSTDEV __host__ __device__
-static_assert(RTC_MAX_DEPTH == 8 && RTC_SPHERE == 0 && RTC_PLANE == 1 && RTC_CUBE == 2 && RTC_CYLINDER == 3 &&
+static_assert(RTC_STACK_DEPTH_BASE == 8 && RTC_MAX_DEPTH <= 255 && RTC_SPHERE == 0 && RTC_PLANE == 1 && RTC_CUBE == 2 && RTC_CYLINDER == 3 &&
                   RTC_CONE == 4 && RTC_TRIANGLE == 5 && RTC_PATTERN_NONE == 0 && RTC_PATTERN_STRIPES == 1 && RTC_PATTERN_GRADIENT == 2 &&
                   RTC_PATTERN_RINGS == 3 && RTC_PATTERN_CHECKERS == 4 && RTC_PATTERN_SINE2D == 5 &&
                   RTC_PATTERN_TEXTURE_MAP == 6 && RTC_PATTERN_CUBE_MAP == 7 && RTC_UV_CHECKERS == 1 &&
@@ -653,7 +653,20 @@ constexpr int STACK_REG_LEVELS = RTC_SPEC_REG_LEVELS;
 #else
 constexpr int STACK_REG_LEVELS = 0;
 #endif
-static_assert(STACK_REG_LEVELS >= 0 && STACK_REG_LEVELS <= RTC_MAX_DEPTH, "RTC_SPEC_REG_LEVELS");
+// Levels of the recursion's frame stack (color_at): RTC_STACK_DEPTH_BASE in every kernel but the ones the host compiles
+// for a deeper recursion (-DRTC_SPEC_MAX_DEPTH=16 / 32 / ...: rtc_device.hip deep_kernel; camera.rs:76 takes any depth).
+// A DEEP kernel differs in bookkeeping only: the path code no longer fits the bits the shallow kernels pack it into, so it
+// is parked in a word of its own and every frame keeps its caller's path (a 32-bit code wraps beyond 31 levels, exactly
+// as the oracle's u32 does; restoring the saved word is then the only way back to the caller's).
+#if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_MAX_DEPTH)
+#define RTC_STACK_DEPTH RTC_SPEC_MAX_DEPTH
+#else
+#define RTC_STACK_DEPTH RTC_STACK_DEPTH_BASE
+#endif
+#define RTC_DEEP_STACK (RTC_STACK_DEPTH > RTC_STACK_DEPTH_BASE)
+static_assert(RTC_STACK_DEPTH >= RTC_STACK_DEPTH_BASE && RTC_STACK_DEPTH <= 255, "RTC_SPEC_MAX_DEPTH");
+static_assert(!RTC_DEEP_STACK || LDS_FRAME_LEVELS == 0, "deep kernels keep their frames in scratch");
+static_assert(STACK_REG_LEVELS >= 0 && STACK_REG_LEVELS <= RTC_STACK_DEPTH, "RTC_SPEC_REG_LEVELS");
 
 constexpr float PLANE_EPS = 1.1920929e-7f * 10000.0f;  // plane.rs:49  f32::EPSILON * 10000.0
 constexpr float SELF_EPS = 1.1920929e-7f * 10000.0f;   // world.rs:210
@@ -2274,7 +2287,7 @@ DI float schlick(V3 eye, V3 n, float n1, float n2) {
 // used inside it (ray, hit, normal, recursion bookkeeping).  Parked there it costs no VGPRs during
 // the 100-sample loop and no scratch (HBM-side) traffic; slot k of lane t lives at lds[k*stride + t],
 // so a wave's accesses are consecutive dwords (conflict-free).
-constexpr int STASH_SLOTS = 13;
+constexpr int STASH_SLOTS = RTC_DEEP_STACK ? 14 : 13;
 constexpr int FRAME_LDS_SLOT0 = USE_STASH ? STASH_SLOTS : 0;                  // recursion frames kept in LDS come after the parking slots
 constexpr int LDS_SLOTS = FRAME_LDS_SLOT0 + 6 * LDS_FRAME_LEVELS > 0 ? FRAME_LDS_SLOT0 + 6 * LDS_FRAME_LEVELS : 1;
 struct LaneStash {
@@ -2293,6 +2306,9 @@ struct Frame {
     V3 acc;       // surface colour, later surface + reflected[*R]
     float reflective, R;
     uint32_t flags;  // bit0: waiting for the refraction child; bit1: has refraction child; bit2: Schlick
+#if RTC_DEEP_STACK
+    uint32_t path;   // the suspended call's own path code
+#endif
 };
 struct FrameRefr {
     V3 ro, rd;    // pending refraction ray (under_point, direction)
@@ -2317,7 +2333,7 @@ struct FrameRegs {
     FrameRefr r[R > 0 ? R : 1];
 };
 struct FrameMem {
-    static constexpr int M = RTC_MAX_DEPTH - STACK_REG_LEVELS;
+    static constexpr int M = RTC_STACK_DEPTH - STACK_REG_LEVELS;
     Frame f[M > 0 ? M : 1];
     FrameRefr r[M > 0 ? M : 1];
 };
@@ -2353,7 +2369,7 @@ struct FrameStack {
         if (M > 0 && sp >= R) mem.r[sp - R] = f;
     }
     DI Frame get(int sp) const {
-        Frame f = {v3(0.0f, 0.0f, 0.0f), 0.0f, 0.0f, 0u};
+        Frame f = {};
 #pragma unroll
         for (int u = 0; u < R; u++)
             if (__any(sp == u)) {
@@ -2432,7 +2448,12 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
             stash.put(9, h.t);
             stash.putu(10, (uint32_t)ob | (inside ? 0x80000000u : 0u));
             stash.putu(11, pixel);
+#if RTC_DEEP_STACK
+            stash.putu(12, path);
+            stash.putu(13, (uint32_t)rem | ((uint32_t)sp << 8) | ((uint32_t)depth << 16));
+#else
             stash.putu(12, path | ((uint32_t)rem << 16) | ((uint32_t)sp << 20) | ((uint32_t)depth << 24));
+#endif
             asm volatile("" ::: "memory");
             li = intensity_at<NOBJ, SIMPLE>(H, S, over_point, pixel, path, cnt);
             asm volatile("" ::: "memory");
@@ -2445,10 +2466,18 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                 ob = (int)(w10 & 0x7fffffffu);
                 inside = (w10 >> 31) != 0;
                 pixel = stash.getu(11);
+#if RTC_DEEP_STACK
+                const uint32_t w13 = stash.getu(13);
+                path = w12;
+                rem = (int)(w13 & 0xffu);
+                sp = (int)((w13 >> 8) & 0xffu);
+                depth = (int)(w13 >> 16);
+#else
                 path = w12 & 0xffffu;
                 rem = (int)((w12 >> 16) & 0xfu);
                 sp = (int)((w12 >> 20) & 0xfu);
                 depth = (int)(w12 >> 24);
+#endif
             }
             }
 
@@ -2501,6 +2530,9 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                 f.reflective = reflective;
                 f.R = R;
                 f.flags = (has_refr ? F_HAS_REFR : 0) | (use_schlick ? F_SCHLICK : 0);
+#if RTC_DEEP_STACK
+                f.path = path;
+#endif
                 if (has_refr) {
                     FrameRefr fr;
                     fr.ro = under_point;
@@ -2532,7 +2564,11 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
             if (sp == 0) return ret;
             Frame f = stack.get(sp - 1);
             rem++;
+#if RTC_DEEP_STACK
+            path = f.path;
+#else
             path >>= 1;
+#endif
             if (!(f.flags & F_WAIT_REFR)) {
                 V3 reflected = ret * f.reflective;  // world.rs:131
                 V3 partial = (f.flags & F_SCHLICK) ? f.acc + reflected * f.R : f.acc + reflected;

@@ -166,6 +166,25 @@ rtc_status grow_device(char** p, size_t* cap, size_t need) {
     return RTC_OK;
 }
 
+// On any early return after work has been queued: wait for everything queued on the devices touched so far, so that no
+// DMA is still writing into the caller's `out` (or reading staging memory the pool is about to reuse) and no render is
+// left running with nobody to wait for it, when the caller sees the error and frees its buffer.
+struct DrainOnError {
+    std::vector<DevState*> touched;
+    bool ok = false;
+    ~DrainOnError() {
+        if (ok) return;
+        for (DevState* S : touched) {
+            if (S->device < 0) continue;
+            (void)hipSetDevice(S->device);
+            if (S->s_render) (void)hipStreamSynchronize(S->s_render);
+            for (hipStream_t c : S->s_copy2)
+                if (c) (void)hipStreamSynchronize(c);
+        }
+        (void)hipGetLastError();
+    }
+};
+
 struct Chunk {  // one launch: part `part` of `n_parts`
     uint32_t part, rows;
     size_t row0;  // first row inside the device's compact buffer
@@ -237,6 +256,7 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
     std::vector<std::vector<Chunk>> chunks(D);
     std::vector<std::vector<std::vector<Band>>> bands(D);
     const auto t_start = std::chrono::steady_clock::now();
+    DrainOnError drain;
     // ---- phase 1: every device's renders are queued (asynchronous) ------------------------------------------------
     for (uint32_t k = 0; k < D; k++) {
         DevState& S = g_state[k];
@@ -245,6 +265,7 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
             S.device = devices[k];
         }
         HIP_TRY(hipSetDevice(S.device));
+        drain.touched.push_back(&S);
         if (!S.ctx) RTC_TRY(rtc_ctx_create(S.device, &S.ctx));
         if (!S.s_render) HIP_TRY(hipStreamCreateWithFlags(&S.s_render, hipStreamNonBlocking));
         for (hipStream_t& c : S.s_copy2)
@@ -376,6 +397,7 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
     total.rows = H;
     total.gather_ms = (float)wall_ms;
     if (stats) *stats = total;
+    drain.ok = true;
     return RTC_OK;
 }
 

@@ -19,19 +19,20 @@ class Renderer:
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.width, self.height = camera.width, camera.height
         self._ctx = C.c_void_p()
-        L.check(L.lib().rtc_ctx_create(self.device.index, C.byref(self._ctx)))
+        self._lib = L.lib()  # the library that owns this context (tests load a second one beside it: _lib.use_library)
+        L.check(self._lib.rtc_ctx_create(self.device.index, C.byref(self._ctx)))
         self._keep = None
         self.set_scene(world, camera)
 
     def set_scene(self, world, camera):
         cs = world._c()
         self._keep = (cs, camera)
-        L.check(L.lib().rtc_ctx_set_scene(self._ctx, C.byref(cs.scene), C.byref(camera._cam)))
+        L.check(self._lib.rtc_ctx_set_scene(self._ctx, C.byref(cs.scene), C.byref(camera._cam)))
         self.width, self.height = camera.width, camera.height
 
     def close(self):
         if self._ctx:
-            L.lib().rtc_ctx_destroy(self._ctx)
+            self._lib.rtc_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
     def __del__(self):
@@ -45,7 +46,7 @@ class Renderer:
         return L.rtc_partition(band_rows, n_parts, part)
 
     def rows(self, part=None):
-        return int(L.lib().rtc_partition_rows(self.height, C.byref(part) if part is not None else None))
+        return int(self._lib.rtc_partition_rows(self.height, C.byref(part) if part is not None else None))
 
     def alloc(self, part=None):
         return torch.empty((self.rows(part), self.width, 3), dtype=torch.float32, device=self.device)
@@ -57,28 +58,28 @@ class Renderer:
         assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
         assert out.numel() == self.rows(part) * self.width * 3
         s = torch.cuda.current_stream(self.device) if stream is None else stream
-        L.check(L.lib().rtc_ctx_render(self._ctx, int(depth), C.byref(part) if part is not None else None,
+        L.check(self._lib.rtc_ctx_render(self._ctx, int(depth), C.byref(part) if part is not None else None,
                                        C.c_void_p(out.data_ptr()), C.c_void_p(s.cuda_stream)))
         return out
 
     @property
     def kernel_name(self):
-        return L.lib().rtc_ctx_kernel_name(self._ctx).decode()
+        return self._lib.rtc_ctx_kernel_name(self._ctx).decode()
 
     @property
     def kernel_id(self):
         """Names the code object that renders the current scene (rtc_ctx_kernel_id)."""
-        return L.lib().rtc_ctx_kernel_id(self._ctx).decode()
+        return self._lib.rtc_ctx_kernel_id(self._ctx).decode()
 
     @property
     def jit_status(self):
         """"" when the scene's kernel is what the specialisation policy asked for, else the reason (rtc_ctx_jit_status)."""
-        return L.lib().rtc_ctx_jit_status(self._ctx).decode(errors="replace")
+        return self._lib.rtc_ctx_jit_status(self._ctx).decode(errors="replace")
 
     def stats(self):
         """Synchronises with the last render and returns its counters."""
         st = L.rtc_stats()
-        L.check(L.lib().rtc_ctx_stats(self._ctx, C.byref(st)))
+        L.check(self._lib.rtc_ctx_stats(self._ctx, C.byref(st)))
         return {"rays": int(st.rays), "shaded_hits": int(st.shaded_hits), "pixels": int(st.pixels),
                 "kernel_ms": float(st.kernel_ms), "launches": int(st.launches), "rows": int(st.rows),
                 "culled_shadow_rays": int(st.culled_shadow_rays), "flags": int(st.flags)}
@@ -87,11 +88,11 @@ class Renderer:
         """Canvas::to_ppm (canvas.rs:58-96) formatted on the device from an (h, w, 3) f32 tensor -> bytes."""
         assert rgb.is_cuda and rgb.dtype == torch.float32 and rgb.is_contiguous() and rgb.dim() == 3
         h, w = int(rgb.shape[0]), int(rgb.shape[1])
-        cap = int(L.lib().rtc_ppm_max_bytes(w, h))
+        cap = int(self._lib.rtc_ppm_max_bytes(w, h))
         text = torch.empty(cap, dtype=torch.uint8, device=rgb.device)
         n = C.c_uint64()
         s = torch.cuda.current_stream(self.device) if stream is None else stream
-        L.check(L.lib().rtc_ctx_to_ppm(self._ctx, C.c_void_p(rgb.data_ptr()), w, h, C.c_void_p(text.data_ptr()), cap,
+        L.check(self._lib.rtc_ctx_to_ppm(self._ctx, C.c_void_p(rgb.data_ptr()), w, h, C.c_void_p(text.data_ptr()), cap,
                                        C.byref(n), C.c_void_p(s.cuda_stream)))
         return text[: n.value].cpu().numpy().tobytes()
 
@@ -101,6 +102,6 @@ class Renderer:
             out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
         assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() == rgb.numel()
         s = torch.cuda.current_stream(self.device) if stream is None else stream
-        L.check(L.lib().rtc_ctx_quantize(self._ctx, C.c_void_p(rgb.data_ptr()), rgb.numel(),
+        L.check(self._lib.rtc_ctx_quantize(self._ctx, C.c_void_p(rgb.data_ptr()), rgb.numel(),
                                          C.c_void_p(out.data_ptr()), C.c_void_p(s.cuda_stream)))
         return out

@@ -142,7 +142,7 @@ def test_shading_scenarios_match_oracle(kat):  # world.rs:483-537, 646-658, 747-
     w = P.World([P.Plane(P.translation(0.0, -1.0, 0.0), m), P.Plane(P.translation(0.0, 1.0, 0.0), m)],
                 P.PointLight(P.point(0, 0, 0), P.color(0, 0, 0)))
     _both_color_at(w, P.point(0, 0, 0), P.vector(0, 1, 0), 1)
-    _both_color_at(w, P.point(0, 0, 0), P.vector(0, 1, 0), L.RTC_MAX_DEPTH)
+    _both_color_at(w, P.point(0, 0, 0), P.vector(0, 1, 0), L.RTC_STACK_DEPTH_BASE)
 
 
 def test_nested_glass_refraction_indices_match_oracle(kat):  # world.rs:396-451 geometry, traced end to end
@@ -503,7 +503,7 @@ def test_lanes_sharing_a_pixel_change_nothing(name, size, kw, share, monkeypatch
 @pytest.mark.parametrize("variant", ["default", "share0", "share1", "share2", "share3", "blocks_s0", "blocks_s1", "blocks_s3", "no_block_list",
                                      "image_order", "glass_s3", "nodes", "nodes_share0", "nodes_of_2_s1", "nodes_of_16_s3"])
 @pytest.mark.parametrize("name,size", [("mesh", (230, 170)), ("here_be_dragons", (250, 100)), ("mesh", (64, 610))])
-def test_lanes_splitting_leaf_runs_change_nothing(name, size, variant, monkeypatch):
+def test_lanes_splitting_leaf_runs_change_nothing(name, size, variant, monkeypatch, request):
     """Worlds whose GroupShapes hold long runs of leaves (the rings divide() leaves around a mesh): the 2^s lanes of a
     pixel split every run between them (for_each_leaf_shared: nearest hit, point-light shadow ray, the n1/n2 container
     walk), mesh runs take the ray into object space once, and the launch is a block list -- the tiles a mesh projects to
@@ -519,6 +519,9 @@ def test_lanes_splitting_leaf_runs_change_nothing(name, size, variant, monkeypat
            "nodes_of_2_s1": {"RTC_AMD_CLUSTERS": "1", "RTC_AMD_CLUSTER_LEAF": "2", "RTC_AMD_CLUSTER_MIN_RUN": "4", "RTC_AMD_CLUSTER_GMAX": "0.99",
                              "RTC_AMD_BLOCK_S": "1"},
            "nodes_of_16_s3": {"RTC_AMD_CLUSTERS": "1", "RTC_AMD_CLUSTER_LEAF": "16", "RTC_AMD_BLOCK_S": "3"}}[variant]
+    from tests.conftest import DEV_ONLY_SWITCHES
+    if any(k in DEV_ONLY_SWITCHES for k in env):
+        request.getfixturevalue("dev_lib")  # tuning constants are pinned through the development build only
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     r = Renderer(world, camera, device=0)

@@ -233,3 +233,29 @@ def test_scene_validation_without_gpu():
         with pytest.raises(P.RtcError) as e:
             bad.validate()
         assert e.value.status == code
+
+
+def test_the_shipped_library_holds_no_development_switch():
+    """RTC_AMD_JIT_SOURCE / _JIT_FLAGS (an environment variable substituting the kernel source or compiler
+    flags of a host process) and the other development switches are compiled only into librtc_amd_dev.so; the library that
+    ships does not even contain their names.  The policy switches it does read are read when a context is created."""
+    import re
+    from ray_tracer_challenge_amd import _lib as L
+    from tests.conftest import DEV_ONLY_SWITCHES
+    assert P.lib().rtc_dev_switches() in (0, 1)
+    shipped = open(os.path.join(os.path.dirname(L.DEV_LIB_PATH), "librtc_amd.so"), "rb").read()
+    names = set(m.decode() for m in re.findall(rb"RTC_AMD_[A-Z0-9_]+", shipped))
+    assert not names & set(DEV_ONLY_SWITCHES), names & set(DEV_ONLY_SWITCHES)
+    assert {"RTC_AMD_SPECIALIZE", "RTC_AMD_LIGHT_CULL", "RTC_AMD_JIT_CACHE"} <= names
+    if os.path.exists(L.DEV_LIB_PATH):
+        dev = open(L.DEV_LIB_PATH, "rb").read()
+        dev_names = set(m.decode() for m in re.findall(rb"RTC_AMD_[A-Z0-9_]+", dev))
+        assert set(DEV_ONLY_SWITCHES) <= dev_names
+        assert L.load(L.DEV_LIB_PATH).rtc_dev_switches() == 1
+
+
+def test_depth_domain_constants():
+    from ray_tracer_challenge_amd import _lib as L
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rtc.h")).read()
+    assert "#define RTC_MAX_DEPTH %d" % L.RTC_MAX_DEPTH in hdr and "#define RTC_STACK_DEPTH_BASE %d" % L.RTC_STACK_DEPTH_BASE in hdr
+    assert L.RTC_MAX_DEPTH >= 32  # camera.rs:76 takes any i16; the author's own deepest render is 20 (todo.md)

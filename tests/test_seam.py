@@ -223,7 +223,8 @@ def test_library_alone_compiles_its_scene_kernels(tmp_path):
 
 @gpu
 def test_failed_scene_compile_is_reported_not_hidden(tmp_path):
-    bad = {"RTC_AMD_JIT_FLAGS": "-Dnamespace=:", "RTC_AMD_JIT_CACHE": "0"}   # `: rtc {` does not compile
+    # (compiler flags can be substituted in the development build of the library only)
+    bad = {"RTC_AMD_JIT_FLAGS": "-Dnamespace=:", "RTC_AMD_JIT_CACHE": "0", "RTC_AMD_LIB": L.DEV_LIB_PATH}   # `: rtc {` does not compile
     info, img, stderr, _ = _run_alone(tmp_path, bad)
     assert info["kernel"].startswith("render_kernel<"), info            # the ahead-of-time kernel ...
     assert info["flags"] & L.RTC_STATS_JIT_FALLBACK and "failed to compile" in info["jit_status"]   # ... and it says so

@@ -85,7 +85,7 @@ def test_adversarial_rays_match_oracle_bitwise():
     assert (got.sum(axis=1) > 0).mean() > 0.3  # the rays do hit things
 
 
-def test_pre_culling_never_changes_a_ray(monkeypatch):
+def test_pre_culling_never_changes_a_ray(monkeypatch, dev_lib):
     """2 M adversarial rays, depth 4 (reflections, refractions with their n1/n2 walks, shadow rays): identical with the
     pre-culling switched off."""
     world = _world()
@@ -123,9 +123,9 @@ def test_mesh_scenes_render_identically_with_and_without(size, monkeypatch):
         assert out["1"][1]["rays"] == out["0"][1]["rays"] and out["1"][1]["shaded_hits"] == out["0"][1]["shaded_hits"]
 
 
-def test_the_adversarial_rays_do_catch_a_naive_cull(monkeypatch):
-    """The same rays against a cull WITHOUT the plane-angle guard and the padding (RTC_AMD_TRI_NAIVE=1, a test-only
-    switch): the exact f32 test reports hits for some rays that miss the triangle's bounding box -- the cases the
+def test_the_adversarial_rays_do_catch_a_naive_cull(monkeypatch, dev_lib):
+    """The same rays against a cull WITHOUT the plane-angle guard and the padding (RTC_AMD_TRI_NAIVE=1, a switch that exists
+    in the development build of the library only): the exact f32 test reports hits for some rays that miss the triangle's bounding box -- the cases the
     guard and the padding exist for.  If this stopped failing, the tests above would prove nothing."""
     world = _world()
     o, d = _adversarial_rays(world, 2_000_000, seed=11)

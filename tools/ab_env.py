@@ -10,6 +10,9 @@ so that a variant which changes a single output bit is caught at once.  A varian
 import hashlib
 import json
 import os
+
+# the development switches this tool drives exist only in the development build of the library
+os.environ.setdefault("RTC_AMD_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ray_tracer_challenge_amd", "librtc_amd_dev.so"))
 import subprocess
 import sys
 

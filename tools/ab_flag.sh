@@ -1,4 +1,6 @@
 #!/bin/bash
+# the development switches (RTC_AMD_JIT_FLAGS, _BLOCK_S, ...) exist only in the development build of the library
+export RTC_AMD_LIB="${RTC_AMD_LIB:-$(cd "$(dirname "$0")/.." && pwd)/ray_tracer_challenge_amd/librtc_amd_dev.so}"
 # development: A/B of one hiprtc flag over several scenes, interleaved on one box:  tools/ab_flag.sh "-DFOO" "soft_shadows 4096" "mesh 2048" ...
 FLAGS="$1"; shift
 for sc in "$@"; do

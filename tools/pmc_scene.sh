@@ -1,4 +1,6 @@
 #!/bin/bash
+# the development switches (RTC_AMD_JIT_FLAGS, _BLOCK_S, ...) exist only in the development build of the library
+export RTC_AMD_LIB="${RTC_AMD_LIB:-$(cd "$(dirname "$0")/.." && pwd)/ray_tracer_challenge_amd/librtc_amd_dev.so}"
 # quick PMC probe of one scene (development tool): bash tools/pmc_scene.sh <outdir> <scene> <size> [steps] [key=value ...]
 OUT=gpurun_out/${1:-pmc}; shift
 mkdir -p $OUT

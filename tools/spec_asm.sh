@@ -1,4 +1,6 @@
 #!/bin/bash
+# the development switches (RTC_AMD_JIT_FLAGS, _BLOCK_S, ...) exist only in the development build of the library
+export RTC_AMD_LIB="${RTC_AMD_LIB:-$(cd "$(dirname "$0")/.." && pwd)/ray_tracer_challenge_amd/librtc_amd_dev.so}"
 # development: compiles a scene-specialised kernel offline (same flags as rtc_device.hip jit_get) and prints its resource
 # usage; the ISA is left in /tmp/k/<name>.s.   bash tools/spec_asm.sh <name> -DRTC_SPEC_LIST=0x500,0x501 -DRTC_SPEC_NOBJ=2 ...
 NAME=$1; shift

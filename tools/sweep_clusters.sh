@@ -1,4 +1,6 @@
 # A/B of the ring hierarchy (RTC_AMD_CLUSTERS) on the mesh scenes
+# the development switches (RTC_AMD_JIT_FLAGS, _BLOCK_S, ...) exist only in the development build of the library
+export RTC_AMD_LIB="${RTC_AMD_LIB:-$(cd "$(dirname "$0")/.." && pwd)/ray_tracer_challenge_amd/librtc_amd_dev.so}"
 for cfg in "here_be_dragons 1000 400" "here_be_dragons 4000 1600"; do
 set -- $cfg
 python tools/ab_env.py --scene $1 --size $2 --height $3 --steps 6 --rounds 2 "default" "no_clusters|RTC_AMD_CLUSTERS=0" \

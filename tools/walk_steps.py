@@ -8,6 +8,9 @@ boxes tested, leaf boxes tested (tri_precull), exact intersection tests, and the
 (the union of its 64 lanes' paths).  One lane per pixel (RTC_AMD_SHARE_LOG2=0) unless the caller says otherwise.
 """
 import os
+
+# the development switches this tool drives exist only in the development build of the library
+os.environ.setdefault("RTC_AMD_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ray_tracer_challenge_amd", "librtc_amd_dev.so"))
 import sys
 
 import numpy as np

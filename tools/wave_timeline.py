@@ -8,6 +8,9 @@ end on the 100 MHz clock and its HW_ID instead of a colour.  Prints the number o
 length, the distribution of wave lengths, and where in the image the longest waves are.
 """
 import os
+
+# the development switches this tool drives exist only in the development build of the library
+os.environ.setdefault("RTC_AMD_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ray_tracer_challenge_amd", "librtc_amd_dev.so"))
 import sys
 
 import numpy as np
