@@ -477,8 +477,10 @@ def one_shot(world, camera, depth):
     buf = np.zeros((h, w, 3), dtype=np.float32)
     res["f32_pageable_ms"] = timed(lambda: camera.render(world, depth, out=buf))
     res["kernel_ms_in_call"] = round(camera.last_stats["kernel_ms"], 4)
+    res["launches_in_call"] = camera.last_stats["launches"]
     buf8 = np.zeros((h, w, 3), dtype=np.uint8)
     res["u8_pageable_ms"] = timed(lambda: camera.render(world, depth, quantize=True, out=buf8))
+    res["u8_kernel_ms_in_call"] = round(camera.last_stats["kernel_ms"], 4)
     lib, cs = P.lib(), world._c()
     p = lib.rtc_host_alloc(h * w * 12)
     if p:
@@ -488,9 +490,11 @@ def one_shot(world, camera, depth):
             opts = L.rtc_opts(dev, 1, 0, q, 0)
             res[name] = timed(lambda: L.check(lib.rtc_render_ex(C.byref(cs.scene), C.byref(camera._cam), depth, C.byref(opts),
                                                                 C.c_void_p(p), C.byref(st))))
+            res[name.replace("_ms", "_kernel_ms_in_call")] = round(float(st.kernel_ms), 4)
         lib.rtc_host_free(p)
-    res["note"] = ("rtc_render_ex, %dx%d, whole call; pageable: DMA into pinned staging + threaded copy into the caller's buffer; "
-                   "pinned: DMA straight into an rtc_host_alloc buffer" % (w, h))
+    res["note"] = ("rtc_render_ex, %dx%d, whole call: ONE launch whose kernel reports finished chunks of rows, each leaving as it is "
+                   "reported; pageable: DMA into pinned staging + threaded copy into the caller's buffer; pinned: DMA straight into an "
+                   "rtc_host_alloc buffer; u8: scale_color'd bytes stored by the render kernel itself" % (w, h))
     lib.rtc_render_release()
     return res
 

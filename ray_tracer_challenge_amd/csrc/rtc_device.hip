@@ -1165,6 +1165,8 @@ struct rtc_ctx {
     std::vector<float> texels_host;
     uint4* d_block_counts = nullptr;
     size_t block_cap = 0;
+    uint32_t* d_progress = nullptr;  // RenderArgs::progress counters (rtc_render_ex), grow-only
+    size_t progress_cap = 0;         // dwords
     // {rays, shaded hits, culled shadow rays} per counter slot: slot 0 = the last rtc_ctx_render launch; rtc_render_ex
     // renders a frame in several launches (row chunks in flight while earlier ones travel) and gives each its own
     unsigned long long* d_total = nullptr;
@@ -1434,6 +1436,7 @@ void rtc_ctx_destroy(rtc_ctx* c) {
     if (c->d_soa) (void)hipFree(c->d_soa);
     if (c->d_texels) (void)hipFree(c->d_texels);
     if (c->d_block_counts) (void)hipFree(c->d_block_counts);
+    if (c->d_progress) (void)hipFree(c->d_progress);
     if (c->d_total) (void)hipFree(c->d_total);
     if (c->d_ppm_rows) (void)hipFree(c->d_ppm_rows);
     if (c->d_ppm_bits) (void)hipFree(c->d_ppm_bits);
@@ -1862,7 +1865,9 @@ static rtc_status deep_kernel(rtc_ctx* c, int32_t depth, hipFunction_t* out) {
 }
 
 // rtc_ctx_render with a counter slot of the caller's choosing (rtc_internal.h)
-rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* part, void* d_out_rgb, void* stream_, uint32_t slot) {
+rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* part, void* d_out_rgb, void* stream_, uint32_t slot,
+                                ProgressPlan* plan, bool out_u8) {
+    if (plan) plan->n_chunks = 0u, plan->chunk_rows = 0u;
     if (!c) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_render: null argument");
     if (slot >= CTX_TOTAL_SLOTS) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_render: counter slot %u", slot);
     if (!c->has_scene || c->hdr.width == 0) return fail(RTC_ERR_INVALID_ARG, "rtc_ctx_render: no scene/camera set");
@@ -1955,6 +1960,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     uint32_t block_x0 = 0u, block_y0 = 0u;
     unsigned long long extra_rays = 0ull;
     uint32_t fill_wg_rows = 0u, fill_rows = 0u, fill_period = 1u, fill_rect[4] = {0u, 0u, 0u, 0u};
+    bool rect_launch = false;
     if (d_tiles == nullptr && share_log2 == 0u && rows > 0u && c->scene_rect[0] < c->scene_rect[1] && c->scene_rect_coverage < P.scene_rect_threshold() &&
         (spec_fn == nullptr || c->spec_rect)) {
         // local rows of this partition whose global row lies in the rectangle's rows, and the traced ones among them
@@ -1967,6 +1973,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             if (lo < hi) yl0 = std::min(yl0, cursor + (lo - y0)), yl1 = std::max(yl1, cursor + (hi - y0));
             cursor += y1 - y0;
         }
+        rect_launch = true;
         if (yl0 < yl1) {
             block_x0 = c->scene_rect[0];
             block_y0 = yl0 / 16u;
@@ -2009,6 +2016,12 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         fill_wg_rows = std::max(1u, (fill_wgs + grid.x - 1u) / grid.x);
         fill_rows = (rows + fill_wg_rows * grid.x - 1u) / (fill_wg_rows * grid.x);
         fill_period = std::max(1u, (grid.y + fill_wg_rows) / fill_wg_rows);  // spread among the rendering rows: the fill shares the memory system with them
+        if (out_u8) {
+            // a frame of bytes: the zeros outside the rectangle are one asynchronous memset in front of the launch (the
+            // kernel's filling workgroups write f32 rows)
+            HIP_TRY(hipMemsetAsync(d_out_rgb, 0, (size_t)rows * c->hdr.width * 3u, stream));
+            fill_wg_rows = 0u, fill_rows = 0u, fill_period = 1u;
+        }
         grid.y += fill_wg_rows;
     }
     const size_t n_blocks = (size_t)grid.x * grid.y * 4;  // partial counts: one per wave
@@ -2018,6 +2031,24 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         HIP_TRY(hipMalloc(&c->d_block_counts, n_blocks * sizeof(uint4)));
         c->block_cap = n_blocks;
     }
+    // progress reporting: a regular grid only (one workgroup per block, every block of the partition launched)
+    uint32_t chunk_block_rows = 1u, n_chunks = 0u;
+    if (plan && plan->d_done && rows > 0u && d_tiles == nullptr && !rect_launch && blocks_y == 1u) {
+        const uint32_t want = std::max(1u, std::min(plan->want_chunks, PROGRESS_MAX_CHUNKS));
+        chunk_block_rows = (grid.y + want - 1u) / want;
+        n_chunks = (grid.y + chunk_block_rows - 1u) / chunk_block_rows;
+        const size_t words = ((size_t)grid.y + n_chunks) * PROGRESS_STRIDE;
+        if (words > c->progress_cap) {
+            if (c->d_progress) HIP_TRY(hipFree(c->d_progress));
+            c->d_progress = nullptr;
+            c->progress_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_progress, words * sizeof(uint32_t)));
+            c->progress_cap = words;
+        }
+        HIP_TRY(hipMemsetAsync(c->d_progress, 0, words * sizeof(uint32_t), stream));
+        plan->n_chunks = n_chunks;
+        plan->chunk_rows = chunk_block_rows * bh;
+    }
     if (rows == 0) {  // nothing to launch: the slot's counters read zero
         HIP_TRY(hipMemsetAsync(c->d_total + 3 * (size_t)slot, 0, 3 * sizeof(unsigned long long), stream));
         if (slot == 0) c->rendered = false;
@@ -2026,7 +2057,12 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     RenderArgs a;
     a.hdr = c->hdr;
     a.soa = soa_view(c->d_soa, c->hdr, c->d_texels);
-    a.out = (float*)d_out_rgb;
+    a.out = out_u8 ? nullptr : (float*)d_out_rgb;
+    a.out_u8 = out_u8 ? (uint8_t*)d_out_rgb : nullptr;
+    a.progress = n_chunks ? c->d_progress : nullptr;
+    a.done = n_chunks ? plan->d_done : nullptr;
+    a.chunk_block_rows = chunk_block_rows;
+    a.epoch = plan ? plan->epoch : 0u;
     a.block_counts = c->d_block_counts;
     a.total = c->d_total + 3 * (size_t)slot;
     a.rows = rows;

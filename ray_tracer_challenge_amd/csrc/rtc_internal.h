@@ -63,7 +63,19 @@ inline uint32_t partition_rows(uint32_t height, const rtc_partition* p) {
 // Hooks of rtc_device.hip for rtc_render_ex (rtc_oneshot.hip): a frame rendered as several launches, each with a
 // counter slot of its own.  `stream`: a hipStream_t.
 constexpr uint32_t CTX_TOTAL_SLOTS = 64;
-rtc_status ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* part, void* d_out_rgb, void* stream, uint32_t slot);
+// Progress reporting of one launch (RenderArgs::progress): in -- where the host words live, how many chunks the caller
+// would like, this frame's epoch; out -- how the launch's rows were cut (n_chunks == 0: this launch cannot report -- a
+// block list, a scene rectangle, several blocks per workgroup -- and the caller waits for the stream instead).
+struct ProgressPlan {
+    uint32_t* d_done;      // device-visible address of the page-locked host words, one per chunk (>= PROGRESS_MAX_CHUNKS)
+    uint32_t want_chunks, epoch;
+    uint32_t n_chunks, chunk_rows;  // out: chunk j = local rows [j * chunk_rows, min(rows, (j + 1) * chunk_rows))
+};
+constexpr uint32_t PROGRESS_MAX_CHUNKS = 64;
+// out_u8: the frame is stored as the bytes Canvas::to_ppm prints (scale_color, canvas.rs:39-43) -- `d_out` then holds
+// rows * width * 3 bytes -- instead of f32 RGB.
+rtc_status ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* part, void* d_out, void* stream, uint32_t slot,
+                           ProgressPlan* plan = nullptr, bool out_u8 = false);
 rtc_status ctx_collect(rtc_ctx* c, uint32_t n_slots, rtc_stats* out);
 
 }  // namespace rtc

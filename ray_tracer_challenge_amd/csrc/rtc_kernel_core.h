@@ -2601,7 +2601,8 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
 struct RenderArgs {
     SceneHdr hdr;
     SceneSoA soa;
-    float* out;            // compact rows of this partition: [rows][width][3]
+    float* out;            // compact rows of this partition: [rows][width][3] ...
+    uint8_t* out_u8;       // ... or, when not null, the same rows as the bytes Canvas::to_ppm prints (scale_color, canvas.rs:39-43)
     uint4* block_counts;   // one partial {rays, shaded hits, culled shadow rays, 0} per wave (4 per workgroup)
     unsigned long long* total;  // {rays, shaded hits, culled}: zeroed here, accumulated by sum_counts_kernel
     uint32_t rows;         // rows in `out`
@@ -2622,7 +2623,18 @@ struct RenderArgs {
     uint32_t block_x0, block_y0;
     uint32_t fill_wg_rows, fill_rows, fill_x0, fill_x1, fill_y0, fill_y1;
     uint32_t fill_period;  // row j * fill_period of the grid is the j-th row of filling workgroups (j < fill_wg_rows), the others render
+    // Progress reporting (rtc_render_ex, regular grid only; nullptr otherwise): the frame is ONE launch, and its rows leave
+    // for the host while later rows are still being rendered.  A workgroup whose four waves have stored their pixels adds one
+    // to its block row's counter; the workgroup that completes a block row adds one to the counter of the row's CHUNK
+    // (chunk_block_rows consecutive block rows); the one that completes a chunk writes `epoch` into the chunk's word of
+    // `done` -- page-locked host memory the caller polls before it starts that chunk's copy.  Every step is a release /
+    // acquire pair at the scope of whoever reads next (workgroup, device, system), so the pixels are in memory before
+    // the word that announces them (render_body, end).  Counters are PROGRESS_STRIDE dwords apart (one cache line each).
+    uint32_t* progress;       // [gridDim.y] block-row counters, then [n_chunks] chunk counters; zeroed before the launch
+    uint32_t* done;           // [n_chunks], host memory
+    uint32_t chunk_block_rows, epoch;
 };
+constexpr uint32_t PROGRESS_STRIDE = 16;
 
 // One of the launch's first workgroups (render_body): zero the part outside the scene rectangle of its share of the rows.
 // Memory-bound work running beside the arithmetic-bound rendering; 16-byte stores where rows and segments are aligned to
@@ -2706,6 +2718,11 @@ DI void render_body(const RenderArgs& A) {
 #endif
     __shared__ float stash_lds[LDS_SLOTS * 256];
     const LaneStash stash = {stash_lds + threadIdx.x, 256u};
+    __shared__ uint32_t waves_done;  // progress reporting: how many of this workgroup's waves have stored their pixels
+    if (A.progress != nullptr) {     // wave-uniform (a kernel argument)
+        if (threadIdx.x == 0) waves_done = 0u;
+        __syncthreads();
+    }
     // A workgroup of the regular grid renders `blocks_y` blocks, one below the other (host: frames whose waves are so
     // short -- C5: 95 % of 67 M pixels miss the scene's box -- that launching them is what the frame costs)
     // Compiled in only where the host asks for it (-DRTC_SPEC_BLOCKS_Y=1): the loop's carried state costs other kernels
@@ -2765,10 +2782,17 @@ DI void render_body(const RenderArgs& A) {
         col = v3(__uint_as_float(dbg_steps()[0] | dbg_steps()[2] << 20), __uint_as_float(dbg_steps()[1]), __uint_as_float(dbg_steps()[3]));
 #endif
         if (cnt.lead()) {
-            float* dst = A.out + ((size_t)yl * H.width + x) * 3;
-            dst[0] = col.x;
-            dst[1] = col.y;
-            dst[2] = col.z;
+            if (A.out_u8 != nullptr) {  // wave-uniform: scale_color on the way out (the arithmetic of quantize_kernel)
+                uint8_t* dst = A.out_u8 + ((size_t)yl * H.width + x) * 3;
+                dst[0] = (uint8_t)fmaxf(fminf(col.x * 255.0f, 255.0f), 0.0f);
+                dst[1] = (uint8_t)fmaxf(fminf(col.y * 255.0f, 255.0f), 0.0f);
+                dst[2] = (uint8_t)fmaxf(fminf(col.z * 255.0f, 255.0f), 0.0f);
+            } else {
+                float* dst = A.out + ((size_t)yl * H.width + x) * 3;
+                dst[0] = col.x;
+                dst[1] = col.y;
+                dst[2] = col.z;
+            }
         }
     }
     }
@@ -2784,6 +2808,23 @@ DI void render_body(const RenderArgs& A) {
     // depth of recursion -- the edge of a glass ball -- the waiting waves were holding the slots of the next workgroup)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) A.total[threadIdx.x] = 0ull;  // for sum_counts_kernel's atomics
     if (lane == 0) A.block_counts[slot + wave] = make_uint4(rays, shaded, culled, 0u);
+    if (A.progress != nullptr) {  // see RenderArgs::progress
+        // this wave's stores are out of the wave (release at workgroup scope) before it counts itself done; the wave that
+        // counts last has thereby seen all four (acquire) ...
+        uint32_t last = 0u;
+        if (lane == 0) last = __hip_atomic_fetch_add(&waves_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 3u ? 1u : 0u;
+        if (__builtin_amdgcn_readfirstlane((int)last) != 0 && lane == 0) {
+            // ... and passes them on at device scope (this XCD's L2 is written back before the counter moves), block row
+            // by block row, chunk by chunk; the word the host reads is stored with a system-scope release
+            const uint32_t row = blockIdx.y;
+            if (__hip_atomic_fetch_add(&A.progress[row * PROGRESS_STRIDE], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x) {
+                const uint32_t ch = row / A.chunk_block_rows;
+                const uint32_t in_chunk = min(A.chunk_block_rows, gridDim.y - ch * A.chunk_block_rows);
+                if (__hip_atomic_fetch_add(&A.progress[(gridDim.y + ch) * PROGRESS_STRIDE], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_chunk)
+                    __hip_atomic_store(&A.done[ch], A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 #ifdef RTC_SPEC_LIST

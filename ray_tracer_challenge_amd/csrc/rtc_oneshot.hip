@@ -7,8 +7,9 @@
 //
 //   * the image's 64-row bands are dealt round-robin over the devices of opts->devices (pixels are independent,
 //     camera.rs:80-85; the jitter key is the global pixel index, so any split assembles to the same image);
-//   * each device's share is rendered as several launches (row chunks: part k + D*j of D*C parts, rtc_partition), so
-//     chunk j travels while chunk j+1 renders;
+//   * each device's share is rendered by ONE launch whose kernel reports, chunk of rows by chunk of rows, what it has
+//     finished (RenderArgs::progress: a word per chunk in page-locked host memory), so chunk j travels while the rows
+//     after it are still being rendered -- and the frame's kernel time is that of a single launch;
 //   * host output: every device copies its own chunks to the host over its own PCIe link -- straight into `out` when
 //     that is page-locked memory (rtc_host_alloc), else through two pinned staging buffers that a small thread pool
 //     empties into `out` while the next DMA runs (a plain hipMemcpy into pageable memory runs at ~10 GB/s here);
@@ -127,14 +128,15 @@ class CopyPool {
 struct DevState {
     int device = -1;
     rtc_ctx* ctx = nullptr;
-    char* d_out = nullptr;  // this device's rows (f32), chunk after chunk
+    char* d_out = nullptr;  // this device's rows, band after band: f32 RGB, or bytes (opts->quantize)
     size_t d_out_cap = 0;
-    char* d_u8 = nullptr;  // the same rows as bytes (opts->quantize)
-    size_t d_u8_cap = 0;
     char* h_stage[2] = {nullptr, nullptr};  // pinned
     size_t stage_cap = 0;
     hipStream_t s_render = nullptr, s_copy2[2] = {nullptr, nullptr};  // chunks alternate between two copy streams: two DMA engines
-    std::vector<hipEvent_t> ev_render, ev_copy;
+    std::vector<hipEvent_t> ev_copy;
+    uint32_t* h_done = nullptr;  // page-locked host words the render kernel reports finished chunks in (RenderArgs::done)
+    uint32_t* d_done = nullptr;  // ... as the device addresses them
+    uint32_t epoch = 0;          // this call's value of a finished chunk's word
 
     void release() {
         if (device < 0) return;
@@ -142,10 +144,9 @@ struct DevState {
         (void)hipDeviceSynchronize();
         if (ctx) rtc_ctx_destroy(ctx);
         if (d_out) (void)hipFree(d_out);
-        if (d_u8) (void)hipFree(d_u8);
         for (char*& h : h_stage)
             if (h) (void)hipHostFree(h), h = nullptr;
-        for (hipEvent_t e : ev_render) (void)hipEventDestroy(e);
+        if (h_done) (void)hipHostFree(h_done);
         for (hipEvent_t e : ev_copy) (void)hipEventDestroy(e);
         if (s_render) (void)hipStreamDestroy(s_render);
         for (hipStream_t& c : s_copy2)
@@ -185,13 +186,22 @@ struct DrainOnError {
     }
 };
 
-struct Chunk {  // one launch: part `part` of `n_parts`
-    uint32_t part, rows;
-    size_t row0;  // first row inside the device's compact buffer
-};
-struct Band {  // one contiguous run of image rows inside a chunk
-    size_t src_row;  // row inside the device's compact buffer
+struct Band {  // one contiguous run of image rows inside a device's compact buffer
+    size_t src_row;  // row inside the compact buffer
     uint32_t y0, rows;
+};
+// One device's share of a frame while it is in flight: ONE launch, cut into chunks of consecutive compact rows that the
+// kernel reports finished one by one (RenderArgs::progress) -- or, for launches that cannot report, one chunk that is
+// finished when the stream is.
+struct Share {
+    uint32_t rows = 0, n_chunks = 0, chunk_rows = 0;
+    bool reports = false;        // the kernel writes S.h_done[j] = S.epoch as chunk j completes
+    bool stream_done = false;    // the render stream has been seen idle: every chunk is complete whatever the words say
+    std::vector<Band> bands;     // all bands of the device, in compact order
+    uint32_t next_copy = 0;      // chunks [0, next_copy) have their transfer queued
+    uint32_t next_unstage = 0;   // pageable output: chunks [0, next_unstage) are in `out`
+    uint32_t chunk_row0(uint32_t j) const { return std::min(rows, j * chunk_rows); }
+    uint32_t chunk_row1(uint32_t j) const { return std::min(rows, (j + 1) * chunk_rows); }
 };
 
 }  // namespace
@@ -237,13 +247,8 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
     std::lock_guard<std::mutex> lock(g_mutex);
     if (g_state.size() < D) g_state.resize(D);
     const uint32_t W = camera->width, H = camera->height;
-    const size_t px_bytes = quantize ? 3 : 12, row_out = (size_t)W * px_bytes, row_f32 = (size_t)W * 12;
+    const size_t px_bytes = quantize ? 3 : 12, row_out = (size_t)W * px_bytes;
     const uint32_t n_bands = (H + band_rows - 1) / band_rows;
-    // chunks per device: ~24 MB of output each, at most 16, at least one band each
-    const size_t share_bytes = (size_t)((n_bands + D - 1) / D) * band_rows * row_out;
-    uint32_t C = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, (share_bytes + (24u << 20) - 1) / (24u << 20)));
-    C = std::min(C, std::max(1u, (n_bands + D - 1) / D));
-    const uint32_t n_parts = D * C;
 
     // is `out` page-locked host memory (then DMA goes straight into it)?
     bool out_pinned = false;
@@ -252,14 +257,18 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
         if (hipPointerGetAttributes(&attr, out) == hipSuccess) out_pinned = attr.type == hipMemoryTypeHost;
         else (void)hipGetLastError();
     }
+    const bool staged = !on_device && !out_pinned;
 
-    std::vector<std::vector<Chunk>> chunks(D);
-    std::vector<std::vector<std::vector<Band>>> bands(D);
+    std::vector<Share> shares(D);
     const auto t_start = std::chrono::steady_clock::now();
     DrainOnError drain;
-    // ---- phase 1: every device's renders are queued (asynchronous) ------------------------------------------------
+    // ---- phase 1: every device's render is queued: ONE launch each, asynchronous ---------------------------------------
+    // (Round 2 cut a device's share into ~24 MB launches so that one could travel while the next rendered; every launch
+    // then ended in its own tail of a few long waves, and the frame's kernel time was 2.5 times that of a single launch.
+    // Now the kernel itself says which rows are done.)
     for (uint32_t k = 0; k < D; k++) {
         DevState& S = g_state[k];
+        Share& sh = shares[k];
         if (S.device != devices[k]) {
             S.release();
             S.device = devices[k];
@@ -270,111 +279,169 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
         if (!S.s_render) HIP_TRY(hipStreamCreateWithFlags(&S.s_render, hipStreamNonBlocking));
         for (hipStream_t& c : S.s_copy2)
             if (!c) HIP_TRY(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
-        while (S.ev_render.size() < C) {
+        while (S.ev_copy.size() < PROGRESS_MAX_CHUNKS) {
             hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            S.ev_render.push_back(e);
             HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             S.ev_copy.push_back(e);
         }
+        if (!S.h_done) {
+            HIP_TRY(hipHostMalloc((void**)&S.h_done, PROGRESS_MAX_CHUNKS * sizeof(uint32_t), hipHostMallocMapped));
+            std::memset(S.h_done, 0, PROGRESS_MAX_CHUNKS * sizeof(uint32_t));
+            HIP_TRY(hipHostGetDevicePointer((void**)&S.d_done, S.h_done, 0));
+        }
+        if (++S.epoch == 0u) {  // (wrapped: words of 2^32 frames ago must not read as this frame's)
+            std::memset(S.h_done, 0, PROGRESS_MAX_CHUNKS * sizeof(uint32_t));
+            S.epoch = 1u;
+        }
         RTC_TRY(rtc_ctx_set_scene(S.ctx, scene, camera));  // a no-op when this very scene is resident already
-        size_t rows_total = 0, chunk_max = 0;
-        for (uint32_t j = 0; j < C; j++) {
-            rtc_partition part = {band_rows, n_parts, k + D * j};
-            Chunk c = {part.part, rtc_partition_rows(H, &part), rows_total};
-            std::vector<Band> bl;
-            size_t r = rows_total;
-            for (uint32_t b = c.part; b < n_bands; b += n_parts) {
-                const uint32_t y0 = b * band_rows, y1 = std::min(H, y0 + band_rows);
-                bl.push_back({r, y0, y1 - y0});
-                r += y1 - y0;
-            }
-            rows_total += c.rows;
-            chunk_max = std::max(chunk_max, (size_t)c.rows);
-            chunks[k].push_back(c);
-            bands[k].push_back(bl);
+        rtc_partition part = {band_rows, D, k};
+        sh.rows = rtc_partition_rows(H, &part);
+        size_t r = 0;
+        for (uint32_t b = k; b < n_bands; b += D) {
+            const uint32_t y0 = b * band_rows, y1 = std::min(H, y0 + band_rows);
+            if (!sh.bands.empty() && sh.bands.back().y0 + sh.bands.back().rows == y0) sh.bands.back().rows += y1 - y0;  // (one device: one run)
+            else sh.bands.push_back({r, y0, y1 - y0});
+            r += y1 - y0;
         }
-        RTC_TRY(grow_device(&S.d_out, &S.d_out_cap, std::max<size_t>(1, rows_total * row_f32)));
-        if (quantize) RTC_TRY(grow_device(&S.d_u8, &S.d_u8_cap, std::max<size_t>(1, rows_total * (size_t)W * 3)));
-        if (!on_device && !out_pinned && chunk_max * row_out > S.stage_cap) {
-            for (char*& h : S.h_stage) {
-                if (h) (void)hipHostFree(h);
-                h = nullptr;
+        RTC_TRY(grow_device(&S.d_out, &S.d_out_cap, std::max<size_t>(1, (size_t)sh.rows * row_out)));
+        // chunks of about 8 MB of output: small enough for the first to leave early and the last to be short, large enough
+        // for a DMA to run at the link's rate
+        ProgressPlan plan;
+        plan.d_done = S.d_done;
+        plan.epoch = S.epoch;
+        plan.want_chunks = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, ((size_t)sh.rows * row_out + (8u << 20) - 1) / (8u << 20)));
+        plan.n_chunks = plan.chunk_rows = 0u;
+        RTC_TRY(ctx_render_slot(S.ctx, depth, &part, S.d_out, S.s_render, 0u, &plan, quantize));
+        sh.reports = plan.n_chunks != 0u;
+        sh.n_chunks = sh.rows == 0u ? 0u : sh.reports ? plan.n_chunks : 1u;
+        sh.chunk_rows = sh.reports ? plan.chunk_rows : sh.rows;
+        if (staged && sh.rows) {
+            const size_t need = (size_t)std::min(sh.rows, sh.chunk_rows) * row_out;
+            if (need > S.stage_cap) {
+                for (char*& h : S.h_stage) {
+                    if (h) (void)hipHostFree(h);
+                    h = nullptr;
+                }
+                S.stage_cap = 0;
+                for (char*& h : S.h_stage) HIP_TRY(hipHostMalloc((void**)&h, need, hipHostMallocDefault));
+                S.stage_cap = need;
             }
-            S.stage_cap = 0;
-            for (char*& h : S.h_stage) HIP_TRY(hipHostMalloc((void**)&h, chunk_max * row_out, hipHostMallocDefault));
-            S.stage_cap = chunk_max * row_out;
-        }
-        for (uint32_t j = 0; j < C; j++) {
-            const Chunk& c = chunks[k][j];
-            rtc_partition part = {band_rows, n_parts, c.part};
-            RTC_TRY(ctx_render_slot(S.ctx, depth, &part, S.d_out + c.row0 * row_f32, S.s_render, j));
-            if (quantize && c.rows)
-                RTC_TRY(rtc_ctx_quantize(S.ctx, S.d_out + c.row0 * row_f32, (uint64_t)c.rows * W * 3, S.d_u8 + c.row0 * (size_t)W * 3, S.s_render));
-            HIP_TRY(hipEventRecord(S.ev_render[j], S.s_render));
         }
     }
-    // ---- phase 2: the rows travel ---------------------------------------------------------------------------------
-    auto src_of = [&](uint32_t k) { return quantize ? g_state[k].d_u8 : g_state[k].d_out; };
-    if (on_device || out_pinned) {
-        // band by band straight to where it belongs (device memory on devices[0], or page-locked host memory)
-        for (uint32_t j = 0; j < C; j++)
-            for (uint32_t k = 0; k < D; k++) {
-                DevState& S = g_state[k];
-                HIP_TRY(hipSetDevice(S.device));
-                hipStream_t s_copy = S.s_copy2[j & 1];
-                HIP_TRY(hipStreamWaitEvent(s_copy, S.ev_render[j], 0));
-                for (const Band& b : bands[k][j]) {
-                    char* dst = (char*)out + (size_t)b.y0 * row_out;
-                    const char* src = src_of(k) + b.src_row * row_out;
-                    const size_t n = (size_t)b.rows * row_out;
-                    if (!on_device) HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s_copy));
-                    else if (S.device == devices[0]) HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s_copy));
-                    else HIP_TRY(hipMemcpyPeerAsync(dst, devices[0], src, S.device, n, s_copy));
-                }
-            }
-        for (uint32_t k = 0; k < D; k++) {
-            HIP_TRY(hipSetDevice(g_state[k].device));
-            for (hipStream_t c : g_state[k].s_copy2) HIP_TRY(hipStreamSynchronize(c));
+    // ---- phase 2: the rows travel as their chunks are reported finished -------------------------------------------------
+    // chunk j of device k is complete when the kernel has stored the frame's epoch into its word, or when the device's
+    // render stream has been seen idle (launches that cannot report; and the safety net: a stream that is done has
+    // written everything)
+    auto chunk_ready = [&](uint32_t k, uint32_t j) {
+        DevState& S = g_state[k];
+        Share& sh = shares[k];
+        if (sh.stream_done) return true;
+        if (sh.reports && __atomic_load_n(&S.h_done[j], __ATOMIC_ACQUIRE) == S.epoch) return true;
+        return false;
+    };
+    auto poll_stream = [&](uint32_t k) -> rtc_status {
+        DevState& S = g_state[k];
+        HIP_TRY(hipSetDevice(S.device));
+        const hipError_t q = hipStreamQuery(S.s_render);
+        if (q == hipSuccess) shares[k].stream_done = true;
+        else if (q != hipErrorNotReady) return fail(RTC_ERR_DEVICE, "render failed: %s", hipGetErrorString(q));
+        else (void)hipGetLastError();
+        return RTC_OK;
+    };
+    // the compact rows [r0, r1) of device k as runs of image rows
+    auto for_each_run = [&](uint32_t k, uint32_t r0, uint32_t r1, const std::function<rtc_status(size_t, uint32_t, uint32_t)>& fn) -> rtc_status {
+        for (const Band& b : shares[k].bands) {
+            const size_t lo = std::max<size_t>(b.src_row, r0), hi = std::min<size_t>(b.src_row + b.rows, r1);
+            if (lo < hi) RTC_TRY(fn(lo, (uint32_t)(b.y0 + (lo - b.src_row)), (uint32_t)(hi - lo)));
         }
-    } else {
-        // pageable host memory: DMA into pinned staging (two slots per device), emptied into `out` by the copy pool
-        // while the next chunk's DMA runs
-        auto enqueue = [&](uint32_t k, uint32_t j) -> rtc_status {
-            DevState& S = g_state[k];
-            const Chunk& c = chunks[k][j];
-            HIP_TRY(hipSetDevice(S.device));
-            hipStream_t s_copy = S.s_copy2[j & 1];  // (slot j & 1 of the staging memory belongs to this stream alone)
-            HIP_TRY(hipStreamWaitEvent(s_copy, S.ev_render[j], 0));
-            if (c.rows) HIP_TRY(hipMemcpyAsync(S.h_stage[j & 1], src_of(k) + c.row0 * row_out, (size_t)c.rows * row_out, hipMemcpyDeviceToHost, s_copy));
-            HIP_TRY(hipEventRecord(S.ev_copy[j], s_copy));
-            return RTC_OK;
+        return RTC_OK;
+    };
+    auto queue_copy = [&](uint32_t k, uint32_t j) -> rtc_status {
+        DevState& S = g_state[k];
+        Share& sh = shares[k];
+        HIP_TRY(hipSetDevice(S.device));
+        hipStream_t s_copy = S.s_copy2[j & 1];
+        const uint32_t r0 = sh.chunk_row0(j), r1 = sh.chunk_row1(j);
+        if (staged) {  // DMA into pinned staging slot j & 1 (this stream's alone), emptied into `out` by the copy pool
+            if (r1 > r0) HIP_TRY(hipMemcpyAsync(S.h_stage[j & 1], S.d_out + (size_t)r0 * row_out, (size_t)(r1 - r0) * row_out, hipMemcpyDeviceToHost, s_copy));
+        } else {  // straight to where the rows belong: page-locked host memory, or device memory on devices[0]
+            RTC_TRY(for_each_run(k, r0, r1, [&](size_t src_row, uint32_t y0, uint32_t nrows) -> rtc_status {
+                char* dst = (char*)out + (size_t)y0 * row_out;
+                const char* src = S.d_out + src_row * row_out;
+                const size_t n = (size_t)nrows * row_out;
+                if (!on_device) HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s_copy));
+                else if (S.device == devices[0]) HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s_copy));
+                else HIP_TRY(hipMemcpyPeerAsync(dst, devices[0], src, S.device, n, s_copy));
+                return RTC_OK;
+            }));
+        }
+        HIP_TRY(hipEventRecord(S.ev_copy[j], s_copy));
+        return RTC_OK;
+    };
+    CopyPool& pool = CopyPool::get();
+    auto unstage = [&](uint32_t k, uint32_t j) -> rtc_status {  // staging slot j & 1 -> `out`, in pieces of ~1 MB so that every thread of the pool has work
+        DevState& S = g_state[k];
+        Share& sh = shares[k];
+        struct Piece {
+            char* dst;
+            const char* src;
+            size_t n;
         };
-        for (uint32_t k = 0; k < D; k++)
-            for (uint32_t j = 0; j < std::min(2u, C); j++) RTC_TRY(enqueue(k, j));
-        CopyPool& pool = CopyPool::get();
-        for (uint32_t j = 0; j < C; j++)
-            for (uint32_t k = 0; k < D; k++) {
-                DevState& S = g_state[k];
-                HIP_TRY(hipSetDevice(S.device));
-                HIP_TRY(hipEventSynchronize(S.ev_copy[j]));
-                // split the chunk's bands into pieces of ~1 MB so that every thread of the pool has work
-                struct Piece {
-                    char* dst;
-                    const char* src;
-                    size_t n;
-                };
-                std::vector<Piece> pieces;
-                const char* stage = S.h_stage[j & 1];
-                const size_t row0 = chunks[k][j].row0;
-                for (const Band& b : bands[k][j]) {
-                    const size_t total = (size_t)b.rows * row_out, step = std::max<size_t>(row_out, ((1u << 20) / row_out) * row_out);
-                    for (size_t off = 0; off < total; off += step)
-                        pieces.push_back({(char*)out + (size_t)b.y0 * row_out + off, stage + (b.src_row - row0) * row_out + off, std::min(step, total - off)});
-                }
-                pool.parallel_for(pieces.size(), [&](size_t i) { std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].n); });
-                if (j + 2 < C) RTC_TRY(enqueue(k, j + 2));
+        std::vector<Piece> pieces;
+        const char* stage = S.h_stage[j & 1];
+        const uint32_t r0 = sh.chunk_row0(j), r1 = sh.chunk_row1(j);
+        RTC_TRY(for_each_run(k, r0, r1, [&](size_t src_row, uint32_t y0, uint32_t nrows) -> rtc_status {
+            const size_t total = (size_t)nrows * row_out, step = std::max<size_t>(row_out, ((1u << 20) / row_out) * row_out);
+            for (size_t off = 0; off < total; off += step)
+                pieces.push_back({(char*)out + (size_t)y0 * row_out + off, stage + (src_row - r0) * row_out + off, std::min(step, total - off)});
+            return RTC_OK;
+        }));
+        pool.parallel_for(pieces.size(), [&](size_t i) { std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].n); });
+        return RTC_OK;
+    };
+    for (uint32_t idle = 0;;) {
+        bool all_done = true, progressed = false;
+        for (uint32_t k = 0; k < D; k++) {
+            DevState& S = g_state[k];
+            Share& sh = shares[k];
+            // queue the transfer of the next finished chunk (pageable output: while one of the two staging slots is free)
+            if (sh.next_copy < sh.n_chunks && (!staged || sh.next_copy < sh.next_unstage + 2u) && chunk_ready(k, sh.next_copy)) {
+                RTC_TRY(queue_copy(k, sh.next_copy));
+                sh.next_copy++;
+                progressed = true;
             }
+            // pageable output: empty the oldest staging slot whose DMA has landed
+            if (staged && sh.next_unstage < sh.next_copy) {
+                HIP_TRY(hipSetDevice(S.device));
+                const hipError_t q = hipEventQuery(S.ev_copy[sh.next_unstage]);
+                if (q == hipSuccess) {
+                    RTC_TRY(unstage(k, sh.next_unstage));
+                    sh.next_unstage++;
+                    progressed = true;
+                } else if (q != hipErrorNotReady) {
+                    return fail(RTC_ERR_DEVICE, "transfer failed: %s", hipGetErrorString(q));
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+            if (sh.next_copy < sh.n_chunks || (staged && sh.next_unstage < sh.n_chunks)) all_done = false;
+        }
+        if (all_done) break;
+        if (progressed) {
+            idle = 0;
+            continue;
+        }
+        // nothing to do yet: look at the render streams now and then (a finished stream finishes all its chunks), else
+        // spin -- the wait is microseconds to a few hundred of them
+        if ((++idle & 255u) == 0u || D > 1) {
+            for (uint32_t k = 0; k < D; k++)
+                if (!shares[k].stream_done && shares[k].next_copy < shares[k].n_chunks) RTC_TRY(poll_stream(k));
+        }
+        if (idle > 4096u) std::this_thread::yield();
+    }
+    for (uint32_t k = 0; k < D; k++) {
+        HIP_TRY(hipSetDevice(g_state[k].device));
+        for (hipStream_t c : g_state[k].s_copy2) HIP_TRY(hipStreamSynchronize(c));
     }
     const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     // ---- statistics -------------------------------------------------------------------------------------------------
@@ -385,7 +452,7 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
         HIP_TRY(hipSetDevice(S.device));
         HIP_TRY(hipStreamSynchronize(S.s_render));
         rtc_stats s;
-        RTC_TRY(ctx_collect(S.ctx, C, &s));
+        RTC_TRY(ctx_collect(S.ctx, 1u, &s));
         total.rays += s.rays;
         total.shaded_hits += s.shaded_hits;
         total.culled_shadow_rays += s.culled_shadow_rays;

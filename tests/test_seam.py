@@ -129,6 +129,52 @@ def test_render_ex_pinned_and_device_output():
 
 
 @gpu
+def test_rows_leave_while_later_rows_render():
+    """rtc_render_ex renders a device's share in ONE launch whose kernel reports finished chunks of rows (RenderArgs::
+    progress), and every chunk's transfer starts when its word arrives -- while later rows are still being rendered.  At
+    sizes that make several chunks (~8 MB each), with DIFFERENT frames alternating in the same persistent buffers -- a chunk
+    copied before its rows were in memory would carry the previous frame's pixels -- f32 and u8, pageable and page-locked
+    output, one device and a device listed twice: every frame equals the persistent-context render of the same scene,
+    which the full-size tests compare with the oracle."""
+    import torch
+    from ray_tracer_challenge_amd.renderer import Renderer
+    frames = []
+    for world, camera, depth in (scenes.soft_shadows(2048, 1536, jitter=("hashed", scenes.DEFAULT_SEED)),
+                                 scenes.glass_and_mirror(2048, 1536), scenes.first_scene(2048, 1536)):
+        r = Renderer(world, camera, device=0)
+        img_t = r.render(depth)
+        st = r.stats()
+        frames.append((world, camera, depth, img_t.cpu().numpy(), r.quantize(img_t).cpu().numpy(), st["rays"]))
+        r.close()
+    lib = P.lib()
+    nbytes = 2048 * 1536 * 12
+    pinned = lib.rtc_host_alloc(nbytes)
+    assert pinned
+    try:
+        for rep in range(3):
+            for world, camera, depth, want, want_u8, rays in frames:
+                cs = world._c()
+                for devices in ([0], [0, 0]):
+                    arr = (C.c_int32 * len(devices))(*devices)
+                    canvas = camera.render(world, depth, devices=devices)                      # pageable, f32: ~5 chunks of rows
+                    assert np.array_equal(canvas.data.view(np.uint32), want.view(np.uint32)) and camera.last_stats["rays"] == rays
+                    assert camera.last_stats["launches"] == len(devices)                       # one launch per device, however many chunks
+                    q = camera.render(world, depth, devices=devices, quantize=True)            # pageable, u8: bytes stored by the kernel
+                    assert np.array_equal(q, want_u8) and camera.last_stats["rays"] == rays
+                    for quantize in (0, 1):                                                     # page-locked: DMA straight into `out`
+                        st = L.rtc_stats()
+                        C.memset(pinned, 0xAB, nbytes)
+                        L.check(lib.rtc_render_ex(C.byref(cs.scene), C.byref(camera._cam), depth,
+                                                  C.byref(L.rtc_opts(arr, len(devices), 0, quantize, 0)), C.c_void_p(pinned), C.byref(st)))
+                        n = 2048 * 1536 * 3
+                        got = np.ctypeslib.as_array(C.cast(pinned, C.POINTER(C.c_uint8 if quantize else C.c_uint32)), shape=(n,)).reshape(1536, 2048, 3)
+                        assert np.array_equal(got, want_u8 if quantize else want.view(np.uint32)) and st.rays == rays and st.launches == len(devices)
+    finally:
+        lib.rtc_host_free(pinned)
+        lib.rtc_render_release()
+
+
+@gpu
 def test_render_ex_keeps_state_between_calls_and_follows_scene_changes():
     """The context, buffers and compiled kernel are kept between calls; a changed scene, camera or size must still be
     picked up (the resident-scene shortcut compares the flattened records, not pointers)."""
