@@ -90,8 +90,10 @@ static rtc_status check_tuple(const float v[4], float w, const char* what) {
 static void pack_geometry(const rtc_object& o, float4 g[4]) {
     uint32_t bits = (uint32_t)o.kind | (o.casts_shadow ? SHAPE_CASTS : 0u) | (o.closed ? SHAPE_CLOSED : 0u);
     if (o.inv[1] == 0.0f && o.inv[2] == 0.0f && o.inv[4] == 0.0f && o.inv[6] == 0.0f && o.inv[8] == 0.0f &&
-        o.inv[9] == 0.0f)
+        o.inv[9] == 0.0f) {
         bits |= SHAPE_DIAG;
+        if (o.inv[0] == o.inv[5] && o.inv[5] == o.inv[10]) bits |= SHAPE_UNIFORM;  // a uniform scale (shadow_fast)
+    }
     float bits_f;
     std::memcpy(&bits_f, &bits, 4);
     g[0] = make_float4(o.inv[0], o.inv[5], o.inv[10], bits_f);
@@ -1712,7 +1714,13 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     }
     int reg_levels = P.reg_levels;
     if (!any_refl && !any_refr) reg_levels = 0;
-    std::vector<std::string> recursion_defs = {std::string("-DRTC_SPEC_ANY_REFL=") + (any_refl ? "1" : "0"),
+    // which components of the area light's cell vectors are exact zeros (kernel: LIGHT_ZEROS / point_on_light); only when
+    // the factors they would be multiplied with are finite -- hashed jitter is in (0, 1], a constant is the caller's
+    uint32_t light_zeros = 0u;
+    if (hdr.light_kind == RTC_LIGHT_RECT && (hdr.jitter_mode == RTC_JITTER_HASHED || std::isfinite(hdr.jitter_const)))
+        for (int k = 0; k < 3; k++) light_zeros |= (hdr.uvec[k] == 0.0f ? 1u << k : 0u) | (hdr.vvec[k] == 0.0f ? 8u << k : 0u);
+    std::vector<std::string> recursion_defs = {"-DRTC_SPEC_LIGHT_ZEROS=" + std::to_string(light_zeros),
+                                               std::string("-DRTC_SPEC_ANY_REFL=") + (any_refl ? "1" : "0"),
                                                std::string("-DRTC_SPEC_ANY_REFR=") + (any_refr ? "1" : "0"),
                                                "-DRTC_SPEC_REG_LEVELS=" + std::to_string(reg_levels),
                                                std::string("-DRTC_SPEC_ANY_SPECULAR=") + (any_specular ? "1" : "0")};

@@ -573,6 +573,9 @@ enum : uint32_t {
     // child added later can lie outside): rays that would hit it may be turned away at the group.  Shortcuts that
     // ASSERT a hit on the object (light_cull_mask's `dark`) must stand down; those that only remove tests are unaffected.
     SHAPE_LOOSE = 1u << 11,
+    // SHAPE_DIAG with all three diagonal entries equal: a uniformly scaled (and translated) object.  Only the margin-guarded
+    // fast decision of a shadow sample (shadow_fast) looks at it -- approximate arithmetic may factor the scale out.
+    SHAPE_UNIFORM = 1u << 12,
 };
 
 // ---- scene specialisation (hiprtc compile only) --------------------------------------------------
@@ -632,6 +635,15 @@ constexpr bool ANY_REFL = true, ANY_REFR = true;
 constexpr bool ANY_SPECULAR = RTC_SPEC_ANY_SPECULAR != 0;
 #else
 constexpr bool ANY_SPECULAR = true;
+#endif
+// ... and which components of the area light's cell vectors are exactly zero (bits 0..2: u_vec.xyz, 3..5: v_vec.xyz; an
+// axis-aligned light has four).  point_on_light (rectangle_light.rs:60-66) adds `vec * (cell + jitter)` per component: a
+// product with an exact zero is +-0 for the finite factors the host vouches for (hashed jitter, or a finite constant), and
+// adding +-0 changes at most the sign of a zero sum -- the terms are dropped like the other exact zeros of this file.
+#if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_LIGHT_ZEROS)
+constexpr uint32_t LIGHT_ZEROS = RTC_SPEC_LIGHT_ZEROS;
+#else
+constexpr uint32_t LIGHT_ZEROS = 0u;
 #endif
 #if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_SELECT)
 constexpr bool SELECT_RECORDS = RTC_SPEC_SELECT != 0;
@@ -1817,8 +1829,18 @@ DI int shadow_fast(const SceneSoA& S, const ShadowPre* pre, V3 v, uint32_t skip)
         if (kind == RTC_SPHERE) {
             // straight-line code: every quantity is formed, the verdicts are combined at the end (the branches this
             // replaces cost more than the few operations they skipped)
-            const V3 pd = v3(g.x * v.x, g.y * v.y, g.z * v.z);
-            const float a = dot3(pd, pd), hb = dot3(pd, o), hb2 = hb * hb, ac = a * pre[i].c;
+            // a = |t_inverse v|^2 and hb = (t_inverse v) . o; a uniformly scaled sphere (t_inverse = s I + translation) has
+            // a = s^2 |v|^2 and hb = s (v . o) -- other roundings of the same quantities, which is all this decision needs
+            // (its margins are three orders of magnitude above any of them)
+            float a, hb;
+            if (bits & SHAPE_UNIFORM) {
+                a = (g.x * g.x) * vv;
+                hb = g.x * dot3(v, o);
+            } else {
+                const V3 pd = v3(g.x * v.x, g.y * v.y, g.z * v.z);
+                a = dot3(pd, pd), hb = dot3(pd, o);
+            }
+            const float hb2 = hb * hb, ac = a * pre[i].c;
             const float q = hb2 - ac;
             const bool sure_q = a >= 1e-30f && a <= 1e30f && fabsf(q) >= FAST_MARGIN * (hb2 + fabsf(ac));  // NaN: false
             const float sq = __builtin_amdgcn_sqrtf(fmaxf(q, 0.0f)), tol = FAST_MARGIN * (fabsf(hb) + sq);
@@ -1879,6 +1901,18 @@ DI uint32_t jitter_base(uint32_t seed, uint32_t pixel, uint32_t path) {
 DI float jitter_value(uint32_t h) {
     return __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, h, 9u)) - 0.99999988079071044921875f;
 }
+// rectangle_light.rs:60-66: corner + u_vec * (u + jitter1) + v_vec * (v + jitter2), per component, left to right; the terms
+// LIGHT_ZEROS names are exact zeros and are not formed
+DI V3 point_on_light(V3 corner, V3 uvec, V3 vvec, float a, float b) {
+    V3 lp = corner;
+    if (!(LIGHT_ZEROS & 1u)) lp.x = lp.x + uvec.x * a;
+    if (!(LIGHT_ZEROS & 2u)) lp.y = lp.y + uvec.y * a;
+    if (!(LIGHT_ZEROS & 4u)) lp.z = lp.z + uvec.z * a;
+    if (!(LIGHT_ZEROS & 8u)) lp.x = lp.x + vvec.x * b;
+    if (!(LIGHT_ZEROS & 16u)) lp.y = lp.y + vvec.y * b;
+    if (!(LIGHT_ZEROS & 32u)) lp.z = lp.z + vvec.z * b;
+    return lp;
+}
 
 // Light::intensity_at: point_light.rs:28-34, rectangle_light.rs:60-66, 76-88
 template <int NOBJ, bool SIMPLE>
@@ -1927,7 +1961,7 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
                     key += 2u * 0x85EBCA6Bu;
                 }
                 // corner + u_vec * (u + jitter1) + v_vec * (v + jitter2)
-                V3 lp = corner + uvec * ((float)u + j1) + vvec * ((float)v + j2);
+                V3 lp = point_on_light(corner, uvec, vvec, (float)u + j1, (float)v + j2);
                 bool blocked;
                 if constexpr (PRE) blocked = sample_blocked<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt, skip, fast);
                 else blocked = is_shadowed<NOBJ>(H, S, lp, p, cnt, skip & 0x7fffffffu);
@@ -1949,7 +1983,7 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
             key += 2u * stride * 0x85EBCA6Bu;
         }
         // corner + u_vec * (u + jitter1) + v_vec * (v + jitter2)
-        V3 lp = corner + uvec * ((float)u + j1) + vvec * ((float)v + j2);
+        V3 lp = point_on_light(corner, uvec, vvec, (float)u + j1, (float)v + j2);
         bool blocked;
         if constexpr (PRE) blocked = sample_blocked<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt, skip, fast);
         else blocked = is_shadowed<NOBJ>(H, S, lp, p, cnt, skip & 0x7fffffffu);

@@ -49,6 +49,19 @@ KERNEL(k_sub, asm volatile("v_sub_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_sub_
 KERNEL(k_cndmask, asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc" : "+v"(a), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(b) : "v"(1.0000001f) : "vcc");)
 KERNEL(k_cmp, asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n v_cmp_lt_f32 vcc, %4, %8\n v_cmp_lt_f32 vcc, %5, %8\n v_cmp_lt_f32 vcc, %6, %8\n v_cmp_lt_f32 vcc, %7, %8" : "+v"(a), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(b) : "v"(1.0000001f) : "vcc");)
 
+// round 3: the classes the C3 sample loop's ISA holds besides the ones above (tools/isa_mix.py prices a loop with this table)
+KERNEL(k_add_e64abs, asm volatile("v_add_f32_e64 %0, |%0|, |%8|\n v_add_f32_e64 %1, |%1|, |%8|\n v_add_f32_e64 %2, |%2|, |%8|\n v_add_f32_e64 %3, |%3|, |%8|\n v_add_f32_e64 %4, |%4|, |%8|\n v_add_f32_e64 %5, |%5|, |%8|\n v_add_f32_e64 %6, |%6|, |%8|\n v_add_f32_e64 %7, |%7|, |%8|" : "+v"(a), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(b) : "v"(1.0000001f));)
+KERNEL(k_sub_e64neg, asm volatile("v_sub_f32_e64 %0, -%0, %8\n v_sub_f32_e64 %1, -%1, %8\n v_sub_f32_e64 %2, -%2, %8\n v_sub_f32_e64 %3, -%3, %8\n v_sub_f32_e64 %4, -%4, %8\n v_sub_f32_e64 %5, -%5, %8\n v_sub_f32_e64 %6, -%6, %8\n v_sub_f32_e64 %7, -%7, %8" : "+v"(a), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(b) : "v"(1e-9f));)
+KERNEL(k_xor_sdwa, asm volatile("v_xor_b32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n v_xor_b32_sdwa %1, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n v_xor_b32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n v_xor_b32_sdwa %1, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n v_xor_b32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n v_xor_b32_sdwa %1, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n v_xor_b32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n v_xor_b32_sdwa %1, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(ua), "+v"(ub));)
+KERNEL(k_alignbit, asm volatile("v_alignbit_b32 %0, %2, %0, 9\n v_alignbit_b32 %1, %2, %1, 9\n v_alignbit_b32 %0, %2, %0, 9\n v_alignbit_b32 %1, %2, %1, 9\n v_alignbit_b32 %0, %2, %0, 9\n v_alignbit_b32 %1, %2, %1, 9\n v_alignbit_b32 %0, %2, %0, 9\n v_alignbit_b32 %1, %2, %1, 9" : "+v"(ua), "+v"(ub) : "v"(0x7fu));)
+KERNEL(k_cmp_e64, asm volatile("v_cmp_ge_f32_e64 s[20:21], |%0|, %8\n v_cmp_ge_f32_e64 s[22:23], |%1|, %8\n v_cmp_ge_f32_e64 s[24:25], |%2|, %8\n v_cmp_ge_f32_e64 s[26:27], |%3|, %8\n v_cmp_ge_f32_e64 s[20:21], |%4|, %8\n v_cmp_ge_f32_e64 s[22:23], |%5|, %8\n v_cmp_ge_f32_e64 s[24:25], |%6|, %8\n v_cmp_ge_f32_e64 s[26:27], |%7|, %8" : "+v"(a), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(b) : "v"(1.0000001f) : "s20","s21","s22","s23","s24","s25","s26","s27");)
+KERNEL(k_add_u32, asm volatile("v_add_u32 %0, 0x85ebca6b, %0\n v_add_u32 %1, 0x85ebca6b, %1\n v_add_u32 %0, 0x85ebca6b, %0\n v_add_u32 %1, 0x85ebca6b, %1\n v_add_u32 %0, 0x85ebca6b, %0\n v_add_u32 %1, 0x85ebca6b, %1\n v_add_u32 %0, 0x85ebca6b, %0\n v_add_u32 %1, 0x85ebca6b, %1" : "+v"(ua), "+v"(ub));)
+KERNEL(k_and_b32, asm volatile("v_and_b32 %0, 0x7fffffff, %0\n v_and_b32 %1, 0x7fffffff, %1\n v_and_b32 %0, 0x7fffffff, %0\n v_and_b32 %1, 0x7fffffff, %1\n v_and_b32 %0, 0x7fffffff, %0\n v_and_b32 %1, 0x7fffffff, %1\n v_and_b32 %0, 0x7fffffff, %0\n v_and_b32 %1, 0x7fffffff, %1" : "+v"(ua), "+v"(ub));)
+KERNEL(k_mov, asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0" : "+v"(a), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(b));)
+KERNEL(k_add_sgpr, asm volatile("v_add_f32 %0, s20, %0\n v_add_f32 %1, s21, %1\n v_add_f32 %2, s22, %2\n v_add_f32 %3, s23, %3\n v_add_f32 %4, s20, %4\n v_add_f32 %5, s21, %5\n v_add_f32 %6, s22, %6\n v_add_f32 %7, s23, %7" : "+v"(a), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(b) :: "s20","s21","s22","s23");)
+KERNEL(k_mullo_sgpr, asm volatile("v_mul_lo_u32 %0, %0, s20\n v_mul_lo_u32 %1, %1, s21\n v_mul_lo_u32 %0, %0, s20\n v_mul_lo_u32 %1, %1, s21\n v_mul_lo_u32 %0, %0, s20\n v_mul_lo_u32 %1, %1, s21\n v_mul_lo_u32 %0, %0, s20\n v_mul_lo_u32 %1, %1, s21" : "+v"(ua), "+v"(ub) :: "s20","s21");)
+KERNEL(k_fmamk, asm volatile("v_mul_f32 %0, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_mul_f32 %2, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n v_mul_f32 %4, %4, %8\n v_cmp_lt_f32 vcc, %5, %8\n v_mul_f32 %6, %6, %8\n v_cmp_lt_f32 vcc, %7, %8" : "+v"(a), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(b) : "v"(1.0000001f) : "vcc");)
+
 template <class K> void run(const char* name, K kern, int waves_per_simd) {
     int dev; hipGetDevice(&dev); hipDeviceProp_t p; hipGetDeviceProperties(&p, dev);
     int cus = p.multiProcessorCount;
@@ -76,6 +89,9 @@ int main() {
         run("v_mul_lo_u32", k_mullo, w); run("v_mul_u32_u24", k_mul24, w); run("v_div_scale", k_divscale, w); run("v_div_fmas", k_divfmas, w);
         run("v_div_fixup", k_divfixup, w); run("cmp+cndmask", k_cmp_cnd, w); run("cmp64+cnd", k_cmp64_cnd, w); run("min/max", k_minmax, w);
         run("v_pk_mul_f32", k_pkmul, w); run("v_fma_f64", k_fma64, w); run("v_cvt_f32_u32", k_cvt, w); run("shift+xor", k_xor_shift, w);
+        run("add_e64 |abs|", k_add_e64abs, w); run("sub_e64 -neg", k_sub_e64neg, w); run("xor_sdwa", k_xor_sdwa, w); run("v_alignbit", k_alignbit, w);
+        run("v_cmp_e64 sgpr", k_cmp_e64, w); run("v_add_u32 lit", k_add_u32, w); run("v_and_b32 lit", k_and_b32, w); run("v_mov_b32", k_mov, w);
+        run("v_add s,v", k_add_sgpr, w); run("v_mul_lo s", k_mullo_sgpr, w); run("mul/cmp alt", k_fmamk, w);
         printf("\n");
     }
     return 0;
