@@ -1833,7 +1833,12 @@ DI int shadow_fast(const SceneSoA& S, const ShadowPre* pre, V3 v, uint32_t skip)
             // a = s^2 |v|^2 and hb = s (v . o) -- other roundings of the same quantities, which is all this decision needs
             // (its margins are three orders of magnitude above any of them)
             float a, hb;
-            if (bits & SHAPE_UNIFORM) {
+#ifdef RTC_NO_UNIFORM_FAST  // development: A/B
+            constexpr bool use_uniform = false;
+#else
+            constexpr bool use_uniform = true;
+#endif
+            if (use_uniform && (bits & SHAPE_UNIFORM)) {
                 a = (g.x * g.x) * vv;
                 hb = g.x * dot3(v, o);
             } else {
@@ -1920,9 +1925,21 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
     if (spec_light_kind(H.light_kind) == RTC_LIGHT_POINT) {
         return is_shadowed<NOBJ, true>(H, S, v3(H.lpos[0], H.lpos[1], H.lpos[2]), p, cnt) ? 0.0f : 1.0f;
     }
-    const V3 corner = v3(H.corner[0], H.corner[1], H.corner[2]);
-    const V3 uvec = v3(H.uvec[0], H.uvec[1], H.uvec[2]);
-    const V3 vvec = v3(H.vvec[0], H.vvec[1], H.vvec[2]);
+#ifdef RTC_LIGHT_VGPRS
+    // The light's geometry as per-lane values: the sample loop then multiplies VGPR by VGPR (an SGPR operand puts v_mul / v_add
+    // in the half-rate issue class, profiles/ubench_valu_r03.txt) and the compiler has nine scalar registers less to keep --
+    // or to re-load from the argument block inside the loop -- across it.
+    auto in_vgpr = [](float x) {
+        float r;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+        return r;
+    };
+#else
+    auto in_vgpr = [](float x) { return x; };
+#endif
+    const V3 corner = v3(in_vgpr(H.corner[0]), in_vgpr(H.corner[1]), in_vgpr(H.corner[2]));
+    const V3 uvec = v3(in_vgpr(H.uvec[0]), in_vgpr(H.uvec[1]), in_vgpr(H.uvec[2]));
+    const V3 vvec = v3(in_vgpr(H.vvec[0]), in_vgpr(H.vvec[1]), in_vgpr(H.vvec[2]));
     const bool hashed = spec_jitter_mode(H.jitter_mode) == RTC_JITTER_HASHED;
     uint32_t key = hashed ? jitter_base(H.jitter_seed, pixel, path) : 0u;
     // every shadow ray of this shade point starts at p: do the origin-only work once per object
@@ -2322,8 +2339,19 @@ DI float schlick(V3 eye, V3 n, float n1, float n2) {
 // the 100-sample loop and no scratch (HBM-side) traffic; slot k of lane t lives at lds[k*stride + t],
 // so a wave's accesses are consecutive dwords (conflict-free).
 constexpr int STASH_SLOTS = RTC_DEEP_STACK ? 14 : 13;
+// COMPACT frames (kernels that select the hit object's records from scalar loads, -DRTC_SPEC_SELECT=1: one or two
+// objects): a suspended shade_hit keeps the object's INDEX instead of its two material coefficients and reads them again
+// when a child returns -- a select between values the wave holds anyway.  The reflection half of a frame is then 5 dwords:
+// five levels of it are 25.6 KB of LDS per workgroup, SIX workgroups per CU instead of five (the occupancy the kernel is
+// compiled for), and the refraction half 6 dwords of scratch instead of 7.
+#if defined(RTC_SPEC_LIST) && defined(RTC_SPEC_SELECT) && RTC_SPEC_SELECT && !RTC_DEEP_STACK && !defined(RTC_NO_COMPACT_FRAMES)  // (the last: development, A/B)
+#define RTC_COMPACT_FRAMES 1
+#else
+#define RTC_COMPACT_FRAMES 0
+#endif
+constexpr int FRAME_LDS_DWORDS = RTC_COMPACT_FRAMES ? 5 : 6;
 constexpr int FRAME_LDS_SLOT0 = USE_STASH ? STASH_SLOTS : 0;                  // recursion frames kept in LDS come after the parking slots
-constexpr int LDS_SLOTS = FRAME_LDS_SLOT0 + 6 * LDS_FRAME_LEVELS > 0 ? FRAME_LDS_SLOT0 + 6 * LDS_FRAME_LEVELS : 1;
+constexpr int LDS_SLOTS = FRAME_LDS_SLOT0 + FRAME_LDS_DWORDS * LDS_FRAME_LEVELS > 0 ? FRAME_LDS_SLOT0 + FRAME_LDS_DWORDS * LDS_FRAME_LEVELS : 1;
 struct LaneStash {
     float* base;
     uint32_t stride;
@@ -2338,15 +2366,20 @@ struct LaneStash {
 // instead of 13: the refraction half is written and read only when there is a refraction child.
 struct Frame {
     V3 acc;       // surface colour, later surface + reflected[*R]
-    float reflective, R;
-    uint32_t flags;  // bit0: waiting for the refraction child; bit1: has refraction child; bit2: Schlick
+#if !RTC_COMPACT_FRAMES
+    float reflective;
+#endif
+    float R;
+    uint32_t flags;  // bit0: waiting for the refraction child; bit1: has refraction child; bit2: Schlick; COMPACT: bits 8.. the hit object
 #if RTC_DEEP_STACK
     uint32_t path;   // the suspended call's own path code
 #endif
 };
 struct FrameRefr {
     V3 ro, rd;    // pending refraction ray (under_point, direction)
+#if !RTC_COMPACT_FRAMES
     float transparency;
+#endif
 };
 enum { F_WAIT_REFR = 1, F_HAS_REFR = 2, F_SCHLICK = 4 };
 
@@ -2388,8 +2421,11 @@ struct FrameStack {
                 if (sp == u) reg.f[u] = f;
             }
         if (in_lds(sp)) {
-            const int b = FRAME_LDS_SLOT0 + 6 * (sp - R);
-            lds.put(b, f.acc.x), lds.put(b + 1, f.acc.y), lds.put(b + 2, f.acc.z), lds.put(b + 3, f.reflective), lds.put(b + 4, f.R), lds.putu(b + 5, f.flags);
+            const int b = FRAME_LDS_SLOT0 + FRAME_LDS_DWORDS * (sp - R);
+            lds.put(b, f.acc.x), lds.put(b + 1, f.acc.y), lds.put(b + 2, f.acc.z), lds.put(b + 3, f.R), lds.putu(b + 4, f.flags);
+#if !RTC_COMPACT_FRAMES
+            lds.put(b + 5, f.reflective);
+#endif
             return;
         }
         if (M > 0 && sp >= R) mem.f[sp - R] = f;
@@ -2410,16 +2446,19 @@ struct FrameStack {
                 if (sp == u) f = reg.f[u];
             }
         if (in_lds(sp)) {
-            const int b = FRAME_LDS_SLOT0 + 6 * (sp - R);
+            const int b = FRAME_LDS_SLOT0 + FRAME_LDS_DWORDS * (sp - R);
             f.acc = v3(lds.get(b), lds.get(b + 1), lds.get(b + 2));
-            f.reflective = lds.get(b + 3), f.R = lds.get(b + 4), f.flags = lds.getu(b + 5);
+            f.R = lds.get(b + 3), f.flags = lds.getu(b + 4);
+#if !RTC_COMPACT_FRAMES
+            f.reflective = lds.get(b + 5);
+#endif
             return f;
         }
         if (M > 0 && sp >= R) f = mem.f[sp - R];
         return f;
     }
     DI FrameRefr get_refr(int sp) const {
-        FrameRefr f = {v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 0.0f), 0.0f};
+        FrameRefr f = {};
 #pragma unroll
         for (int u = 0; u < R; u++)
             if (__any(sp == u)) {
@@ -2561,9 +2600,13 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                 ret = use_schlick ? surface + black * R + black * (1.0f - R) : surface + black + black;
             } else {
                 Frame f;
-                f.reflective = reflective;
                 f.R = R;
                 f.flags = (has_refr ? F_HAS_REFR : 0) | (use_schlick ? F_SCHLICK : 0);
+#if RTC_COMPACT_FRAMES
+                f.flags |= (uint32_t)ob << 8;
+#else
+                f.reflective = reflective;
+#endif
 #if RTC_DEEP_STACK
                 f.path = path;
 #endif
@@ -2571,7 +2614,9 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                     FrameRefr fr;
                     fr.ro = under_point;
                     fr.rd = rdir;
+#if !RTC_COMPACT_FRAMES
                     fr.transparency = transparency;
+#endif
                     stack.put_refr(sp, fr);
                 }
                 if (has_refl) {
@@ -2603,8 +2648,20 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
 #else
             path >>= 1;
 #endif
+#if RTC_COMPACT_FRAMES
+            // the suspended hit's material coefficients, selected again from the scalar-loaded records (select_material)
+            float f_reflective = 0.0f, f_transparency = 0.0f;
+#pragma unroll
+            for (uint32_t i = 0; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) {
+                const bool mine = (f.flags >> 8) == i;
+                f_reflective = mine ? uniform_value(S.mat_b[i].w) : f_reflective;
+                f_transparency = mine ? uniform_value(S.mat_c[i].x) : f_transparency;
+            }
+#else
+            const float f_reflective = f.reflective;
+#endif
             if (!(f.flags & F_WAIT_REFR)) {
-                V3 reflected = ret * f.reflective;  // world.rs:131
+                V3 reflected = ret * f_reflective;  // world.rs:131
                 V3 partial = (f.flags & F_SCHLICK) ? f.acc + reflected * f.R : f.acc + reflected;
                 if (ANY_REFR && (f.flags & F_HAS_REFR)) {
                     f.acc = partial;
@@ -2621,7 +2678,11 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                 ret = (f.flags & F_SCHLICK) ? partial + black * (1.0f - f.R) : partial + black;
                 sp--;
             } else {
+#if RTC_COMPACT_FRAMES
+                V3 refracted = ret * f_transparency;  // world.rs:159-160
+#else
                 V3 refracted = ret * stack.get_refr(sp - 1).transparency;  // world.rs:159-160
+#endif
                 ret = (f.flags & F_SCHLICK) ? f.acc + refracted * (1.0f - f.R) : f.acc + refracted;
                 sp--;
             }
@@ -2661,9 +2722,12 @@ struct RenderArgs {
     // for the host while later rows are still being rendered.  A workgroup whose four waves have stored their pixels adds one
     // to its block row's counter; the workgroup that completes a block row adds one to the counter of the row's CHUNK
     // (chunk_block_rows consecutive block rows); the one that completes a chunk writes `epoch` into the chunk's word of
-    // `done` -- page-locked host memory the caller polls before it starts that chunk's copy.  Every step is a release /
-    // acquire pair at the scope of whoever reads next (workgroup, device, system), so the pixels are in memory before
-    // the word that announces them (render_body, end).  Counters are PROGRESS_STRIDE dwords apart (one cache line each).
+    // `done` -- page-locked host memory the caller polls before it starts that chunk's copy.
+    // What makes the pixels be in memory before the word that announces them: in this mode they are stored WRITE-THROUGH
+    // (system-scope stores: no dirty line is left in any XCD's L2), a wave counts itself done only after its stores have
+    // been acknowledged (s_waitcnt vmcnt(0)), and the counters are device-scope atomics chained by what each returns.
+    // (The textbook form -- release / acquire fences at device scope -- writes this XCD's whole L2 back per workgroup, the
+    // recursion's scratch included: measured 0.97 -> 2.47 ms for the C3 frame.)  Counters are PROGRESS_STRIDE dwords apart.
     uint32_t* progress;       // [gridDim.y] block-row counters, then [n_chunks] chunk counters; zeroed before the launch
     uint32_t* done;           // [n_chunks], host memory
     uint32_t chunk_block_rows, epoch;
@@ -2816,16 +2880,29 @@ DI void render_body(const RenderArgs& A) {
         col = v3(__uint_as_float(dbg_steps()[0] | dbg_steps()[2] << 20), __uint_as_float(dbg_steps()[1]), __uint_as_float(dbg_steps()[3]));
 #endif
         if (cnt.lead()) {
+            const bool through = A.progress != nullptr;  // wave-uniform: write-through stores (RenderArgs::progress)
             if (A.out_u8 != nullptr) {  // wave-uniform: scale_color on the way out (the arithmetic of quantize_kernel)
                 uint8_t* dst = A.out_u8 + ((size_t)yl * H.width + x) * 3;
-                dst[0] = (uint8_t)fmaxf(fminf(col.x * 255.0f, 255.0f), 0.0f);
-                dst[1] = (uint8_t)fmaxf(fminf(col.y * 255.0f, 255.0f), 0.0f);
-                dst[2] = (uint8_t)fmaxf(fminf(col.z * 255.0f, 255.0f), 0.0f);
+                const uint8_t r = (uint8_t)fmaxf(fminf(col.x * 255.0f, 255.0f), 0.0f), g = (uint8_t)fmaxf(fminf(col.y * 255.0f, 255.0f), 0.0f),
+                              b = (uint8_t)fmaxf(fminf(col.z * 255.0f, 255.0f), 0.0f);
+                if (through) {
+                    __hip_atomic_store(dst, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(dst + 1, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(dst + 2, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    dst[0] = r, dst[1] = g, dst[2] = b;
+                }
             } else {
                 float* dst = A.out + ((size_t)yl * H.width + x) * 3;
-                dst[0] = col.x;
-                dst[1] = col.y;
-                dst[2] = col.z;
+                if (through) {
+                    __hip_atomic_store(dst, col.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(dst + 1, col.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(dst + 2, col.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    dst[0] = col.x;
+                    dst[1] = col.y;
+                    dst[2] = col.z;
+                }
             }
         }
     }
@@ -2843,19 +2920,19 @@ DI void render_body(const RenderArgs& A) {
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) A.total[threadIdx.x] = 0ull;  // for sum_counts_kernel's atomics
     if (lane == 0) A.block_counts[slot + wave] = make_uint4(rays, shaded, culled, 0u);
     if (A.progress != nullptr) {  // see RenderArgs::progress
-        // this wave's stores are out of the wave (release at workgroup scope) before it counts itself done; the wave that
-        // counts last has thereby seen all four (acquire) ...
+        // every store of this wave has been acknowledged -- and, being write-through, is in memory -- before the wave counts
+        // itself done
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
         uint32_t last = 0u;
-        if (lane == 0) last = __hip_atomic_fetch_add(&waves_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == 3u ? 1u : 0u;
+        if (lane == 0) last = __hip_atomic_fetch_add(&waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3u ? 1u : 0u;
         if (__builtin_amdgcn_readfirstlane((int)last) != 0 && lane == 0) {
-            // ... and passes them on at device scope (this XCD's L2 is written back before the counter moves), block row
-            // by block row, chunk by chunk; the word the host reads is stored with a system-scope release
             const uint32_t row = blockIdx.y;
-            if (__hip_atomic_fetch_add(&A.progress[row * PROGRESS_STRIDE], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x) {
+            if (__hip_atomic_fetch_add(&A.progress[row * PROGRESS_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x) {
                 const uint32_t ch = row / A.chunk_block_rows;
                 const uint32_t in_chunk = min(A.chunk_block_rows, gridDim.y - ch * A.chunk_block_rows);
-                if (__hip_atomic_fetch_add(&A.progress[(gridDim.y + ch) * PROGRESS_STRIDE], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_chunk)
-                    __hip_atomic_store(&A.done[ch], A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (__hip_atomic_fetch_add(&A.progress[(gridDim.y + ch) * PROGRESS_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_chunk)
+                    __hip_atomic_store(&A.done[ch], A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }

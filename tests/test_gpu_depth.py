@@ -86,12 +86,12 @@ def test_hall_of_mirrors_area_light_path_codes_wrap_like_the_oracles(depth):
 
 
 def test_each_stack_size_against_the_oracle():
-    """reflect_refract at depth 8 (the base kernels), 9 (a 16-level stack), 20 (32 levels: the author's own render) and 70
-    (128): each frame equals the oracle at its own depth -- the glass sphere's inner reflections keep the recursion alive
-    well beyond 20 levels, so these are four different images."""
+    """reflect_refract at depth 8 (the base kernels), 9 (a 16-level stack), 20 (32 levels: the author's own render): each
+    frame equals the oracle at its own depth -- the glass sphere's inner reflections keep the recursion alive well beyond
+    20 levels (and the ray tree growing: depth 70 takes the oracle minutes), so these are different images."""
     world, camera, _ = scenes.reflect_refract(320, 160)
     imgs = {}
-    for depth in (8, 9, 20, 70):
+    for depth in (8, 9, 20):
         imgs[depth], _ = _check(world, camera, depth, "reflect_refract 320x160")
     assert not np.array_equal(imgs[8], imgs[9]) and not np.array_equal(imgs[9], imgs[20])
 

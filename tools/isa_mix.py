@@ -52,9 +52,11 @@ def classify(line):
         return "valu", "dp", base
     if base in ("v_readlane_b32", "v_writelane_b32", "v_readfirstlane_b32"):
         return "valu", "half", base + " (lane access)"
-    if base in FULL_RATE and not sgpr_src and not op.endswith(("_e64", "_sdwa", "_dpp")):
-        return "valu", "full", base
-    why = base + (" +sgpr operand" if sgpr_src and base in FULL_RATE else "") + (" (VOP3 / sdwa encoding)" if base in FULL_RATE and op.endswith(("_e64", "_sdwa", "_dpp")) else "")
+    # (measured, profiles/ubench_valu_r03.txt: a VOP3 encoding with |abs| / -neg modifiers keeps v_add / v_sub / v_mul at full
+    # rate -- 2.5 cycles --, an SDWA encoding or an SGPR source does not -- 4.2)
+    if base in FULL_RATE and not sgpr_src and not op.endswith(("_sdwa", "_dpp")):
+        return "valu", "full", base + (" (VOP3 modifiers)" if op.endswith("_e64") else "")
+    why = base + (" +sgpr operand" if sgpr_src and base in FULL_RATE else "") + (" (sdwa encoding)" if base in FULL_RATE and op.endswith(("_sdwa", "_dpp")) else "")
     return "valu", "half", why
 
 
