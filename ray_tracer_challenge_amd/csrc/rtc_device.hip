@@ -1738,12 +1738,15 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     bool compile_now = false;
     const int policy = P.specialise;
     const uint64_t pixels = (uint64_t)hdr.width * hdr.height;
+    // do all objects share one kind / flags word?  (SHAPE_UNIFORM aside: only the unrolled kernels' fast shadow decision
+    // reads it, and a cloud of spheres must not lose its like-objects kernel because some are squashed)
     auto uniform_bits = [&](uint32_t* first) {
         std::memcpy(first, &soa[0].w, 4);
+        *first &= ~(uint32_t)SHAPE_UNIFORM;
         for (uint32_t i = 1; i < n; i++) {
             uint32_t bits;
             std::memcpy(&bits, &soa[i].w, 4);
-            if (bits != *first) return false;
+            if ((bits & ~(uint32_t)SHAPE_UNIFORM) != *first) return false;
         }
         return n > 0;
     };

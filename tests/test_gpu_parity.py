@@ -333,9 +333,9 @@ def test_specialisation_policy_defaults(monkeypatch):
     world, camera, _ = scenes.soft_shadows(1024, 512)
     assert Renderer(world, camera, device=0).kernel_name.startswith("render_kernel_spec[")  # >= 2^18 pixels
     world, camera, _ = scenes.sphere_grid(1024, 512)
-    assert Renderer(world, camera, device=0).kernel_name == "render_kernel_spec[tree,bvh;all 0x1500]"  # 64 bounded objects
+    assert Renderer(world, camera, device=0).kernel_name == "render_kernel_spec[tree,bvh;all 0x500]"  # 64 bounded objects
     monkeypatch.setenv("RTC_AMD_BVH", "0")
-    assert Renderer(world, camera, device=0).kernel_name == "render_kernel_spec[all 0x1500]"  # 64 like objects
+    assert Renderer(world, camera, device=0).kernel_name == "render_kernel_spec[all 0x500]"  # 64 like objects
     world.objects[3].casts_shadow = False                                                  # ... no longer alike
     assert Renderer(world, camera, device=0).kernel_name == "render_kernel<0,general>"
 
