@@ -1855,6 +1855,9 @@ DI int shadow_fast(const SceneSoA& S, const ShadowPre* pre, V3 v, uint32_t skip)
             const bool misses = q < 0.0f || n < 0.0f;  // the line misses the sphere, or the sphere lies behind
             if (!sure_q || (!(q < 0.0f) && !sure_n)) uncertain = true;
             else if (!misses && n < a) blocked = true;
+            // (Round 3 also built the decision from SIGNS alone -- roots exist, the side of t = 1 from f(1) = A + 2 B + C and the
+            // vertex A + B: no square root, no numerator whose cancellation decides.  Same image; slower, 0.86 -> 1.03 ms on C3:
+            // a dozen more lane masks to combine, 74 spilled scalar registers.  LABNOTES.md "Round 3".)
         } else {  // RTC_PLANE (plane.rs:45-56): parallel if |d.y| < PLANE_EPS for the normalised direction d = pd / |v|
             const float pdy = g.y * v.y, pdy2 = pdy * pdy, lim = PLANE_EPS * PLANE_EPS * vv;
             if (!(fabsf(pdy2 - lim) >= FAST_MARGIN * (pdy2 + lim)) || !(fabsf(o.y) >= 1e-30f)) {
@@ -1882,6 +1885,9 @@ DI bool sample_blocked(const SceneHdr& H, const SceneSoA& S, const ShadowPre* pr
             }
         }
     }
+#ifdef RTC_COUNT_EXACT  // development: the `culled` statistic counts the samples that took the exact path instead
+    cnt.shaded += 1u << CNT_CULLED_SHIFT;
+#endif
     return is_shadowed_pre<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt, skip);
 }
 
@@ -1952,14 +1958,18 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
         // "lit": total = 1.0 + ... + 1.0 = cells exactly (an integer below 2^24), and cells / cells = 1.0
         const uint32_t cells = (uint32_t)(H.u_steps * H.v_steps);
         cnt.rays += cnt.my_cells(cells);
+#ifndef RTC_COUNT_EXACT
         cnt.shaded += cnt.my_cells(cells) << CNT_CULLED_SHIFT;  // statistics: rays answered without an object test
+#endif
         return (float)cells / H.cells_f;
     }
     if (dark) {
         // per lane: every is_shadowed() call answers "shadowed": total stays 0.0, and 0.0 / cells = 0.0
         const uint32_t cells = (uint32_t)(H.u_steps * H.v_steps);
         cnt.rays += cnt.my_cells(cells);
+#ifndef RTC_COUNT_EXACT
         cnt.shaded += cnt.my_cells(cells) << CNT_CULLED_SHIFT;
+#endif
         return 0.0f / H.cells_f;
     }
     if constexpr (PRE) shadow_prepare<NOBJ>(H, S, p, pre);

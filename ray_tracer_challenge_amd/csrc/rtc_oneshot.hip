@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -261,6 +263,12 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
 
     std::vector<Share> shares(D);
     const auto t_start = std::chrono::steady_clock::now();
+#ifdef RTC_DEV_SWITCHES
+    // development (librtc_amd_dev.so only): RTC_AMD_SEAM_TRACE=1 prints where a call's time goes
+    static const bool seam_trace = std::getenv("RTC_AMD_SEAM_TRACE") != nullptr;
+    double t_queued = 0.0, t_first = 0.0, t_last = 0.0, t_copied = 0.0;
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+#endif
     DrainOnError drain;
     // ---- phase 1: every device's render is queued: ONE launch each, asynchronous ---------------------------------------
     // (Round 2 cut a device's share into ~24 MB launches so that one could travel while the next rendered; every launch
@@ -328,6 +336,9 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
             }
         }
     }
+#ifdef RTC_DEV_SWITCHES
+    t_queued = since();
+#endif
     // ---- phase 2: the rows travel as their chunks are reported finished -------------------------------------------------
     // chunk j of device k is complete when the kernel has stored the frame's epoch into its word, or when the device's
     // render stream has been seen idle (launches that cannot report; and the safety net: a stream that is done has
@@ -409,6 +420,10 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
                 RTC_TRY(queue_copy(k, sh.next_copy));
                 sh.next_copy++;
                 progressed = true;
+#ifdef RTC_DEV_SWITCHES
+                if (t_first == 0.0) t_first = since();
+                t_last = since();
+#endif
             }
             // pageable output: empty the oldest staging slot whose DMA has landed
             if (staged && sh.next_unstage < sh.next_copy) {
@@ -444,6 +459,9 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
         for (hipStream_t c : g_state[k].s_copy2) HIP_TRY(hipStreamSynchronize(c));
     }
     const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+#ifdef RTC_DEV_SWITCHES
+    t_copied = since();
+#endif
     // ---- statistics -------------------------------------------------------------------------------------------------
     rtc_stats total;
     std::memset(&total, 0, sizeof(total));
@@ -464,6 +482,11 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
     total.rows = H;
     total.gather_ms = (float)wall_ms;
     if (stats) *stats = total;
+#ifdef RTC_DEV_SWITCHES
+    if (seam_trace)
+        std::fprintf(stderr, "rtc_render_ex: queued %.3f ms, first chunk's copy queued %.3f, last %.3f, copies done %.3f, stats %.3f; kernel %.3f ms, %u chunk(s)\n",
+                     t_queued, t_first, t_last, t_copied, since(), total.kernel_ms, shares[0].n_chunks);
+#endif
     drain.ok = true;
     return RTC_OK;
 }
