@@ -312,12 +312,13 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
             r += y1 - y0;
         }
         RTC_TRY(grow_device(&S.d_out, &S.d_out_cap, std::max<size_t>(1, (size_t)sh.rows * row_out)));
-        // chunks of about 8 MB of output: small enough for the first to leave early and the last to be short, large enough
-        // for a DMA to run at the link's rate
+        // chunks of about 4 MB of output, at most 24: the call ends one chunk's transfer after the kernel does, so the last
+        // should be short (a 50 MB u8 frame: 6 chunks 1.46 ms, the copy of the last alone 0.46; 12 chunks: see bench.py
+        // one_shot), and a DMA of a few MB already runs at the link's rate
         ProgressPlan plan;
         plan.d_done = S.d_done;
         plan.epoch = S.epoch;
-        plan.want_chunks = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, ((size_t)sh.rows * row_out + (8u << 20) - 1) / (8u << 20)));
+        plan.want_chunks = (uint32_t)std::min<size_t>(24, std::max<size_t>(1, ((size_t)sh.rows * row_out + (4u << 20) - 1) / (4u << 20)));
         plan.n_chunks = plan.chunk_rows = 0u;
         RTC_TRY(ctx_render_slot(S.ctx, depth, &part, S.d_out, S.s_render, 0u, &plan, quantize));
         sh.reports = plan.n_chunks != 0u;
