@@ -176,7 +176,9 @@ EXTRA = {"rtc_powf_host": (None, [FP, FP, C.c_uint32, FP]),
          # device self-test of the range-checked exact sqrt/divide cores against sqrtf and '/'
          "rtc_selftest_fastmath": (C.c_int, [FP, C.c_uint32, C.c_int32, C.POINTER(C.c_uint32)]),
          # 1 in librtc_amd_dev.so (built with -DRTC_DEV_SWITCHES), 0 in the library that ships
-         "rtc_dev_switches": (C.c_int32, [])}
+         "rtc_dev_switches": (C.c_int32, []),
+         # the level-by-level renderer's counters after a context's last frame (tools / tests)
+         "rtc_ctx_wavefront_counters": (C.c_uint32, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32])}
 
 _lib = None
 _loaded = {}  # path -> CDLL

@@ -28,6 +28,7 @@
 
 #include "rtc_internal.h"
 #include "rtc_kernel_core.h"
+#include "rtc_wavefront.h"
 
 namespace rtc {
 
@@ -264,6 +265,7 @@ struct Policy {
     int clusters = -1;    // RTC_AMD_CLUSTERS: nodes over long triangle runs -- 0 never, 1 always, -1 by frame size
     int share_log2 = -1;  // RTC_AMD_SHARE_LOG2 = 0..3: lanes per pixel (log2) pinned for every frame; -1: by frame size
     int scene_rect = 1;   // RTC_AMD_SCENE_RECT: 0 never launch the scene's rectangle only, 2 whenever there is one, 1 under half the frame
+    int wavefront = 0;    // RTC_AMD_WAVEFRONT=1: tree worlds are rendered by the level-by-level renderer (rtc_wavefront.h); default: never
     std::string jit_cache;  // RTC_AMD_JIT_CACHE=<dir>; "0" / "off": compiled kernels stay in memory; empty: <library dir>/jit_cache
     // development
     std::string jit_source, jit_flags;  // RTC_AMD_JIT_SOURCE=<path of rtc_kernel_core.h>, RTC_AMD_JIT_FLAGS="-D... -m..."
@@ -289,6 +291,7 @@ struct Policy {
         if (const char* e = std::getenv("RTC_AMD_CLUSTERS")) p.clusters = *e ? (e[0] != '0' ? 1 : 0) : -1;
         p.share_log2 = digit(std::getenv("RTC_AMD_SHARE_LOG2"), 0, 3, -1);
         if (const char* e = std::getenv("RTC_AMD_SCENE_RECT")) p.scene_rect = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
+        if (const char* e = std::getenv("RTC_AMD_WAVEFRONT")) p.wavefront = (*e && e[0] != '0') ? 1 : 0;
         if (const char* e = std::getenv("RTC_AMD_JIT_CACHE")) p.jit_cache = e;
         if (const char* e = RTC_DEV_ENV("RTC_AMD_JIT_SOURCE")) p.jit_source = e;
         if (const char* e = RTC_DEV_ENV("RTC_AMD_JIT_FLAGS")) p.jit_flags = e;
@@ -1167,6 +1170,15 @@ struct rtc_ctx {
     std::vector<float> texels_host;
     uint4* d_block_counts = nullptr;
     size_t block_cap = 0;
+    // the level-by-level renderer (rtc_wavefront.h): ray lists (two levels x reflection / refraction), the node pool, counters
+    WfRay* d_wf_rays[4] = {nullptr, nullptr, nullptr, nullptr};
+    WfNode* d_wf_nodes = nullptr;
+    uint32_t* d_wf_ctr = nullptr;
+    size_t wf_cap_rays = 0, wf_cap_nodes = 0;
+    bool wf_pays = false;      // this scene: a tree world with long leaf runs whose materials both reflect and transmit
+    bool wf_disabled = false;  // ... but a frame overflowed the pools: per-pixel kernels from then on
+    bool wf_last = false;      // the last frame was rendered level by level (rtc_ctx_kernel_name says so)
+    std::string wf_name;
     uint32_t* d_progress = nullptr;  // RenderArgs::progress counters (rtc_render_ex), grow-only
     size_t progress_cap = 0;         // dwords
     // {rays, shaded hits, culled shadow rays} per counter slot: slot 0 = the last rtc_ctx_render launch; rtc_render_ex
@@ -1401,6 +1413,17 @@ extern "C" {
 
 int32_t rtc_device_count(void) { return usable_devices(); }
 
+// Diagnostic (not in rtc.h): the level-by-level renderer's counters after the context's last frame (rtc_wavefront.h: nodes,
+// overflow, then per level {reflection rays, refraction rays, nodes so far}); returns the number of words written.
+uint32_t rtc_ctx_wavefront_counters(rtc_ctx* c, uint32_t* out, uint32_t cap) {
+    if (!c || !out || !c->d_wf_ctr) return 0u;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    const uint32_t n = std::min<uint32_t>(cap, WF_CTR_WORDS);
+    if (hipMemcpy(out, c->d_wf_ctr, n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return 0u;
+    return n;
+}
+
 // Diagnostic (not in rtc.h): was this library built with the development switches (Policy, -DRTC_DEV_SWITCHES)?
 int32_t rtc_dev_switches(void) {
 #ifdef RTC_DEV_SWITCHES
@@ -1439,6 +1462,10 @@ void rtc_ctx_destroy(rtc_ctx* c) {
     if (c->d_texels) (void)hipFree(c->d_texels);
     if (c->d_block_counts) (void)hipFree(c->d_block_counts);
     if (c->d_progress) (void)hipFree(c->d_progress);
+    for (WfRay* r : c->d_wf_rays)
+        if (r) (void)hipFree(r);
+    if (c->d_wf_nodes) (void)hipFree(c->d_wf_nodes);
+    if (c->d_wf_ctr) (void)hipFree(c->d_wf_ctr);
     if (c->d_total) (void)hipFree(c->d_total);
     if (c->d_ppm_rows) (void)hipFree(c->d_ppm_rows);
     if (c->d_ppm_bits) (void)hipFree(c->d_ppm_bits);
@@ -1712,6 +1739,10 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         any_refr = any_refr || !(m.transparency == 0.0f);
         any_specular = any_specular || !(m.specular == 0.0f && m.shininess >= 0.0f && m.shininess <= 1e6f);  // phong: needs powf
     }
+    // Level-by-level rendering pays where a pixel's ray tree is what makes a frame long: tree worlds with the long leaf runs
+    // of divided meshes whose materials both reflect and transmit (every such hit doubles the rays below it)
+    c->wf_pays = hdr.n_trav != 0u && hdr.max_leaf_run >= 16u && any_refl && any_refr;
+    c->wf_disabled = false;
     int reg_levels = P.reg_levels;
     if (!any_refl && !any_refr) reg_levels = 0;
     // which components of the area light's cell vectors are exact zeros (kernel: LIGHT_ZEROS / point_on_light); only when
@@ -1880,6 +1911,113 @@ static rtc_status deep_kernel(rtc_ctx* c, int32_t depth, hipFunction_t* out) {
     return RTC_OK;
 }
 
+// The frame level by level (rtc_wavefront.h): one lane per ray, suspended shade_hits as nodes in HBM.  *used: false when the
+// frame was not rendered this way (pools could not be allocated, or ran full: the caller renders it with the per-pixel kernel).
+static rtc_status render_wavefront(rtc_ctx* c, int32_t depth, const Partition& q, uint32_t rows, void* d_out, bool out_u8, hipStream_t stream,
+                                   uint32_t slot, bool* used) {
+    *used = false;
+    const size_t pixels = (size_t)rows * c->hdr.width;
+    // pools: a level's two ray lists hold up to two rays per pixel each, the node pool six suspended hits per pixel (a glass
+    // mesh filling a quarter of the frame at depth 5 needs about one and three); a frame that needs more is rendered again
+    const size_t cap_rays = std::max<size_t>(1024, 2 * pixels), cap_nodes = std::max<size_t>(1024, 6 * pixels);
+    if (cap_nodes > 0x7fffffffull) return RTC_OK;
+    if (cap_rays > c->wf_cap_rays || cap_nodes > c->wf_cap_nodes || !c->d_wf_ctr) {
+        HIP_TRY(hipDeviceSynchronize());  // (the pools may be in use by a frame in flight)
+        for (WfRay*& r : c->d_wf_rays) {
+            if (r) (void)hipFree(r);
+            r = nullptr;
+        }
+        if (c->d_wf_nodes) (void)hipFree(c->d_wf_nodes);
+        c->d_wf_nodes = nullptr;
+        c->wf_cap_rays = c->wf_cap_nodes = 0;
+        bool ok = true;
+        for (WfRay*& r : c->d_wf_rays) ok = ok && hipMalloc((void**)&r, cap_rays * sizeof(WfRay)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&c->d_wf_nodes, cap_nodes * sizeof(WfNode)) == hipSuccess;
+        if (ok && !c->d_wf_ctr) ok = hipMalloc((void**)&c->d_wf_ctr, WF_CTR_WORDS * sizeof(uint32_t)) == hipSuccess;
+        if (!ok) {  // not enough memory for the pools: the per-pixel kernel needs none
+            (void)hipGetLastError();
+            for (WfRay*& r : c->d_wf_rays) {
+                if (r) (void)hipFree(r);
+                r = nullptr;
+            }
+            if (c->d_wf_nodes) (void)hipFree(c->d_wf_nodes);
+            c->d_wf_nodes = nullptr;
+            return RTC_OK;
+        }
+        c->wf_cap_rays = cap_rays, c->wf_cap_nodes = cap_nodes;
+    }
+    WfArgs a;
+    a.hdr = c->hdr;
+    a.soa = soa_view(c->d_soa, c->hdr, c->d_texels);
+    a.out = out_u8 ? nullptr : (float*)d_out;
+    a.out_u8 = out_u8 ? (uint8_t*)d_out : nullptr;
+    a.rows = rows, a.band_rows = q.band_rows, a.n_parts = q.n_parts, a.part = q.part;
+    a.depth = depth;
+    a.nodes = c->d_wf_nodes;
+    a.ctr = c->d_wf_ctr;
+    a.cap_rays = (uint32_t)c->wf_cap_rays, a.cap_nodes = (uint32_t)c->wf_cap_nodes;
+    // (levels after the first and the combining passes draw their work from counters: a launch that fills the chip once)
+    const uint32_t ray_wgs = 256u * 6u, node_wgs = 256u * 4u;
+    const dim3 primary_grid((c->hdr.width + 15u) / 16u, (rows + 15u) / 16u);
+    const size_t n_counts = ((size_t)primary_grid.x * primary_grid.y + (size_t)depth * ray_wgs) * 4;  // one partial per wave of every tracing launch
+    if (n_counts > c->block_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->d_block_counts) HIP_TRY(hipFree(c->d_block_counts));
+        c->d_block_counts = nullptr;
+        c->block_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_block_counts, n_counts * sizeof(uint4)));
+        c->block_cap = n_counts;
+    }
+    a.wave_counts = c->d_block_counts;
+    unsigned long long* total = c->d_total + 3 * (size_t)slot;
+    HIP_TRY(hipMemsetAsync(c->d_wf_ctr, 0, WF_CTR_WORDS * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(total, 0, 3 * sizeof(unsigned long long), stream));
+    if (c->events_used == c->events.size()) {
+        if (c->events.size() >= 4096) {
+            c->events_used = 0;
+        } else {
+            std::pair<hipEvent_t, hipEvent_t> e;
+            HIP_TRY(hipEventCreate(&e.first));
+            HIP_TRY(hipEventCreate(&e.second));
+            c->events.push_back(e);
+        }
+    }
+    auto& ev = c->events[c->events_used++];
+    HIP_TRY(hipEventRecord(ev.first, stream));
+    for (int32_t level = 0; level <= depth; level++) {
+        a.level = (uint32_t)level;
+        a.in_refl = c->d_wf_rays[2 * ((level + 1) & 1)], a.in_refr = c->d_wf_rays[2 * ((level + 1) & 1) + 1];
+        a.out_refl = c->d_wf_rays[2 * (level & 1)], a.out_refr = c->d_wf_rays[2 * (level & 1) + 1];
+        a.count_base = level == 0 ? 0u : (uint32_t)(((size_t)primary_grid.x * primary_grid.y + (size_t)(level - 1) * ray_wgs) * 4);
+        if (level == 0)
+            hipLaunchKernelGGL(wf_trace_kernel<true>, primary_grid, dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL(wf_trace_kernel<false>, dim3(ray_wgs), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(wf_snapshot_kernel, dim3(1), dim3(1), 0, stream, c->d_wf_ctr, (uint32_t)level, a.cap_nodes);
+    }
+    for (int32_t level = depth; level >= 0; level--) {
+        a.level = (uint32_t)level;
+        hipLaunchKernelGGL(wf_combine_kernel, dim3(node_wgs), dim3(256), 0, stream, a);
+    }
+    HIP_TRY(hipEventRecord(ev.second, stream));
+    hipLaunchKernelGGL(sum_counts_kernel, dim3((uint32_t)((n_counts + SUM_COUNTS_SLICE - 1) / SUM_COUNTS_SLICE)), dim3(1024), 0, stream, c->d_block_counts,
+                       (uint32_t)n_counts, total, 0ull);
+    HIP_TRY(hipGetLastError());
+    // did everything fit?  (One small read-back: the call returns when the frame is done -- these frames take milliseconds.)
+    uint32_t overflow = 0u;
+    HIP_TRY(hipMemcpyAsync(&overflow, c->d_wf_ctr + WF_CTR_OVERFLOW, sizeof(overflow), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (overflow) {
+        c->wf_disabled = true;  // this scene needs more than the pools hold: per-pixel kernels from now on
+        c->events_used--;
+        return RTC_OK;
+    }
+    c->rendered = true;
+    c->wf_last = true;
+    *used = true;
+    return RTC_OK;
+}
+
 // rtc_ctx_render with a counter slot of the caller's choosing (rtc_internal.h)
 rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* part, void* d_out_rgb, void* stream_, uint32_t slot,
                                 ProgressPlan* plan, bool out_u8) {
@@ -1967,6 +2105,21 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     }
     c->last_rows = rows;
     c->last_pixels = traced_rows * (uint64_t)(c->hdr.width - 1);
+    // Level by level instead of pixel by pixel (rtc_wavefront.h): only on request (RTC_AMD_WAVEFRONT=1).  Built in round 3 for
+    // the frames whose time is their longest wave (glass meshes), bit-identical -- and measured slower everywhere: mesh 2048^2
+    // 8.0 ms against 3.8, here_be_dragons 4000 x 1600 9.6 against 3.0 (profiles/r03_wavefront_ab.txt).  A level is a launch, a
+    // launch ends with ITS longest wave -- one packet walk over a divided mesh is hundreds of microseconds -- and a frame of
+    // depth 5 pays six of those tails where the per-pixel kernel pays one; its walks are also the generic ones (no lanes
+    // splitting leaf runs, no per-scene compile).  What the finding asks for is a single persistent launch with a queue of rays
+    // and continuation frames, not level-synchronous passes.  Kept as a verified alternative, not a default.
+    if (c->hdr.n_trav != 0u && rows > 0u && depth >= 1 && depth <= RTC_STACK_DEPTH_BASE && (int)depth < (int)WF_MAX_LEVELS && !c->wf_disabled &&
+        (size_t)rows * c->hdr.width <= (16u << 20) && P.wavefront == 1) {
+        bool used = false;
+        rtc_status wst = render_wavefront(c, depth, q, rows, d_out_rgb, out_u8, stream, slot, &used);
+        if (wst != RTC_OK) return wst;
+        if (used) return RTC_OK;
+    }
+    c->wf_last = false;
     // Scene rectangle: every primary ray outside the rectangle the scene's box projects to (project_heavy_boxes: exact
     // camera arithmetic in double, 8 pixels of padding, "everything" if the box reaches behind the camera) sees nothing --
     // black, one ray.  Where that rectangle is under half the frame (C5: a grid of spheres in the middle of 8192^2) the
@@ -2182,7 +2335,14 @@ rtc_status rtc_ctx_stats(rtc_ctx* c, rtc_stats* out) {
     return RTC_OK;
 }
 
-const char* rtc_ctx_kernel_name(rtc_ctx* c) { return c ? c->kernel_name.c_str() : ""; }
+const char* rtc_ctx_kernel_name(rtc_ctx* c) {
+    if (!c) return "";
+    if (c->wf_last) {  // the frame before this call was rendered by rtc_wavefront.h's kernels, not by the scene's per-pixel kernel
+        c->wf_name = "wavefront[tree walk of " + c->kernel_name + "]";
+        return c->wf_name.c_str();
+    }
+    return c->kernel_name.c_str();
+}
 const char* rtc_ctx_jit_status(rtc_ctx* c) { return c ? c->jit_note.c_str() : ""; }
 const char* rtc_ctx_kernel_id(rtc_ctx* c) { return c ? c->kernel_id.c_str() : ""; }
 
