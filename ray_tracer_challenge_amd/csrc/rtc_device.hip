@@ -1845,6 +1845,15 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
             if (any_refl || any_refr) defs.push_back("-DRTC_SPEC_LDS_FRAMES=5");
             if (n <= 2) defs.push_back("-DRTC_SPEC_SELECT=1");  // (4 - 6 objects: the selects cost more than the gathers, +13 ... +30 %)
             defs.push_back("-DRTC_WAVES_PER_SIMD=6");
+        } else if (hdr.light_kind == RTC_LIGHT_POINT && !reg_waves) {
+            // ... and the kernels of rotated objects, cylinders, cones and patterns under a point light (round 3): at seven
+            // waves per SIMD they spill without the parking (reflect_refract 1.21 -> 1.49 ms, round 2) -- at FIVE (102 VGPRs) they
+            // do not, and the LDS holds five levels of reflection halves instead: reflect_refract 4096 x 2048 1.204 -> 0.984 ms
+            // (its counters: 64 % of the wave-cycles waiting on memory, 2.4 GB of scratch traffic for a 0.1 GB frame), skybox
+            // 0.198 -> 0.188, first_plane / first_patterns -2 %, first_scene +1 % (profiles/r03_ab_point_light_policy.txt)
+            defs.push_back("-DRTC_SPEC_STASH=0");
+            if (any_refl || any_refr) defs.push_back("-DRTC_SPEC_LDS_FRAMES=5");
+            defs.push_back("-DRTC_WAVES_PER_SIMD=5");
         }
         spec_name = "render_kernel_spec[" + list.substr(16) + (c->simple ? ";simple" : "") + (hdr.has_patterns ? ";patterns" : "") + (hdr.n_gates ? ";gates" : "") + "]";
     } else if (n > 8) {
