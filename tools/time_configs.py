@@ -17,9 +17,9 @@ CASES = [("C1 soft_shadows 1000x400", "soft_shadows", (1000, 400)), ("C2 single_
 for label, name, size in CASES:
     world, camera, depth = getattr(scenes, name)(*size)
     r = Renderer(world, camera, device=0); out = r.alloc()
-    for _ in range(2): r.render(depth, out=out)
-    r.stats()
-    for _ in range(5): r.render(depth, out=out)
+    for _ in range(10): r.render(depth, out=out)   # (ten warm-up launches: after a run of tiny kernels the clocks need them -- with two,
+    r.stats()                                       #  C3 read 0.917 ms where bench.py on the same box measured 0.826)
+    for _ in range(10): r.render(depth, out=out)
     st = r.stats()
     print("| %s | %s | %.3f | %d | %.1f | %.2f |" % (label, r.kernel_name, st["kernel_ms"], st["rays"], st["rays"] / st["kernel_ms"] / 1e6,
                                                   st["pixels"] / st["kernel_ms"] / 1e6), flush=True)
