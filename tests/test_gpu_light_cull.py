@@ -269,6 +269,8 @@ def _random_simple_world(rng, n_objects, jitter):
             objs.append(P.Plane(t, P.Material(color=tuple(rng.uniform(0.3, 1, 3))), casts_shadow=bool(rng.random() < 0.5)))
             continue
         s = float(10.0 ** rng.uniform(-1.3, 0.3)) * rng.uniform(0.6, 1.6, 3)
+        if rng.random() < 0.4:
+            s[:] = s[0]  # a uniformly scaled sphere: the fast decision factors the scale out (SHAPE_UNIFORM)
         if rng.random() < 0.2:
             s[int(rng.integers(0, 3))] *= -1.0
         pos = rng.uniform(-2.5, 2.5, 3) + np.array([0.0, 1.0, 0.0])
