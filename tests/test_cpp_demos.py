@@ -24,7 +24,7 @@ def built():
 
 def test_demos_build_and_refuse_to_run_without_gpu(built):
     for name in ("soft_shadows", "first_scene", "first_plane", "first_patterns", "reflect_refract", "hexagons", "first_textures",
-                 "here_be_dragons"):
+                 "skybox", "here_be_dragons"):
         assert os.access(os.path.join(built, name), os.X_OK)
     if P.device_count() == 0:
         p = subprocess.run([os.path.join(built, "first_plane"), "8x8"], capture_output=True, text=True)
@@ -55,6 +55,21 @@ def test_first_textures_demo_reads_its_image_from_a_ppm_file(built, tmp_path):
     img, _ = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=8)
     assert p.stdout == O.to_ppm(img) + b"\n"
     bad = subprocess.run([os.path.join(built, "first_textures"), str(tmp_path / "missing.ppm")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "cannot open" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_skybox_demo_reads_its_six_faces_from_a_directory(built, tmp_path):
+    """skybox.rs takes a directory of six P3 images (posz / negz / posx / negx / posy / negy .ppm -- posx is handed to `left`,
+    as the demo writes it); so does the C++ counterpart.  Same faces as scenes.skybox: same PPM as the oracle's."""
+    for k, name in enumerate(("posz", "negz", "posx", "negx", "posy", "negy")):   # front, back, left, right, up, down
+        (tmp_path / (name + ".ppm")).write_text(scenes.synthetic_ppm(48, 48, seed=k + 2))
+    p = subprocess.run([os.path.join(built, "skybox"), str(tmp_path), "160x80"], capture_output=True)
+    assert p.returncode == 0, p.stderr
+    world, camera, depth = scenes.skybox(160, 80, face_size=48)
+    img, _ = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=8)
+    assert p.stdout == O.to_ppm(img) + b"\n"
+    bad = subprocess.run([os.path.join(built, "skybox"), str(tmp_path / "nowhere")], capture_output=True, text=True)
     assert bad.returncode == 1 and "cannot open" in bad.stderr
 
 
