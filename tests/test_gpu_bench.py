@@ -42,3 +42,22 @@ def test_workload_selector_runs_c5_by_name():
     line = _bench(["--workload", "C5", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-one-shot"])
     assert line["config"]["workload"].startswith("C5: sphere_grid 8192x8192") and line["config"]["pixels_per_frame"] == 8191 * 8191
     assert line["parity_check"]["rows_checked_bit_exact_vs_oracle"]
+
+
+def test_the_drivers_launcher_form_still_works():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`:
+    the ranks come from the launcher (WORLD_SIZE / RANK in the environment), bench.py must not start its own."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "384",
+                        "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["parity_check"]["rows_checked_bit_exact_vs_oracle"] and line["multi_gpu"]["calibration"]
