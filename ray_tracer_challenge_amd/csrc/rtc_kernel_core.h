@@ -1407,6 +1407,100 @@ DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, const Count
     return best;
 }
 
+// nearest_hit for the rays of color_at in a TREE kernel, gathering on the way what precompute_values' n1 / n2 walk
+// (world.rs:235-263; refraction_indices below has the argument) needs from the intersections BEHIND the origin: the two
+// innermost odd-parity containers, and whether the hit object is one.  Round 2 walked the tree a second time for them (with the
+// limit at t = 0) whenever the hit was transparent -- a third of a glass mesh's walks.  One walk serves both: a group the
+// container walk opens (its box holds the origin: entry parameter <= 0 within the pruning slack) the nearest-hit walk opens as
+// well (its limit is the nearest hit's t >= 0, so its condition is the weaker one), leaves and nodes are pre-culled by the same
+// line tests, and an object in a box the ray enters at t > 0 has no intersection behind the origin -- unless its group is
+// "loose", and those are never pruned by either walk.  Every object is visited once: all its intersections are formed
+// (HITS_ONLY = false: the same expressions, so the hit distances are the ones nearest_hit returns), the negative ones counted,
+// the smallest non-negative one offered as the hit together with the object's parity.
+template <int NOBJ>
+DI Hit nearest_hit_and_containers(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, const Counters& cnt, float& t1, int& c1, float& t2, int& c2,
+                                  bool& hit_inside) {
+    static_assert(NOBJ < 0, "tree kernels");
+    Hit best = {0.0f, -1};
+    bool best_inside = false;
+    t1 = t2 = 0.0f;
+    c1 = c2 = -1;
+    WorldRay wr = world_ray<NOBJ>(H, o, d);
+    wr.limit = RTC_INF;
+    auto after = [&](float ta, int ia, float tb, int ib) { return ta > tb || (ta == tb && ia > ib); };  // does (ta, ia) sort after (tb, ib)?
+    auto offer_container = [&](float t, int c) {
+        if (c1 < 0 || after(t, c, t1, c1)) {
+            t2 = t1, c2 = c1;
+            t1 = t, c1 = c;
+        } else if (c2 < 0 || after(t, c, t2, c2)) {
+            t2 = t, c2 = c;
+        }
+    };
+    auto offer_hit = [&](uint32_t i, float t, bool inside) {  // t >= 0
+        if (best.obj < 0 || t < best.t || (t == best.t && (int)i < best.obj)) {
+            best.t = t, best.obj = (int)i, best_inside = inside;
+            wr.limit = fminf(wr.limit, t);
+        }
+    };
+    auto per_object = [&](uint32_t i, const Obj& ob, auto lane_idx) {
+        const V3 po = obj_point(ob, o), pd = obj_vector(ob, d);
+        int negatives = 0;
+        float tmax = 0.0f, tpos = 0.0f;
+        bool has = false;
+        local_intersect<false, decltype(lane_idx)::value>(ob.bits, ob.min_y(), ob.max_y(), S.tri, i, po, pd, [&](float t) {
+            if (t < 0.0f) {
+                if (negatives == 0 || t > tmax) tmax = t;
+                negatives++;
+            } else if (t >= 0.0f && (!has || t < tpos)) {  // (NaN: neither)
+                tpos = t, has = true;
+            }
+        });
+        const bool inside = (negatives & 1) != 0;
+        if (inside) offer_container(tmax, (int)i);
+        if (has) offer_hit(i, tpos, inside);
+    };
+    using LaneIdx = BoolConstant<true>;
+    using UniformIdx = BoolConstant<false>;
+    if constexpr (Counters::SHARE_LANES && SHARED_WALK && SHARED_WALK_HIT && SHARED_WALK_N12)
+      if (cnt.share_log2() != 0u) {  // the pixel's lanes split the leaf runs (for_each_leaf_shared) and pool what they find
+        for_each_leaf_shared(
+            H, S, wr, cnt,
+            [&](uint32_t i) {
+                Obj ob = load_obj(S, i);
+                ob.bits = spec_bits(i, ob.bits);
+                per_object(i, ob, LaneIdx());
+            },
+            [&](uint32_t i, float t) {  // a triangle of a mesh run: its one intersection
+                if (t < 0.0f) offer_container(t, (int)i);
+                else if (t >= 0.0f) offer_hit(i, t, false);
+            },
+            [&]() {  // after a run: the pixel's nearest hit so far, in (t, object index) order, with its parity
+                for (uint32_t m = 1u; m < (1u << cnt.share_log2()); m <<= 1) {
+                    const float ot = __shfl_xor(best.t, (int)m, 64);
+                    const int oo = __shfl_xor(best.obj, (int)m, 64);
+                    const int oi = __shfl_xor((int)best_inside, (int)m, 64);
+                    if (oo >= 0 && (best.obj < 0 || ot < best.t || (ot == best.t && oo < best.obj))) best.t = ot, best.obj = oo, best_inside = oi != 0;
+                }
+                if (best.obj >= 0) wr.limit = fminf(wr.limit, best.t);
+            });
+        for (uint32_t m = 1u; m < (1u << cnt.share_log2()); m <<= 1) {  // every object was examined by exactly one lane: no duplicates
+            const float pt1 = __shfl_xor(t1, (int)m, 64), pt2 = __shfl_xor(t2, (int)m, 64);
+            const int pc1 = __shfl_xor(c1, (int)m, 64), pc2 = __shfl_xor(c2, (int)m, 64);
+            if (pc1 >= 0) offer_container(pt1, pc1);
+            if (pc2 >= 0) offer_container(pt2, pc2);
+        }
+        hit_inside = best_inside;
+        return best;
+      }
+    for_each_object<NOBJ>(H, S, wr, [&](uint32_t i) {
+        const Obj ob = load_obj_static<true>(S, i);
+        if ((ob.bits & SHAPE_KIND_MASK) == SHAPE_NONE) return;  // padding record (wave-uniform)
+        per_object(i, ob, UniformIdx());
+    });
+    hit_inside = best_inside;
+    return best;
+}
+
 // world.rs:104-119
 // SHARED: see nearest_hit (the ray is counted once per pixel)
 template <int NOBJ, bool SHARED = false>
@@ -2348,7 +2442,19 @@ DI float schlick(V3 eye, V3 n, float n1, float n2) {
 // used inside it (ray, hit, normal, recursion bookkeeping).  Parked there it costs no VGPRs during
 // the 100-sample loop and no scratch (HBM-side) traffic; slot k of lane t lives at lds[k*stride + t],
 // so a wave's accesses are consecutive dwords (conflict-free).
-constexpr int STASH_SLOTS = RTC_DEEP_STACK ? 14 : 13;
+// (tree kernels park two more words: the hit's n1 / n2, known when the nearest-hit walk ends -- nearest_hit_and_containers)
+#if defined(RTC_SPEC_LIST) && RTC_SPEC_NOBJ >= 0
+constexpr int STASH_N12 = 0;
+#else
+constexpr int STASH_N12 = 2;
+#endif
+constexpr int STASH_N12_SLOT0 = RTC_DEEP_STACK ? 14 : 13;
+constexpr int STASH_SLOTS = STASH_N12_SLOT0 + STASH_N12;
+#ifdef RTC_NO_MERGED_N12  // development (A/B): the containers from a second walk (refraction_indices), as up to round 2
+constexpr bool MERGED_N12 = false;
+#else
+constexpr bool MERGED_N12 = true;
+#endif
 // COMPACT frames (kernels that select the hit object's records from scalar loads, -DRTC_SPEC_SELECT=1: one or two
 // objects): a suspended shade_hit keeps the object's INDEX instead of its two material coefficients and reads them again
 // when a child returns -- a select between values the wave holds anyway.  The reflection half of a frame is then 5 dwords:
@@ -2496,7 +2602,13 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
     for (;;) {
         // ---------------- color_at(ray(o, d), rem)
         cnt.rays += cnt.lead();
-        Hit h = nearest_hit<NOBJ, true>(H, S, o, d, cnt);
+        Hit h;
+        float kt1 = 0.0f, kt2 = 0.0f;  // tree kernels: the ray's containers, from the same walk (nearest_hit_and_containers)
+        int kc1 = -1, kc2 = -1;
+        bool k_inside = false;
+        constexpr bool TREE_N12 = NOBJ < 0 && ANY_REFR && MERGED_N12;
+        if constexpr (TREE_N12) h = nearest_hit_and_containers<NOBJ>(H, S, o, d, cnt, kt1, kc1, kt2, kc2, k_inside);
+        else h = nearest_hit<NOBJ, true>(H, S, o, d, cnt);
         bool descend = false;
         ret = v3(0.0f, 0.0f, 0.0f);
         if (h.obj >= 0) {
@@ -2507,6 +2619,14 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
             V3 n;
             bool inside;
             V3 over_point;
+            float tree_n1 = 1.0f, tree_n2 = 1.0f;  // n1 / n2 of precompute_values (world.rs:235-263), for a transparent hit of a tree kernel
+            if constexpr (TREE_N12) {
+                const float4 mc0 = S.mat_c[ob];
+                if (mc0.x != 0.0f) {  // (what refraction_indices derives from the same containers)
+                    tree_n1 = kc1 >= 0 ? S.mat_c[kc1].y : 1.0f;  // REFRACTION_VACCUM, constants.rs:6
+                    tree_n2 = !k_inside ? mc0.y : kc1 == ob ? (kc2 >= 0 ? S.mat_c[kc2].y : 1.0f) : tree_n1;
+                }
+            }
             {
                 Obj rec = SELECT_RECORDS && NOBJ > 0 ? select_obj<NOBJ>(S, ob) : load_obj(S, ob);
                 V3 point = o + d * h.t;
@@ -2537,6 +2657,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
 #else
             stash.putu(12, path | ((uint32_t)rem << 16) | ((uint32_t)sp << 20) | ((uint32_t)depth << 24));
 #endif
+            if constexpr (TREE_N12 && STASH_N12 == 2) stash.put(STASH_N12_SLOT0, tree_n1), stash.put(STASH_N12_SLOT0 + 1, tree_n2);
             asm volatile("" ::: "memory");
             li = intensity_at<NOBJ, SIMPLE>(H, S, over_point, pixel, path, cnt);
             asm volatile("" ::: "memory");
@@ -2562,6 +2683,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
                 depth = (int)(w12 >> 24);
 #endif
             }
+            if constexpr (TREE_N12 && STASH_N12 == 2) tree_n1 = stash.get(STASH_N12_SLOT0), tree_n2 = stash.get(STASH_N12_SLOT0 + 1);
             }
 
             V3 eye = -d;
@@ -2592,7 +2714,8 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
             V3 rdir = v3(0.0f, 0.0f, 0.0f);
             if (ANY_REFR && transparency != 0.0f) {
                 float n1, n2;
-                refraction_indices<NOBJ>(H, S, o, d, ob, n1, n2, cnt);
+                if constexpr (TREE_N12) n1 = tree_n1, n2 = tree_n2;
+                else refraction_indices<NOBJ>(H, S, o, d, ob, n1, n2, cnt);
                 if (use_schlick) R = schlick(eye, n, n1, n2);
                 if (rem != 0) {  // refracted_color, world.rs:140-161
                     float n_ratio = n1 / n2;
