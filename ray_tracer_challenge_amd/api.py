@@ -433,7 +433,8 @@ class Shape:
         lists in the reference's push order."""
         o = np.ascontiguousarray(np.asarray(origins, dtype=f32).reshape(-1, 4))
         d = np.ascontiguousarray(np.asarray(directions, dtype=f32).reshape(-1, 4))
-        assert o.shape == d.shape
+        if o.shape != d.shape:
+            raise ValueError("origins and directions differ in shape: %r, %r" % (o.shape, d.shape))
         ts = np.zeros((o.shape[0], 4), dtype=f32)
         counts = np.zeros(o.shape[0], dtype=np.int32)
         c = self._c()

@@ -265,6 +265,7 @@ struct Policy {
     int clusters = -1;    // RTC_AMD_CLUSTERS: nodes over long triangle runs -- 0 never, 1 always, -1 by frame size
     int share_log2 = -1;  // RTC_AMD_SHARE_LOG2 = 0..3: lanes per pixel (log2) pinned for every frame; -1: by frame size
     int scene_rect = 1;   // RTC_AMD_SCENE_RECT: 0 never launch the scene's rectangle only, 2 whenever there is one, 1 under half the frame
+    bool tree_split = true;  // RTC_AMD_TREE_SPLIT: the waves of a workgroup share a pixel's ray tree out (kernel: color_at, ray-tree splitting)
     int wavefront = 0;    // RTC_AMD_WAVEFRONT=1: tree worlds are rendered by the level-by-level renderer (rtc_wavefront.h); default: never
     std::string jit_cache;  // RTC_AMD_JIT_CACHE=<dir>; "0" / "off": compiled kernels stay in memory; empty: <library dir>/jit_cache
     // development
@@ -287,6 +288,7 @@ struct Policy {
         p.gates = flag(std::getenv("RTC_AMD_GATES"), true);
         p.tri_precull = flag(std::getenv("RTC_AMD_TRI_PRECULL"), true);
         p.block_list = flag(std::getenv("RTC_AMD_BLOCK_LIST"), true);
+        p.tree_split = flag(std::getenv("RTC_AMD_TREE_SPLIT"), true);
         p.quiet = flag(std::getenv("RTC_AMD_QUIET"), false);
         if (const char* e = std::getenv("RTC_AMD_CLUSTERS")) p.clusters = *e ? (e[0] != '0' ? 1 : 0) : -1;
         p.share_log2 = digit(std::getenv("RTC_AMD_SHARE_LOG2"), 0, 3, -1);
@@ -1128,6 +1130,7 @@ struct rtc_ctx_tiles {
 struct BlockList {  // RenderArgs::tiles of one partition (build_block_list), resident on the device
     uint32_t* d = nullptr;
     size_t n = 0;
+    uint32_t n_split = 0;  // RenderArgs::split_blocks
 };
 struct rtc_ctx {
     int device = 0;
@@ -1145,6 +1148,7 @@ struct rtc_ctx {
     uint32_t* d_ppm_bits = nullptr;
     size_t ppm_rows_cap = 0, ppm_bits_cap = 0;
     bool spec_shares = false;         // spec_fn was compiled with -DRTC_SPEC_SHARE=1
+    bool spec_splits = false;         // ... and with -DRTC_SPEC_TREE_SPLIT=1 (ray-tree splitting in the block list's dearest tiles)
     bool spec_blocks_y = false;       // ... with -DRTC_SPEC_BLOCKS_Y=1 (several blocks per workgroup)
     bool spec_rect = false;           // ... with -DRTC_SPEC_RECT=1 (scene rectangle launches: block offsets, zero-filling workgroups)
     hipFunction_t spec_fn = nullptr;  // scene-specialised kernel (hiprtc), or null: ahead-of-time kernels
@@ -1557,8 +1561,13 @@ static void mark_plane_side(const std::array<double, 4>& row, const rtc_camera* 
 // The block list of one partition (RenderArgs::tiles): the 16 x 16 tiles of the partition's compact rows, those a mesh
 // projects to first and cut into blocks of 2^mesh_share_log2 lanes per pixel (8 x 8 or 8 x 4 pixels), the others after
 // them, whole, one lane per pixel.
-static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t width, uint32_t mesh_share_log2, uint32_t rows, const Partition& q, std::vector<uint32_t>* out) {
+// `split` (kernels compiled for ray-tree splitting): the rank-3 tiles -- glass that also reflects, where a pixel's ray tree
+// branches -- are listed first as 8 x 8-pixel blocks of one lane per pixel, which all four waves of a workgroup trace together
+// (RenderArgs::split_blocks); *n_split: how many.
+static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t width, uint32_t mesh_share_log2, uint32_t rows, const Partition& q, bool split,
+                             std::vector<uint32_t>* out, uint32_t* n_split) {
     out->clear();
+    *n_split = 0u;
     std::vector<uint32_t> light;
     uint32_t hs = mesh_share_log2;  // lanes per pixel (log2) in the mesh tiles; RTC_AMD_BLOCK_S=0..3: development
     if (P.block_s >= 0) hs = (uint32_t)P.block_s;
@@ -1567,9 +1576,11 @@ static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t w
     const bool ordered = P.block_order;
     uint32_t hs_top = hs;
     if (P.block_s_top >= 0) hs_top = (uint32_t)P.block_s_top;
+    split = split && ordered;  // (they must come first)
     for (uint32_t rank = 3u; rank >= 1u; rank--) {
-        const uint32_t s = rank == 3u ? hs_top : hs;
-        const uint32_t hbw = 16u >> (s >> 1), hbh = 16u >> ((s + 1u) >> 1);
+        const bool splits = split && rank == 3u;
+        const uint32_t s = splits ? 0u : rank == 3u ? hs_top : hs;
+        const uint32_t hbw = splits ? 8u : 16u >> (s >> 1), hbh = splits ? 8u : 16u >> ((s + 1u) >> 1);
         for (uint32_t yl0 = 0; yl0 < rows; yl0 += 16u) {
             const uint32_t band = yl0 / q.band_rows;
             const uint32_t y = (band * q.n_parts + q.part) * q.band_rows + (yl0 - band * q.band_rows);  // global row of the tile's first row
@@ -1580,6 +1591,7 @@ static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t w
                     for (uint32_t dy = 0; dy < 16u && yl0 + dy < rows; dy += hbh)
                         for (uint32_t dx = 0; dx < 16u && x0 + dx < width; dx += hbw)
                             out->push_back(s << 30 | ((x0 + dx) / 4u) << 16 | ((yl0 + dy) / 4u));
+                    if (splits) *n_split = (uint32_t)out->size();
                 } else if (rank == 1u && r == 0u) {
                     light.push_back(0u << 30 | (x0 / 4u) << 16 | (yl0 / 4u));
                 }
@@ -1595,6 +1607,7 @@ static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t w
 static rtc_status jit_failed(rtc_ctx* c, int policy, rtc_status jst) {
     c->spec_fn = nullptr;
     c->spec_shares = false;
+    c->spec_splits = false;
     c->kernel_id = aot_kernel_id();
     c->jit_note = rtc_last_error();
     if (policy == 1) {
@@ -1743,6 +1756,10 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     // of divided meshes whose materials both reflect and transmit (every such hit doubles the rays below it)
     c->wf_pays = hdr.n_trav != 0u && hdr.max_leaf_run >= 16u && any_refl && any_refr;
     c->wf_disabled = false;
+    // Ray-tree splitting (kernel: color_at): compiled into the kernels that take block lists (point light, lane sharing compiled
+    // in) when some tile shows glass that also reflects -- there a pixel's ray tree branches, and the workgroup's waves share it out
+    c->spec_splits = P.tree_split && c->spec_shares && hdr.n_trav != 0u && hdr.light_kind == RTC_LIGHT_POINT && any_refl && any_refr &&
+                     std::find(c->heavy_tiles.begin(), c->heavy_tiles.end(), (uint8_t)3) != c->heavy_tiles.end();
     int reg_levels = P.reg_levels;
     if (!any_refl && !any_refr) reg_levels = 0;
     // which components of the area light's cell vectors are exact zeros (kernel: LIGHT_ZEROS / point_on_light); only when
@@ -1804,6 +1821,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         defs.push_back(share_def);
         defs.push_back(blocks_def);
         defs.push_back(rect_def);
+        if (c->spec_splits) defs.push_back("-DRTC_SPEC_TREE_SPLIT=1");
         defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
         spec_name = std::string("render_kernel_spec[") + how + (uniform ? std::string(";all ") + b : std::string()) + (hdr.has_patterns ? ";patterns" : "") + "]";
     } else if (n >= 1 && n <= 8) {
@@ -2070,6 +2088,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     // Tree worlds with meshes: a block list instead of the regular grid -- the tiles a mesh projects to first, eight
     // lanes per pixel there and one elsewhere (build_block_list).  Not when RTC_AMD_SHARE_LOG2 pins one value for all.
     const uint32_t* d_tiles = nullptr;
+    uint32_t split_blocks = 0u;
     if (spec_fn && c->spec_shares && !c->heavy_tiles.empty() && c->hdr.light_kind == RTC_LIGHT_POINT && P.share_log2 < 0 &&
         c->hdr.width <= 65532u && rows <= 262140u && rows > 0u) {
         // one list per partition, built on first use and kept until the scene changes: rtc_render_ex renders a frame as
@@ -2086,8 +2105,8 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             }
             const rtc_ctx_tiles T = {c->heavy_tiles.data(), c->heavy_w, c->heavy_h};
             std::vector<uint32_t> host;
-            build_block_list(P, T, c->hdr.width, share_log2, rows, q, &host);
             BlockList bl;
+            build_block_list(P, T, c->hdr.width, share_log2, rows, q, c->spec_splits, &host, &bl.n_split);
             bl.n = host.size();
             HIP_TRY(hipMalloc(&bl.d, std::max<size_t>(1, host.size()) * sizeof(uint32_t)));
             // (a new buffer: no launch in flight can be reading it; the copy is complete when the call returns)
@@ -2099,6 +2118,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             it = c->block_lists.emplace(key, bl).first;
         }
         d_tiles = it->second.d;
+        split_blocks = it->second.n_split;
         grid = dim3((uint32_t)it->second.n, 1);
     }
     // traced pixels among this partition's rows: x < w-1, y < h-1
@@ -2250,6 +2270,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     a.depth = depth;
     a.share_log2 = share_log2;
     a.tiles = d_tiles;
+    a.split_blocks = split_blocks;
     a.blocks_y = blocks_y;
     a.block_x0 = block_x0;
     a.block_y0 = block_y0;
