@@ -265,14 +265,14 @@ struct Policy {
     int clusters = -1;    // RTC_AMD_CLUSTERS: nodes over long triangle runs -- 0 never, 1 always, -1 by frame size
     int share_log2 = -1;  // RTC_AMD_SHARE_LOG2 = 0..3: lanes per pixel (log2) pinned for every frame; -1: by frame size
     int scene_rect = 1;   // RTC_AMD_SCENE_RECT: 0 never launch the scene's rectangle only, 2 whenever there is one, 1 under half the frame
-    bool tree_split = true;  // RTC_AMD_TREE_SPLIT: the waves of a workgroup share a pixel's ray tree out (kernel: color_at, ray-tree splitting)
+    bool block_feedback = true;  // RTC_AMD_BLOCK_FEEDBACK: a block list's second and later frames go by the first one's wave times (refine_block_list)
     int wavefront = 0;    // RTC_AMD_WAVEFRONT=1: tree worlds are rendered by the level-by-level renderer (rtc_wavefront.h); default: never
     std::string jit_cache;  // RTC_AMD_JIT_CACHE=<dir>; "0" / "off": compiled kernels stay in memory; empty: <library dir>/jit_cache
     // development
     std::string jit_source, jit_flags;  // RTC_AMD_JIT_SOURCE=<path of rtc_kernel_core.h>, RTC_AMD_JIT_FLAGS="-D... -m..."
     bool jit_print = false, cluster_stats = false, tri_naive = false, block_order = true;
     int tree_waves = 6, reg_levels = 0, blocks_y = 0, block_s = -1, block_s_top = -1;  // (0 / -1: the library's own choice)
-    uint32_t fill_wgs = 0u, cluster_min_run = 0u, cluster_leaf = 0u;
+    uint32_t fill_wgs = 0u, cluster_min_run = 0u, cluster_leaf = 0u, feedback_pct = 85u, feedback_down_pct = 40u, feedback_passes = 2u;
     double cluster_gmax = -1.0;
 
     static Policy from_env() {
@@ -288,7 +288,7 @@ struct Policy {
         p.gates = flag(std::getenv("RTC_AMD_GATES"), true);
         p.tri_precull = flag(std::getenv("RTC_AMD_TRI_PRECULL"), true);
         p.block_list = flag(std::getenv("RTC_AMD_BLOCK_LIST"), true);
-        p.tree_split = flag(std::getenv("RTC_AMD_TREE_SPLIT"), true);
+        p.block_feedback = flag(std::getenv("RTC_AMD_BLOCK_FEEDBACK"), true);
         p.quiet = flag(std::getenv("RTC_AMD_QUIET"), false);
         if (const char* e = std::getenv("RTC_AMD_CLUSTERS")) p.clusters = *e ? (e[0] != '0' ? 1 : 0) : -1;
         p.share_log2 = digit(std::getenv("RTC_AMD_SHARE_LOG2"), 0, 3, -1);
@@ -306,6 +306,9 @@ struct Policy {
         p.blocks_y = digit(RTC_DEV_ENV("RTC_AMD_BLOCKS_Y"), 1, 8, 0);
         p.block_s = digit(RTC_DEV_ENV("RTC_AMD_BLOCK_S"), 0, 3, -1);
         p.block_s_top = digit(RTC_DEV_ENV("RTC_AMD_BLOCK_S_TOP"), 0, 3, -1);
+        if (const char* e = RTC_DEV_ENV("RTC_AMD_FEEDBACK_PCT")) p.feedback_pct = std::max(1u, (uint32_t)std::atoi(e));
+        if (const char* e = RTC_DEV_ENV("RTC_AMD_FEEDBACK_DOWN_PCT")) p.feedback_down_pct = (uint32_t)std::atoi(e);
+        if (const char* e = RTC_DEV_ENV("RTC_AMD_FEEDBACK_PASSES")) p.feedback_passes = std::max(1u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_FILL_WGS")) p.fill_wgs = std::max(1u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_CLUSTER_MIN_RUN")) p.cluster_min_run = std::max(3u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_CLUSTER_LEAF")) p.cluster_leaf = std::min(64u, std::max(2u, (uint32_t)std::atoi(e)));
@@ -1130,7 +1133,11 @@ struct rtc_ctx_tiles {
 struct BlockList {  // RenderArgs::tiles of one partition (build_block_list), resident on the device
     uint32_t* d = nullptr;
     size_t n = 0;
-    uint32_t n_split = 0;  // RenderArgs::split_blocks
+    // feedback (refine_block_list): the list as built, where its first launch leaves its waves' running times, and how far it is
+    std::vector<uint32_t> host;
+    uint32_t* d_ticks = nullptr;
+    enum { FRESH, TIMED, REFINED } state = FRESH;
+    uint32_t passes = 0;  // refinements so far
 };
 struct rtc_ctx {
     int device = 0;
@@ -1148,7 +1155,6 @@ struct rtc_ctx {
     uint32_t* d_ppm_bits = nullptr;
     size_t ppm_rows_cap = 0, ppm_bits_cap = 0;
     bool spec_shares = false;         // spec_fn was compiled with -DRTC_SPEC_SHARE=1
-    bool spec_splits = false;         // ... and with -DRTC_SPEC_TREE_SPLIT=1 (ray-tree splitting in the block list's dearest tiles)
     bool spec_blocks_y = false;       // ... with -DRTC_SPEC_BLOCKS_Y=1 (several blocks per workgroup)
     bool spec_rect = false;           // ... with -DRTC_SPEC_RECT=1 (scene rectangle launches: block offsets, zero-filling workgroups)
     hipFunction_t spec_fn = nullptr;  // scene-specialised kernel (hiprtc), or null: ahead-of-time kernels
@@ -1561,13 +1567,8 @@ static void mark_plane_side(const std::array<double, 4>& row, const rtc_camera* 
 // The block list of one partition (RenderArgs::tiles): the 16 x 16 tiles of the partition's compact rows, those a mesh
 // projects to first and cut into blocks of 2^mesh_share_log2 lanes per pixel (8 x 8 or 8 x 4 pixels), the others after
 // them, whole, one lane per pixel.
-// `split` (kernels compiled for ray-tree splitting): the rank-3 tiles -- glass that also reflects, where a pixel's ray tree
-// branches -- are listed first as 8 x 8-pixel blocks of one lane per pixel, which all four waves of a workgroup trace together
-// (RenderArgs::split_blocks); *n_split: how many.
-static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t width, uint32_t mesh_share_log2, uint32_t rows, const Partition& q, bool split,
-                             std::vector<uint32_t>* out, uint32_t* n_split) {
+static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t width, uint32_t mesh_share_log2, uint32_t rows, const Partition& q, std::vector<uint32_t>* out) {
     out->clear();
-    *n_split = 0u;
     std::vector<uint32_t> light;
     uint32_t hs = mesh_share_log2;  // lanes per pixel (log2) in the mesh tiles; RTC_AMD_BLOCK_S=0..3: development
     if (P.block_s >= 0) hs = (uint32_t)P.block_s;
@@ -1576,11 +1577,9 @@ static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t w
     const bool ordered = P.block_order;
     uint32_t hs_top = hs;
     if (P.block_s_top >= 0) hs_top = (uint32_t)P.block_s_top;
-    split = split && ordered;  // (they must come first)
     for (uint32_t rank = 3u; rank >= 1u; rank--) {
-        const bool splits = split && rank == 3u;
-        const uint32_t s = splits ? 0u : rank == 3u ? hs_top : hs;
-        const uint32_t hbw = splits ? 8u : 16u >> (s >> 1), hbh = splits ? 8u : 16u >> ((s + 1u) >> 1);
+        const uint32_t s = rank == 3u ? hs_top : hs;
+        const uint32_t hbw = 16u >> (s >> 1), hbh = 16u >> ((s + 1u) >> 1);
         for (uint32_t yl0 = 0; yl0 < rows; yl0 += 16u) {
             const uint32_t band = yl0 / q.band_rows;
             const uint32_t y = (band * q.n_parts + q.part) * q.band_rows + (yl0 - band * q.band_rows);  // global row of the tile's first row
@@ -1591,7 +1590,6 @@ static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t w
                     for (uint32_t dy = 0; dy < 16u && yl0 + dy < rows; dy += hbh)
                         for (uint32_t dx = 0; dx < 16u && x0 + dx < width; dx += hbw)
                             out->push_back(s << 30 | ((x0 + dx) / 4u) << 16 | ((yl0 + dy) / 4u));
-                    if (splits) *n_split = (uint32_t)out->size();
                 } else if (rank == 1u && r == 0u) {
                     light.push_back(0u << 30 | (x0 / 4u) << 16 | (yl0 / 4u));
                 }
@@ -1601,13 +1599,66 @@ static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t w
     out->insert(out->end(), light.begin(), light.end());
 }
 
+// Feedback for block lists.  The list a scene starts with knows three kinds of tile (build_block_list) and nothing of what a tile
+// costs; the frame it schedules ends with a tail -- here_be_dragons 4000 x 1600: waves of 2.3 ms that started at 0.8 ms of a 3.1 ms
+// frame; mesh 2048^2: the machine runs out of waves at 2.2 ms, the longest (two lanes per pixel, the centre of the glass mesh)
+// run to 3.4.  The first launch of a list therefore times its waves (RenderArgs::wave_ticks), and the list of every later frame
+// of this scene and partition is made from those times: a 16 x 16 tile whose longest wave ran more than half of the frame's
+// throughput time (the sum of all waves' times over the wave slots of the device) gets more lanes per pixel, each doubling
+// taken to shorten its waves to 0.7 (measured: tools/sweep_block_s.sh), and the tiles start in the order of their predicted
+// longest wave.  Which lanes trace a pixel and when changes nothing about its value (tests/test_gpu_fullsize.py compares first
+// and later frames with the oracle).
+static void refine_block_list(const std::vector<uint32_t>& list, const std::vector<uint32_t>& ticks, uint32_t width, uint32_t rows, double wave_slots,
+                              double threshold, double down, std::vector<uint32_t>* out) {
+    struct Tile {
+        uint32_t x0, y0, s;
+        uint64_t longest = 0;
+        double predicted = 0.0;
+    };
+    const uint32_t tw = (width + 15u) / 16u;
+    std::vector<Tile> tiles;
+    std::vector<int32_t> index((size_t)tw * ((rows + 15u) / 16u), -1);
+    double total = 0.0;
+    for (size_t b = 0; b < list.size(); b++) {
+        const uint32_t t = list[b], x0 = ((t >> 16) & 0x3fffu) << 2, y0 = (t & 0xffffu) << 2;
+        int32_t& slot = index[(size_t)(y0 / 16u) * tw + x0 / 16u];
+        if (slot < 0) {
+            slot = (int32_t)tiles.size();
+            Tile n;
+            n.x0 = x0 & ~15u, n.y0 = y0 & ~15u, n.s = t >> 30;
+            tiles.push_back(n);
+        }
+        Tile& tile = tiles[(size_t)slot];
+        for (uint32_t w = 0; w < 4u; w++) {
+            const uint32_t d = ticks[4u * b + w];
+            tile.longest = std::max<uint64_t>(tile.longest, d);
+            total += d;
+        }
+    }
+    const double throughput = total / std::max(1.0, wave_slots);  // ticks the frame takes if the work were spread evenly
+    for (Tile& t : tiles) {
+        t.predicted = (double)t.longest;
+        while (t.s < 3u && t.predicted > threshold * throughput) t.s++, t.predicted *= 0.7;
+        while (t.s > 0u && t.predicted / 0.7 < down * throughput) t.s--, t.predicted /= 0.7;
+    }
+    std::vector<uint32_t> order(tiles.size());
+    for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return tiles[a].predicted > tiles[b].predicted; });
+    out->clear();
+    for (uint32_t i : order) {
+        const Tile& t = tiles[i];
+        const uint32_t hbw = 16u >> (t.s >> 1), hbh = 16u >> ((t.s + 1u) >> 1);
+        for (uint32_t dy = 0; dy < 16u && t.y0 + dy < rows; dy += hbh)
+            for (uint32_t dx = 0; dx < 16u && t.x0 + dx < width; dx += hbw) out->push_back(t.s << 30 | ((t.x0 + dx) / 4u) << 16 | ((t.y0 + dy) / 4u));
+    }
+}
+
 // The policy wanted a scene-compiled kernel and hiprtc did not deliver one.  RTC_AMD_SPECIALIZE=1: an error.  Default
 // policy: the ahead-of-time kernel renders the same image -- several times slower on area-light scenes -- so say so:
 // rtc_ctx_jit_status(), rtc_stats.flags, one line on stderr per process.
 static rtc_status jit_failed(rtc_ctx* c, int policy, rtc_status jst) {
     c->spec_fn = nullptr;
     c->spec_shares = false;
-    c->spec_splits = false;
     c->kernel_id = aot_kernel_id();
     c->jit_note = rtc_last_error();
     if (policy == 1) {
@@ -1678,8 +1729,10 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     c->has_scene = true;
     c->soa_host = soa;
     c->texels_host = texels;
-    for (auto& bl : c->block_lists)  // (nothing is in flight any more: the synchronisation above)
+    for (auto& bl : c->block_lists) {  // (nothing is in flight any more: the synchronisation above)
         if (bl.second.d) (void)hipFree(bl.second.d);
+        if (bl.second.d_ticks) (void)hipFree(bl.second.d_ticks);
+    }
     c->block_lists.clear();
     c->deep_fn.clear();
     c->spec_defs.clear();
@@ -1756,10 +1809,6 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     // of divided meshes whose materials both reflect and transmit (every such hit doubles the rays below it)
     c->wf_pays = hdr.n_trav != 0u && hdr.max_leaf_run >= 16u && any_refl && any_refr;
     c->wf_disabled = false;
-    // Ray-tree splitting (kernel: color_at): compiled into the kernels that take block lists (point light, lane sharing compiled
-    // in) when some tile shows glass that also reflects -- there a pixel's ray tree branches, and the workgroup's waves share it out
-    c->spec_splits = P.tree_split && c->spec_shares && hdr.n_trav != 0u && hdr.light_kind == RTC_LIGHT_POINT && any_refl && any_refr &&
-                     std::find(c->heavy_tiles.begin(), c->heavy_tiles.end(), (uint8_t)3) != c->heavy_tiles.end();
     int reg_levels = P.reg_levels;
     if (!any_refl && !any_refr) reg_levels = 0;
     // which components of the area light's cell vectors are exact zeros (kernel: LIGHT_ZEROS / point_on_light); only when
@@ -1821,7 +1870,6 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         defs.push_back(share_def);
         defs.push_back(blocks_def);
         defs.push_back(rect_def);
-        if (c->spec_splits) defs.push_back("-DRTC_SPEC_TREE_SPLIT=1");
         defs.insert(defs.end(), recursion_defs.begin(), recursion_defs.end());
         spec_name = std::string("render_kernel_spec[") + how + (uniform ? std::string(";all ") + b : std::string()) + (hdr.has_patterns ? ";patterns" : "") + "]";
     } else if (n >= 1 && n <= 8) {
@@ -2088,7 +2136,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     // Tree worlds with meshes: a block list instead of the regular grid -- the tiles a mesh projects to first, eight
     // lanes per pixel there and one elsewhere (build_block_list).  Not when RTC_AMD_SHARE_LOG2 pins one value for all.
     const uint32_t* d_tiles = nullptr;
-    uint32_t split_blocks = 0u;
+    uint32_t* d_ticks = nullptr;
     if (spec_fn && c->spec_shares && !c->heavy_tiles.empty() && c->hdr.light_kind == RTC_LIGHT_POINT && P.share_log2 < 0 &&
         c->hdr.width <= 65532u && rows <= 262140u && rows > 0u) {
         // one list per partition, built on first use and kept until the scene changes: rtc_render_ex renders a frame as
@@ -2099,15 +2147,18 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         if (it == c->block_lists.end()) {
             if (c->block_lists.size() >= 256u) {  // a caller cycling through partitions without end: start over (nothing may be in flight)
                 HIP_TRY(hipDeviceSynchronize());
-                for (auto& bl : c->block_lists)
+                for (auto& bl : c->block_lists) {
                     if (bl.second.d) (void)hipFree(bl.second.d);
+                    if (bl.second.d_ticks) (void)hipFree(bl.second.d_ticks);
+                }
                 c->block_lists.clear();
             }
             const rtc_ctx_tiles T = {c->heavy_tiles.data(), c->heavy_w, c->heavy_h};
             std::vector<uint32_t> host;
+            build_block_list(P, T, c->hdr.width, share_log2, rows, q, &host);
             BlockList bl;
-            build_block_list(P, T, c->hdr.width, share_log2, rows, q, c->spec_splits, &host, &bl.n_split);
             bl.n = host.size();
+            if (P.block_feedback) bl.host = host;
             HIP_TRY(hipMalloc(&bl.d, std::max<size_t>(1, host.size()) * sizeof(uint32_t)));
             // (a new buffer: no launch in flight can be reading it; the copy is complete when the call returns)
             hipError_t ce = hipMemcpy(bl.d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
@@ -2117,8 +2168,45 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             }
             it = c->block_lists.emplace(key, bl).first;
         }
+        BlockList& bl = it->second;
+        if (P.block_feedback && bl.state == BlockList::TIMED) {
+            // the list's first launch has left its waves' times: the list of this and every later frame is made from them
+            HIP_TRY(hipDeviceSynchronize());  // (once per scene and partition; the launch may be on any stream)
+            std::vector<uint32_t> ticks(4u * bl.n), refined;
+            HIP_TRY(hipMemcpy(ticks.data(), bl.d_ticks, ticks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+            refine_block_list(bl.host, ticks, c->hdr.width, rows, 0.85 * 4.0 * prop.multiProcessorCount * P.tree_waves, 0.01 * P.feedback_pct, 0.01 * P.feedback_down_pct, &refined);
+            (void)hipFree(bl.d_ticks);
+            bl.d_ticks = nullptr;
+            uint32_t* d_new = nullptr;
+            HIP_TRY(hipMalloc(&d_new, std::max<size_t>(1, refined.size()) * sizeof(uint32_t)));
+            hipError_t ce = hipMemcpy(d_new, refined.data(), refined.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (ce != hipSuccess) {
+                (void)hipFree(d_new);
+                return fail(RTC_ERR_DEVICE, "block list upload failed: %s", hipGetErrorString(ce));
+            }
+            (void)hipFree(bl.d);  // (nothing is in flight: the synchronisation above)
+            bl.d = d_new;
+            bl.n = refined.size();
+            bl.passes++;
+            if (bl.passes < P.feedback_passes) {
+                bl.host = refined;
+                bl.state = BlockList::FRESH;  // time this list's first launch as well
+            } else {
+                bl.host.clear();
+                bl.host.shrink_to_fit();
+                bl.state = BlockList::REFINED;
+            }
+            if (P.jit_print) std::fprintf(stderr, "librtc_amd: block list refined from the first frame's wave times: %zu blocks\n", bl.n);
+        }
+        if (P.block_feedback && bl.state == BlockList::FRESH && bl.n != 0) {
+            HIP_TRY(hipMalloc(&bl.d_ticks, 4u * bl.n * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(bl.d_ticks, 0, 4u * bl.n * sizeof(uint32_t), stream));
+            d_ticks = bl.d_ticks;
+            bl.state = BlockList::TIMED;
+        }
         d_tiles = it->second.d;
-        split_blocks = it->second.n_split;
         grid = dim3((uint32_t)it->second.n, 1);
     }
     // traced pixels among this partition's rows: x < w-1, y < h-1
@@ -2270,7 +2358,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     a.depth = depth;
     a.share_log2 = share_log2;
     a.tiles = d_tiles;
-    a.split_blocks = split_blocks;
+    a.wave_ticks = d_ticks;
     a.blocks_y = blocks_y;
     a.block_x0 = block_x0;
     a.block_y0 = block_y0;

@@ -979,18 +979,6 @@ struct Counters {
     DI uint32_t share_mask() const { return (1u << share_log2()) - 1u; }
     DI uint32_t sub() const { return threadIdx.x & share_mask(); }           // this lane's place among its pixel's lanes
     DI uint32_t lead() const { return sub() == 0u ? 1u : 0u; }               // 1 on the lane that counts the shared work
-    // Ray-tree splitting (color_at, -DRTC_SPEC_TREE_SPLIT=1: point-light tree kernels of scenes whose glass also reflects; in the
-    // blocks the host marks, RenderArgs::split_blocks): the four WAVES of a workgroup serve the same 8 x 8 pixels, lane for lane.
-    // Wave 0 starts every pixel; where a shade point has both children, the refraction's subtree is handed to another wave.
-    // `grp_log2_`, PER LANE: this lane may still hand work to the 2^grp_log2_ - 1 waves after its own.
-#if defined(RTC_SPEC_TREE_SPLIT) && RTC_SPEC_TREE_SPLIT
-    static constexpr bool TREE_SPLIT = SHARE_LANES;
-#else
-    static constexpr bool TREE_SPLIT = false;
-#endif
-    uint32_t grp_log2_;
-    uint32_t split_block_;  // wave-uniform: this workgroup renders such a block
-    DI bool split_block() const { return TREE_SPLIT && split_block_ != 0u; }
     DI uint32_t my_cells(uint32_t cells) const { return (cells + share_mask() - sub()) >> share_log2(); }  // cells c with c % 2^s == sub
 };
 constexpr uint32_t CNT_SHADED_MASK = 0xfffu, CNT_CULLED_SHIFT = 12u;
@@ -1431,14 +1419,14 @@ DI Hit nearest_hit(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, const Count
 // the smallest non-negative one offered as the hit together with the object's parity.
 template <int NOBJ>
 DI Hit nearest_hit_and_containers(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, const Counters& cnt, float& t1, int& c1, float& t2, int& c2,
-                                  bool& hit_inside, bool idle = false) {  // idle: this lane has no ray (it takes part in the wave's walk and finds nothing)
+                                  bool& hit_inside) {
     static_assert(NOBJ < 0, "tree kernels");
     Hit best = {0.0f, -1};
     bool best_inside = false;
     t1 = t2 = 0.0f;
     c1 = c2 = -1;
     WorldRay wr = world_ray<NOBJ>(H, o, d);
-    wr.limit = idle ? -RTC_INF : RTC_INF;
+    wr.limit = RTC_INF;
     auto after = [&](float ta, int ia, float tb, int ib) { return ta > tb || (ta == tb && ia > ib); };  // does (ta, ia) sort after (tb, ib)?
     auto offer_container = [&](float t, int c) {
         if (c1 < 0 || after(t, c, t1, c1)) {
@@ -2489,44 +2477,6 @@ struct LaneStash {
     DI uint32_t getu(int k) const { return __float_as_uint(base[k * stride]); }
 };
 
-// Ray-tree splitting (color_at): the workgroup's LDS words through which a lane hands the refraction subtree of one of its shade
-// points to the same lane of another wave, and gets that subtree's colour back.  Per wave and lane: a task (ray, remaining depth
-// and what is left of the right to hand on, path code), its state (0: none yet, 1: there, 2: there will be none), and the colour
-// with ITS state -- each written once in a workgroup's life, by one lane, and read by one other.
-struct SplitBox {
-    float* base;  // [10 words][256 threads]
-    enum { W_TASK = 8, W_DONE = 9 };
-    DI float* word(uint32_t wave, int k) const { return base + k * 256 + (wave << 6) + (threadIdx.x & 63u); }
-    DI static void put(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-    DI static float get(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-    DI void give(uint32_t wave, V3 o, V3 d, uint32_t depth_word, uint32_t path) const {
-        put(word(wave, 0), o.x), put(word(wave, 1), o.y), put(word(wave, 2), o.z);
-        put(word(wave, 3), d.x), put(word(wave, 4), d.y), put(word(wave, 5), d.z);
-        put(word(wave, 6), __uint_as_float(depth_word)), put(word(wave, 7), __uint_as_float(path));
-        __hip_atomic_store(word(wave, W_TASK), 1.0f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    DI void cancel(uint32_t wave) const { put(word(wave, W_TASK), 2.0f); }
-    DI int task(V3& o, V3& d, uint32_t& depth_word, uint32_t& path) const {  // this lane's own: 0 not yet, 2 never, 1 here it is
-        const uint32_t wave = threadIdx.x >> 6;
-        const float st = __hip_atomic_load(word(wave, W_TASK), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (st != 1.0f) return st == 0.0f ? 0 : 2;
-        o = v3(get(word(wave, 0)), get(word(wave, 1)), get(word(wave, 2)));
-        d = v3(get(word(wave, 3)), get(word(wave, 4)), get(word(wave, 5)));
-        depth_word = __float_as_uint(get(word(wave, 6))), path = __float_as_uint(get(word(wave, 7)));
-        return 1;
-    }
-    DI void post(V3 c) const {  // the colour of this lane's task
-        const uint32_t wave = threadIdx.x >> 6;
-        put(word(wave, 0), c.x), put(word(wave, 1), c.y), put(word(wave, 2), c.z);
-        __hip_atomic_store(word(wave, W_DONE), 1.0f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    DI bool take(uint32_t wave, V3& c) const {  // the colour of the task this lane gave wave `wave`, if it is there
-        if (__hip_atomic_load(word(wave, W_DONE), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0.0f) return false;
-        c = v3(get(word(wave, 0)), get(word(wave, 1)), get(word(wave, 2)));
-        return true;
-    }
-};
-
 // One suspended shade_hit (world.rs:62-86) waiting for a child colour.
 // Split in two so that the common frame -- a mirror-like hit waiting for its reflection only -- moves 6 dwords
 // instead of 13: the refraction half is written and read only when there is a refraction child.
@@ -2547,7 +2497,7 @@ struct FrameRefr {
     float transparency;
 #endif
 };
-enum { F_WAIT_REFR = 1, F_HAS_REFR = 2, F_SCHLICK = 4, F_SPLIT = 8, F_GRP_SHIFT = 4 };  // (F_SPLIT, bits 4..5: see color_at, ray-tree splitting)
+enum { F_WAIT_REFR = 1, F_HAS_REFR = 2, F_SCHLICK = 4 };
 
 // The post-order stack of color_at: one Frame (+ FrameRefr) per suspended shade_hit, at most `depth` of them.
 // A per-lane array indexed by a per-lane stack pointer lives in scratch memory: every push and pop is a round trip
@@ -2641,7 +2591,7 @@ struct FrameStack {
 // of p, 2p+1 for its refraction child.
 template <int NOBJ, bool SIMPLE>
 DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint32_t pixel, Counters& cnt,
-               const LaneStash stash, const SplitBox box = {nullptr}, bool helper = false) {
+               const LaneStash stash) {
     FrameRegs stack_regs;
     FrameMem stack_mem;
     const FrameStack stack = {stack_regs, stack_mem, stash};
@@ -2649,65 +2599,18 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
     int rem = depth;
     uint32_t path = 1;
     V3 ret = v3(0.0f, 0.0f, 0.0f);
-    // Ray-tree splitting (Counters::TREE_SPLIT, in the blocks the host marks).  The frame of a glass mesh is as long as its longest
-    // wave, and a wave is as long as its pixels' ray trees: reflection AND refraction at every hit is up to 2^(depth+1) - 1 shade
-    // points per pixel, traced one after the other (round 2's timeline: waves running 3.6 of a frame's 3.8 ms).  Lanes of one wave
-    // cannot share a tree out -- a packet walk costs the UNION of its lanes' paths through the scene, and eight subtrees per pixel
-    // in one wave walk eight times as much of it (built, bit-identical, slower); four waves each tracing everything down to the
-    // branching points do four times the work wherever a tile's pixels do not branch (built, bit-identical, slower).  So the unit
-    // handed over is a TASK: the four waves of a workgroup serve the same 64 pixels, lane for lane; wave 0 starts every pixel, the
-    // others wait (`await`).  Where a shade point has both children and this lane may still hand work on, the refraction ray goes
-    // -- through LDS (SplitBox) -- to the same lane of the wave 2^(c-1) further on, with the right to hand on to the waves behind
-    // THAT one (c - 1), and this lane continues with the reflection (c - 1 left as well); the suspended shade_hit is marked F_SPLIT.
-    // Back at that frame the lane waits (`idle`) until the subtree's colour has arrived, and forms surface + reflected + refracted
-    // from the same operands in the reference's order -- the same bits whichever wave traced what.  A lane without a ray takes
-    // part in its wave's walks with a ray that needs nothing.  A wave that finishes a task returns its colour and tells the waves
-    // it never used that no task will come.  Every ray is traced exactly once, by some wave; a wave stays a bundle of
-    // neighbouring pixels' rays of like kind.
-#if RTC_COMPACT_FRAMES
-    constexpr bool SPLIT = false;
-#else
-    constexpr bool SPLIT = NOBJ < 0 && Counters::TREE_SPLIT && ANY_REFL && ANY_REFR;
-#endif
-    bool idle = false, await = SPLIT && helper;
-    // (an exit every wave reaches whatever happens to the protocol: past it the pixel is NaN, which no test lets through)
-    uint32_t rounds_left = 1u << 22;
     for (;;) {
-        bool wave_has_rays = true;
-        if constexpr (SPLIT) {
-            if (cnt.split_block()) {
-                if (rounds_left-- == 0u) return v3(__uint_as_float(0x7fc00000u), __uint_as_float(0x7fc00000u), __uint_as_float(0x7fc00000u));
-                if (await) {
-                    uint32_t depth_word = 0u;
-                    const int t = box.task(o, d, depth_word, path);
-                    if (t == 2) return ret;  // this pixel has no work for this wave
-                    if (t == 1) {
-                        rem = (int)(depth_word & 0xffu);
-                        cnt.grp_log2_ = depth_word >> 8;
-                        await = false;
-                    }
-                }
-                wave_has_rays = __any(!(idle || await)) != 0;
-                if (!wave_has_rays) __builtin_amdgcn_s_sleep(16);  // every lane of the wave waits for another wave: let that one run
-            }
-        }
-        const bool rayless = SPLIT && (idle || await);
         // ---------------- color_at(ray(o, d), rem)
-        if (!rayless) cnt.rays += cnt.lead();
+        cnt.rays += cnt.lead();
         Hit h;
         float kt1 = 0.0f, kt2 = 0.0f;  // tree kernels: the ray's containers, from the same walk (nearest_hit_and_containers)
         int kc1 = -1, kc2 = -1;
         bool k_inside = false;
         constexpr bool TREE_N12 = NOBJ < 0 && ANY_REFR && MERGED_N12;
-        static_assert(!SPLIT || TREE_N12, "ray-tree splitting is built on nearest_hit_and_containers");
-        if constexpr (TREE_N12) {
-            h = {0.0f, -1};
-            if (!SPLIT || wave_has_rays) h = nearest_hit_and_containers<NOBJ>(H, S, o, d, cnt, kt1, kc1, kt2, kc2, k_inside, rayless);
-        } else {
-            h = nearest_hit<NOBJ, true>(H, S, o, d, cnt);
-        }
+        if constexpr (TREE_N12) h = nearest_hit_and_containers<NOBJ>(H, S, o, d, cnt, kt1, kc1, kt2, kc2, k_inside);
+        else h = nearest_hit<NOBJ, true>(H, S, o, d, cnt);
         bool descend = false;
-        if (!rayless) ret = v3(0.0f, 0.0f, 0.0f);  // (a waiting lane keeps its subtree's colour)
+        ret = v3(0.0f, 0.0f, 0.0f);
         if (h.obj >= 0) {
             // precompute_values, world.rs:212-233.  Only what the light sampling needs is computed before
             // it (point, normal, over_point); everything else is (re)derived afterwards so that it is not
@@ -2849,18 +2752,7 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
 #endif
                     stack.put_refr(sp, fr);
                 }
-                bool split = false;
-                if constexpr (SPLIT) split = has_refl && has_refr && cnt.split_block() && cnt.grp_log2_ != 0u;
-                if (SPLIT && split) {  // both children: the refraction's subtree goes to another wave
-                    const uint32_t c = cnt.grp_log2_;
-                    box.give(((threadIdx.x >> 6) + (1u << (c - 1u))) & 3u, under_point, rdir, (uint32_t)(rem - 1) | (c - 1u) << 8, path * 2u + 1u);
-                    f.acc = surface;
-                    f.flags |= F_SPLIT | (c << F_GRP_SHIFT);
-                    cnt.grp_log2_ = c - 1u;
-                    o = over_point;
-                    d = reflectv;
-                    path = path * 2u;
-                } else if (has_refl) {
+                if (has_refl) {
                     f.acc = surface;
                     o = over_point;
                     d = reflectv;
@@ -2879,83 +2771,6 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
             }
         }
         if (descend) continue;
-#if !RTC_COMPACT_FRAMES
-        if constexpr (SPLIT) {
-            if (cnt.split_block()) {  // wave-uniform
-                // ---------------- return `ret` to the suspended callers; at an F_SPLIT frame wait for the other wave's colour
-                if (await) continue;
-                bool done = false;
-                for (;;) {
-                    bool got_ray = false;
-                    while (!idle) {
-                        if (sp == 0) {
-                            done = true;
-                            break;
-                        }
-                        Frame f = stack.get(sp - 1);
-                        if (f.flags & F_SPLIT) {
-                            idle = true;
-                            break;
-                        }
-                        rem++;
-#if RTC_DEEP_STACK
-                        path = f.path;
-#else
-                        path >>= 1;
-#endif
-                        if (!(f.flags & F_WAIT_REFR)) {
-                            V3 reflected = ret * f.reflective;  // world.rs:131
-                            V3 partial = (f.flags & F_SCHLICK) ? f.acc + reflected * f.R : f.acc + reflected;
-                            if (f.flags & F_HAS_REFR) {
-                                f.acc = partial;
-                                f.flags |= F_WAIT_REFR;
-                                stack.put(sp - 1, f);
-                                const FrameRefr fr = stack.get_refr(sp - 1);
-                                o = fr.ro;
-                                d = fr.rd;
-                                rem--;
-                                path = path * 2u + 1u;
-                                got_ray = true;
-                                break;
-                            }
-                            const V3 black = v3(0.0f, 0.0f, 0.0f);
-                            ret = (f.flags & F_SCHLICK) ? partial + black * (1.0f - f.R) : partial + black;
-                            sp--;
-                        } else {
-                            V3 refracted = ret * stack.get_refr(sp - 1).transparency;  // world.rs:159-160
-                            ret = (f.flags & F_SCHLICK) ? f.acc + refracted * (1.0f - f.R) : f.acc + refracted;
-                            sp--;
-                        }
-                    }
-                    if (done || got_ray) break;
-                    // waiting at an F_SPLIT frame with the reflection's colour in `ret`: has the refraction's arrived?
-                    const Frame f = stack.get(sp - 1);
-                    const uint32_t c = (f.flags >> F_GRP_SHIFT) & 3u;
-                    V3 from_refr;
-                    if (!box.take(((threadIdx.x >> 6) + (1u << (c - 1u))) & 3u, from_refr)) break;
-                    V3 reflected = ret * f.reflective;  // world.rs:131
-                    V3 partial = (f.flags & F_SCHLICK) ? f.acc + reflected * f.R : f.acc + reflected;
-                    V3 refracted = from_refr * stack.get_refr(sp - 1).transparency;  // world.rs:159-160
-                    ret = (f.flags & F_SCHLICK) ? partial + refracted * (1.0f - f.R) : partial + refracted;
-                    sp--;
-                    rem++;
-#if RTC_DEEP_STACK
-                    path = f.path;
-#else
-                    path >>= 1;
-#endif
-                    idle = false;
-                }
-                if (done) {
-                    const uint32_t wave = threadIdx.x >> 6;
-                    if (helper) box.post(ret);  // a task's colour
-                    for (uint32_t h = 1u; h < (1u << cnt.grp_log2_); h++) box.cancel((wave + h) & 3u);  // the waves this lane never gave work
-                    return ret;
-                }
-                continue;
-            }
-        }
-#endif
         // ---------------- return `ret` to the suspended callers
         for (;;) {
             if (sp == 0) return ret;
@@ -3028,9 +2843,9 @@ struct RenderArgs {
     // projects to first and with 8 lanes per pixel, the rest after them with one (rtc_device.hip build_block_list):
     // such a frame's time is that of its slowest waves, so those start first and are cut into eight.  nullptr: regular grid.
     const uint32_t* tiles;
-    // ... of which the first `split_blocks` are 8 x 8 pixels traced by all four waves of their workgroup together, which share
-    // the pixels' ray trees out between them (color_at, ray-tree splitting; kernels compiled with -DRTC_SPEC_TREE_SPLIT=1)
-    uint32_t split_blocks;
+    // Block lists only; nullptr: not asked for.  Wave w of workgroup b leaves its own running time here, [4 b + w], in ticks of the
+    // 100 MHz clock: what the host orders and cuts the NEXT frames' block list by (rtc_device.hip refine_block_list).
+    uint32_t* wave_ticks;
     uint32_t blocks_y;  // regular grid: blocks rendered by one workgroup, stacked vertically (>= 1)
     // regular grid: the launch covers the blocks from (block_x0, block_y0) on -- of a frame whose scene can only be seen
     // inside a rectangle of pixel columns [fill_x0, fill_x1) x local rows [fill_y0, fill_y1) only that rectangle is rendered
@@ -3092,13 +2907,11 @@ DI void render_body(const RenderArgs& A) {
     // With 2^s lanes per pixel a wave takes a tile of 64 >> s pixels (8x8, 8x4, 4x4, 4x2) and every lane a 2^-s share of
     // each shade point's light cells; all other work is replicated across a pixel's lanes (same inputs, same bits).
     uint32_t sl = Counters::SHARE_LANES ? A.share_log2 : 0u, bx0, by0;  // lanes per pixel (log2) and pixel origin of this workgroup's block
-    bool split_block = false;  // (workgroup-uniform)
     if (Counters::SHARE_LANES && A.tiles != nullptr) {
         const uint32_t t = A.tiles[blockIdx.x];  // wave-uniform
         sl = t >> 30;
         bx0 = ((t >> 16) & 0x3fffu) << 2;
         by0 = (t & 0xffffu) << 2;
-        split_block = Counters::TREE_SPLIT && blockIdx.x < A.split_blocks;  // (the host lists these with one lane per pixel)
     } else {
         bx0 = blockIdx.x << (4u - (sl >> 1));
         by0 = blockIdx.y << (4u - ((sl + 1u) >> 1));
@@ -3129,10 +2942,11 @@ DI void render_body(const RenderArgs& A) {
     }
     const uint32_t q = lane >> sl;  // q: the pixel's slot in the wave's tile
     const uint32_t tw_log2 = 3u - (sl >> 1), th_log2 = 3u - ((sl + 1u) >> 1);
-    const uint32_t tile = split_block ? 0u : wave;  // this wave's tile among the block's 2 x 2
-    const uint32_t x = bx0 + ((tile & 1u) << tw_log2) + (q & ((1u << tw_log2) - 1u));
-    Counters cnt = {0u, 0u, sl, split_block ? 2u : 0u, split_block ? 1u : 0u};
-    const bool helper = split_block && (lane >> 4) != wave;  // this lane traces what its pixel's lane in wave `lane / 16` hands on, see color_at
+    const uint32_t x = bx0 + ((wave & 1u) << tw_log2) + (q & ((1u << tw_log2) - 1u));
+    Counters cnt = {0u, 0u, sl};
+    const bool timed = Counters::SHARE_LANES && A.tiles != nullptr && A.wave_ticks != nullptr;  // wave-uniform
+    uint32_t ticks0 = 0u;
+    if (timed) ticks0 = (uint32_t)wall_clock64();
 #ifdef RTC_DEBUG_TIMELINE  // development (tools/wave_timeline.py): the frame holds each wave's start / end / place instead of colours
     const uint32_t t_start = (uint32_t)wall_clock64();
 #endif
@@ -3141,15 +2955,6 @@ DI void render_body(const RenderArgs& A) {
 #endif
     __shared__ float stash_lds[LDS_SLOTS * 256];
     const LaneStash stash = {stash_lds + threadIdx.x, 256u};
-    __shared__ float split_lds[Counters::TREE_SPLIT ? 10 * 256 : 1];  // SplitBox
-    const SplitBox split_box = {split_lds};
-    if constexpr (Counters::TREE_SPLIT) {
-        if (split_block) {
-            split_lds[SplitBox::W_TASK * 256 + threadIdx.x] = 0.0f;
-            split_lds[SplitBox::W_DONE * 256 + threadIdx.x] = 0.0f;
-            __syncthreads();
-        }
-    }
     __shared__ uint32_t waves_done;  // progress reporting: how many of this workgroup's waves have stored their pixels
     if (A.progress != nullptr) {     // wave-uniform (a kernel argument)
         if (threadIdx.x == 0) waves_done = 0u;
@@ -3168,7 +2973,7 @@ DI void render_body(const RenderArgs& A) {
         if (fills) fill_outside(A, grid_y);
     }
     for (uint32_t rep = 0; rep < blocks_y; rep++) {
-    const uint32_t yl = (A.tiles != nullptr ? by0 : (grid_y * blocks_y + rep + block_y0) << (4u - ((sl + 1u) >> 1))) + ((tile >> 1) << th_log2) + (q >> tw_log2);
+    const uint32_t yl = (A.tiles != nullptr ? by0 : (grid_y * blocks_y + rep + block_y0) << (4u - ((sl + 1u) >> 1))) + ((wave >> 1) << th_log2) + (q >> tw_log2);
     if ((!RECT_LAUNCH || !fills) && x < H.width && yl < A.rows) {
         // compact local row -> global row of the image
         const uint32_t band = yl / A.band_rows;
@@ -3200,10 +3005,10 @@ DI void render_body(const RenderArgs& A) {
                                          make_float4(H.scene_box[3], H.scene_box[4], H.scene_box[5], 0.0f), tmin);
             }
             if (sees_nothing) {
-                if (!helper) cnt.rays += cnt.lead();
+                cnt.rays += cnt.lead();
             } else {
                 V3 direction = norm3(pixel - origin);
-                col = color_at<NOBJ, SIMPLE>(H, A.soa, origin, direction, A.depth, y * H.width + x, cnt, stash, split_box, helper);
+                col = color_at<NOBJ, SIMPLE>(H, A.soa, origin, direction, A.depth, y * H.width + x, cnt, stash);
             }
         }
 #ifdef RTC_DEBUG_TIMELINE
@@ -3213,7 +3018,7 @@ DI void render_body(const RenderArgs& A) {
 #ifdef RTC_DEBUG_STEPS  // group tests | exact tests << 20, leaf box tests, entries the WAVE stepped through
         col = v3(__uint_as_float(dbg_steps()[0] | dbg_steps()[2] << 20), __uint_as_float(dbg_steps()[1]), __uint_as_float(dbg_steps()[3]));
 #endif
-        if (cnt.lead() && !helper) {
+        if (cnt.lead()) {
             const bool through = A.progress != nullptr;  // wave-uniform: write-through stores (RenderArgs::progress)
             if (A.out_u8 != nullptr) {  // wave-uniform: scale_color on the way out (the arithmetic of quantize_kernel)
                 uint8_t* dst = A.out_u8 + ((size_t)yl * H.width + x) * 3;
@@ -3253,6 +3058,7 @@ DI void render_body(const RenderArgs& A) {
     // depth of recursion -- the edge of a glass ball -- the waiting waves were holding the slots of the next workgroup)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) A.total[threadIdx.x] = 0ull;  // for sum_counts_kernel's atomics
     if (lane == 0) A.block_counts[slot + wave] = make_uint4(rays, shaded, culled, 0u);
+    if (timed && lane == 0) A.wave_ticks[slot + wave] = (uint32_t)wall_clock64() - ticks0;
     if (A.progress != nullptr) {  // see RenderArgs::progress
         // every store of this wave has been acknowledged -- and, being write-through, is in memory -- before the wave counts
         // itself done

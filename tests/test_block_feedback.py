@@ -1,0 +1,79 @@
+"""Block lists made from the previous frame's wave times (rtc_device.hip refine_block_list; -m gpu).
+
+The first frame of a scene with divided meshes under a point light is rendered from a block list that knows three kinds of
+tile; that launch times its waves, and every later frame's list -- which tiles start first, how many lanes trace a pixel of
+each -- is made from those times.  None of it may change a pixel or the ray count: every frame of a sequence is compared with
+the oracle, whole, with the feedback on (first frame: the list as built; later ones: refined once, twice) and off, and for
+a frame rendered as two interleaved partitions (each has a list and a refinement of its own).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from ray_tracer_challenge_amd import scenes
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+THREADS = min(16, len(os.sched_getaffinity(0)))
+
+
+def _renderer(world, camera):
+    from ray_tracer_challenge_amd.renderer import Renderer
+    return Renderer(world, camera, device=0)
+
+
+@pytest.fixture
+def feedback_env():
+    saved = os.environ.get("RTC_AMD_BLOCK_FEEDBACK")
+
+    def set_(v):
+        if v is None:
+            os.environ.pop("RTC_AMD_BLOCK_FEEDBACK", None)
+        else:
+            os.environ["RTC_AMD_BLOCK_FEEDBACK"] = v
+    yield set_
+    set_(saved)
+
+
+@pytest.mark.parametrize("name,size", [("mesh", (320, 240)), ("mesh", (1024, 768)), ("here_be_dragons", (500, 200))])
+def test_every_frame_of_a_sequence_equals_the_oracle(feedback_env, name, size):
+    world, camera, depth = getattr(scenes, name)(*size)
+    exp, exp_rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=THREADS)
+    for mode in (None, "0"):  # the library's default (feedback on), and off
+        feedback_env(mode)
+        r = _renderer(world, camera)  # (switches are read when the context is created)
+        assert r.kernel_name.startswith("render_kernel_spec[tree"), r.kernel_name
+        for frame in range(5):
+            image = r.render(depth).cpu().numpy()
+            st = r.stats()
+            what = "%s %dx%d feedback=%s frame %d" % (name, size[0], size[1], mode, frame)
+            if not np.array_equal(image, exp):
+                H.assert_images_equal(image, exp, what)
+            assert st["rays"] == exp_rays, (what, st["rays"], exp_rays)
+        r.close()
+
+
+def test_partitions_refine_their_own_lists(feedback_env):
+    feedback_env(None)
+    world, camera, depth = scenes.mesh(640, 480)
+    exp, exp_rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=THREADS)
+    r = _renderer(world, camera)
+    n_parts, band = 2, 48
+    for frame in range(4):
+        image = np.zeros_like(exp)
+        rays = 0
+        for part in range(n_parts):
+            q = r.partition(band, n_parts, part)
+            rows = r.render(depth, part=q).cpu().numpy()
+            rays += r.stats()["rays"]
+            cursor = 0
+            for b in range(part, (camera.height + band - 1) // band, n_parts):
+                y0, y1 = b * band, min(camera.height, (b + 1) * band)
+                image[y0:y1] = rows[cursor:cursor + (y1 - y0)]
+                cursor += y1 - y0
+            assert cursor == rows.shape[0]
+        if not np.array_equal(image, exp):
+            H.assert_images_equal(image, exp, "two partitions, frame %d" % frame)
+        assert rays == exp_rays, (frame, rays, exp_rays)
+    r.close()

@@ -249,6 +249,12 @@ def test_demo_scenes_whole_frame_at_the_sizes_they_are_timed_at(torch, name, siz
     r = _renderer(world, camera)
     image = r.render(depth).cpu().numpy()
     st = r.stats()
+    # ... and so do the later frames of the same scene, which is what the table times: block lists are made from the frames
+    # before (rtc_device.hip refine_block_list)
+    for _ in range(3):
+        later = r.render(depth).cpu().numpy()
+    later_rays = r.stats()["rays"]
     r.close()
     assert not np.isnan(image).any()
+    assert np.array_equal(later, image) and later_rays == st["rays"], "%s: the fourth frame differs from the first" % name
     _check_whole_frame(image, st["rays"], world, camera, depth, "%s %dx%d" % ((name,) + size))

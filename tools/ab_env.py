@@ -26,7 +26,7 @@ def child(scene, w, h, steps):
     world, camera, depth = getattr(scenes, scene)(w, h)
     r = Renderer(world, camera, device=0)
     out = r.alloc()
-    for _ in range(3):
+    for _ in range(5):
         r.render(depth, out=out)
     r.stats()
     for _ in range(steps):
