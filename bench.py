@@ -263,9 +263,18 @@ def main(argv=None):
     gather = BandGather(camera.height, camera.width, 3, torch.float32, device, rank, world_size)
     assert gather.local_view(0).shape[0] == renderer_for(rank).rows(Renderer.partition(64, world_size, rank))
     run = make_runner(gather)
-    run(args.warmup)
+    # the first frame of a scene is rendered in image order; from the next one on the blocks start in the order of the work
+    # the frame before counted in them (rtc_device.hip refine_block_list).  Every ray is traced in every frame all the same.
+    first = None
+    if args.warmup > 0:
+        run(1)
+        fence()
+        first = drain()
+    run(max(0, args.warmup - 1))
     fence()
     warm = drain()
+    if args.warmup <= 1 and first is not None:
+        warm = first
 
     # xGMI is point-to-point: every peer's rows reach rank 0 over that peer's one link.  When moving a peer's share
     # takes longer than rendering it, rank 0 -- whose rows never travel -- takes E extra parts of an (N + E)-way split
@@ -375,6 +384,10 @@ def main(argv=None):
                            world_size + extra_parts, (", rank 0 renders %d of them; RCCL gather of f32 rows to rank 0"
                                                       % (extra_parts + 1)) if world_size > 1 else "")},
             "tested_rays_per_s": round((rays - culled) / (elapsed / args.steps), 1),
+            "schedule": {"blocks": "16x16-pixel blocks; first frame of a scene in image order, later frames longest first by the "
+                                   "work counts (rays, shade points) of the frame before -- every frame traces every ray",
+                         "first_frame_kernel_ms": round(first["kernel_ms"], 4) if first else None,
+                         "off_switch": "RTC_AMD_BLOCK_FEEDBACK=0"},
             "roofline": valu_roofline(pmc, st["kernel_ms"], renderer),
             "contract_hbm_figure": {"algorithmic_bytes": algo_bytes, "achieved_GBps": round(achieved, 2), "peak_GBps": HBM_PEAK_GBS,
                                     "frac": round(achieved / HBM_PEAK_GBS, 4),

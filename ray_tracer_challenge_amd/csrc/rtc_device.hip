@@ -265,6 +265,7 @@ struct Policy {
     int clusters = -1;    // RTC_AMD_CLUSTERS: nodes over long triangle runs -- 0 never, 1 always, -1 by frame size
     int share_log2 = -1;  // RTC_AMD_SHARE_LOG2 = 0..3: lanes per pixel (log2) pinned for every frame; -1: by frame size
     int scene_rect = 1;   // RTC_AMD_SCENE_RECT: 0 never launch the scene's rectangle only, 2 whenever there is one, 1 under half the frame
+    bool grid_feedback = true;   // RTC_AMD_GRID_FEEDBACK: ... and so do the frames of a regular grid: their blocks start longest first
     bool block_feedback = true;  // RTC_AMD_BLOCK_FEEDBACK: a block list's second and later frames go by the first one's wave times (refine_block_list)
     int wavefront = 0;    // RTC_AMD_WAVEFRONT=1: tree worlds are rendered by the level-by-level renderer (rtc_wavefront.h); default: never
     std::string jit_cache;  // RTC_AMD_JIT_CACHE=<dir>; "0" / "off": compiled kernels stay in memory; empty: <library dir>/jit_cache
@@ -289,6 +290,7 @@ struct Policy {
         p.tri_precull = flag(std::getenv("RTC_AMD_TRI_PRECULL"), true);
         p.block_list = flag(std::getenv("RTC_AMD_BLOCK_LIST"), true);
         p.block_feedback = flag(std::getenv("RTC_AMD_BLOCK_FEEDBACK"), true);
+        p.grid_feedback = flag(std::getenv("RTC_AMD_GRID_FEEDBACK"), true);
         p.quiet = flag(std::getenv("RTC_AMD_QUIET"), false);
         if (const char* e = std::getenv("RTC_AMD_CLUSTERS")) p.clusters = *e ? (e[0] != '0' ? 1 : 0) : -1;
         p.share_log2 = digit(std::getenv("RTC_AMD_SHARE_LOG2"), 0, 3, -1);
@@ -1135,7 +1137,8 @@ struct BlockList {  // RenderArgs::tiles of one partition (build_block_list), re
     size_t n = 0;
     // feedback (refine_block_list): the list as built, where its first launch leaves its waves' running times, and how far it is
     std::vector<uint32_t> host;
-    uint32_t* d_ticks = nullptr;
+    uint32_t* d_ticks = nullptr;  // [4 n] wave times -- or, for kernels that do not time their waves, [4 n] uint4 work counts (a copy of block_counts)
+    bool counts = false;
     enum { FRESH, TIMED, REFINED } state = FRESH;
     uint32_t passes = 0;  // refinements so far
 };
@@ -2137,6 +2140,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     // lanes per pixel there and one elsewhere (build_block_list).  Not when RTC_AMD_SHARE_LOG2 pins one value for all.
     const uint32_t* d_tiles = nullptr;
     uint32_t* d_ticks = nullptr;
+    void* copy_counts_to = nullptr;
     if (spec_fn && c->spec_shares && !c->heavy_tiles.empty() && c->hdr.light_kind == RTC_LIGHT_POINT && P.share_log2 < 0 &&
         c->hdr.width <= 65532u && rows <= 262140u && rows > 0u) {
         // one list per partition, built on first use and kept until the scene changes: rtc_render_ex renders a frame as
@@ -2310,6 +2314,80 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         }
         grid.y += fill_wg_rows;
     }
+    // A regular grid's frames after the first: the same 16 x 16 blocks, started in the order of their longest wave in the frame
+    // before (refine_block_list: a list of one lane per pixel throughout).  Where the grid is the plain one -- one block per
+    // workgroup, no scene rectangle, nobody waiting for rows in image order (rtc_render_ex's progress words) -- and the frame
+    // has a tail worth the list: its longest wave is a tenth of its throughput time or more.
+    if (d_tiles == nullptr && P.block_feedback && P.grid_feedback && plan == nullptr && rows > 0u && !rect_launch && blocks_y == 1u && share_log2 == 0u &&
+        c->hdr.width <= 65532u && rows <= 262140u && !(c->hdr.n_trav != 0u && c->policy.wavefront)) {
+        const std::array<uint32_t, 4> key = {q.band_rows, q.n_parts, q.part, 0xffffffffu};
+        auto it = c->block_lists.find(key);
+        if (it == c->block_lists.end()) {
+            if (c->block_lists.size() >= 256u) {
+                HIP_TRY(hipDeviceSynchronize());
+                for (auto& bl : c->block_lists) {
+                    if (bl.second.d) (void)hipFree(bl.second.d);
+                    if (bl.second.d_ticks) (void)hipFree(bl.second.d_ticks);
+                }
+                c->block_lists.clear();
+            }
+            BlockList bl;
+            bl.n = (size_t)grid.x * grid.y;
+            it = c->block_lists.emplace(key, bl).first;
+        }
+        BlockList& bl = it->second;
+        if (bl.state == BlockList::TIMED) {
+            HIP_TRY(hipDeviceSynchronize());  // (once per scene and partition)
+            std::vector<uint32_t> ticks(4u * bl.n), raster(bl.n), ordered;
+            if (bl.counts) {
+                // a kernel that does not time its waves: what a wave cost, from what it counted -- rays that met objects, and
+                // shade points (each a light-cone cull, a Phong evaluation, a push or pop of the recursion) at sixteen rays apiece
+                std::vector<uint4> counts(4u * bl.n);
+                HIP_TRY(hipMemcpy(counts.data(), bl.d_ticks, counts.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < counts.size(); i++) ticks[i] = (counts[i].x - std::min(counts[i].x, counts[i].z)) + 16u * counts[i].y + counts[i].z / 8u;
+            } else {
+                HIP_TRY(hipMemcpy(ticks.data(), bl.d_ticks, ticks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            }
+            (void)hipFree(bl.d_ticks);
+            bl.d_ticks = nullptr;
+            for (uint32_t by = 0; by < grid.y; by++)
+                for (uint32_t bx = 0; bx < grid.x; bx++) raster[(size_t)by * grid.x + bx] = (bx * 4u) << 16 | (by * 4u);
+            uint64_t longest = 0;
+            double total = 0.0;
+            for (uint32_t t : ticks) longest = std::max<uint64_t>(longest, t), total += t;
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+            const double wave_slots = 0.85 * 4.0 * prop.multiProcessorCount * 6.0;
+            bl.state = BlockList::REFINED;
+            if ((double)longest >= 0.1 * total / wave_slots) {
+                refine_block_list(raster, ticks, c->hdr.width, rows, wave_slots, INFINITY, 0.0, &ordered);
+                if (ordered.size() == bl.n) {
+                    HIP_TRY(hipMalloc(&bl.d, bl.n * sizeof(uint32_t)));
+                    hipError_t ce = hipMemcpy(bl.d, ordered.data(), bl.n * sizeof(uint32_t), hipMemcpyHostToDevice);
+                    if (ce != hipSuccess) {
+                        (void)hipFree(bl.d);
+                        bl.d = nullptr;
+                        return fail(RTC_ERR_DEVICE, "block list upload failed: %s", hipGetErrorString(ce));
+                    }
+                }
+            }
+            if (P.jit_print) std::fprintf(stderr, "librtc_amd: grid of %zu blocks %s by the first frame's wave %s\n", bl.n, bl.d ? "ordered" : "left as it is", bl.counts ? "counts" : "times");
+        }
+        if (bl.state == BlockList::FRESH && bl.n == (size_t)grid.x * grid.y) {
+            bl.counts = !(spec_fn && c->spec_shares);
+            HIP_TRY(hipMalloc(&bl.d_ticks, 4u * bl.n * (bl.counts ? sizeof(uint4) : sizeof(uint32_t))));
+            if (bl.counts) {
+                copy_counts_to = bl.d_ticks;  // (after the launch, on its stream)
+            } else {
+                HIP_TRY(hipMemsetAsync(bl.d_ticks, 0, 4u * bl.n * sizeof(uint32_t), stream));
+                d_ticks = bl.d_ticks;
+            }
+            bl.state = BlockList::TIMED;
+        } else if (bl.state == BlockList::REFINED && bl.d != nullptr) {
+            d_tiles = bl.d;
+            grid = dim3((uint32_t)bl.n, 1);
+        }
+    }
     const size_t n_blocks = (size_t)grid.x * grid.y * 4;  // partial counts: one per wave
     if (n_blocks > c->block_cap) {  // grow-only workspace (first call / larger image only)
         if (c->d_block_counts) HIP_TRY(hipFree(c->d_block_counts));
@@ -2388,6 +2466,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     else if (c->n_objects <= 8) hipLaunchKernelGGL((render_kernel<8, false>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, 0, stream, a);
     HIP_TRY(hipEventRecord(ev.second, stream));
+    if (copy_counts_to) HIP_TRY(hipMemcpyAsync(copy_counts_to, c->d_block_counts, n_blocks * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(sum_counts_kernel, dim3((uint32_t)((n_blocks + SUM_COUNTS_SLICE - 1) / SUM_COUNTS_SLICE)), dim3(1024), 0, stream,
                        c->d_block_counts, (uint32_t)n_blocks, c->d_total + 3 * (size_t)slot, extra_rays);
     HIP_TRY(hipGetLastError());

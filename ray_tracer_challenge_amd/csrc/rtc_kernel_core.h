@@ -2837,14 +2837,16 @@ struct RenderArgs {
     uint32_t band_rows, n_parts, part;
     int32_t depth;
     uint32_t share_log2;   // 2^share_log2 lanes per pixel (see Counters): > 0 only for area lights on small images
-    // Block list (kernels compiled for lane sharing; tree worlds with long leaf runs): workgroup b renders the block
-    // tiles[b] = s << 30 | (x0 / 4) << 16 | (y0 / 4) -- pixel origin (x0, local row y0) and ITS OWN lanes-per-pixel 2^s --
-    // instead of block (blockIdx.x, blockIdx.y) of a regular grid.  The host lists the blocks of image regions a mesh
-    // projects to first and with 8 lanes per pixel, the rest after them with one (rtc_device.hip build_block_list):
-    // such a frame's time is that of its slowest waves, so those start first and are cut into eight.  nullptr: regular grid.
+    // Block list: workgroup b renders the block tiles[b] = s << 30 | (x0 / 4) << 16 | (y0 / 4) -- pixel origin (x0, local row y0)
+    // and, in kernels compiled for lane sharing, ITS OWN lanes-per-pixel 2^s -- instead of block (blockIdx.x, blockIdx.y) of a
+    // regular grid.  For tree worlds with long leaf runs the host lists the blocks of image regions a mesh projects to first and
+    // with more lanes per pixel, the rest after them with one (rtc_device.hip build_block_list): such a frame's time is that of
+    // its slowest waves, so those start first and are cut up.  From a scene's second frame on, any list is made from the wave
+    // times of the frame before (refine_block_list).  nullptr: regular grid.
     const uint32_t* tiles;
-    // Block lists only; nullptr: not asked for.  Wave w of workgroup b leaves its own running time here, [4 b + w], in ticks of the
-    // 100 MHz clock: what the host orders and cuts the NEXT frames' block list by (rtc_device.hip refine_block_list).
+    // Kernels compiled for lane sharing; nullptr: not asked for.  Wave w of workgroup b (of a block list, or b = blockIdx.y *
+    // gridDim.x + blockIdx.x) leaves its own running time here, [4 b + w], in ticks of the 100 MHz clock: what the host orders
+    // and cuts the NEXT frames' list by.  (The other kernels' lists are ordered by the waves' work counts, block_counts.)
     uint32_t* wave_ticks;
     uint32_t blocks_y;  // regular grid: blocks rendered by one workgroup, stacked vertically (>= 1)
     // regular grid: the launch covers the blocks from (block_x0, block_y0) on -- of a frame whose scene can only be seen
@@ -2906,16 +2908,6 @@ DI void render_body(const RenderArgs& A) {
     // each working through 64 pixels x 100 shadow rays, leaves most of the chip idle for the length of one wave.
     // With 2^s lanes per pixel a wave takes a tile of 64 >> s pixels (8x8, 8x4, 4x4, 4x2) and every lane a 2^-s share of
     // each shade point's light cells; all other work is replicated across a pixel's lanes (same inputs, same bits).
-    uint32_t sl = Counters::SHARE_LANES ? A.share_log2 : 0u, bx0, by0;  // lanes per pixel (log2) and pixel origin of this workgroup's block
-    if (Counters::SHARE_LANES && A.tiles != nullptr) {
-        const uint32_t t = A.tiles[blockIdx.x];  // wave-uniform
-        sl = t >> 30;
-        bx0 = ((t >> 16) & 0x3fffu) << 2;
-        by0 = (t & 0xffffu) << 2;
-    } else {
-        bx0 = blockIdx.x << (4u - (sl >> 1));
-        by0 = blockIdx.y << (4u - ((sl + 1u) >> 1));
-    }
     // Scene rectangle launches (the ahead-of-time kernels, and scene kernels compiled with -DRTC_SPEC_RECT=1: the few
     // extra argument loads and operations in front of every wave cost the frames of very short waves 6 - 10 % --
     // first_plane, first_patterns -- so kernels of scenes that have no use for it do not carry them): is this one of the
@@ -2925,26 +2917,58 @@ DI void render_body(const RenderArgs& A) {
 #else
     constexpr bool RECT_LAUNCH = false;
 #endif
-    bool fills = false;
-    uint32_t grid_y = blockIdx.y, block_y0 = 0u;
-    if constexpr (RECT_LAUNCH) {
-        if (A.tiles == nullptr) {
-            block_y0 = A.block_y0;
-            if (A.fill_wg_rows != 0u) {
-                const uint32_t j = blockIdx.y / A.fill_period;
-                fills = j < A.fill_wg_rows && blockIdx.y == j * A.fill_period;
-                if (fills) grid_y = j;
-                else grid_y = blockIdx.y - min(A.fill_wg_rows, j + 1u);
+    // A workgroup of the regular grid renders `blocks_y` blocks, one below the other (host: frames whose waves are so
+    // short -- C5: 95 % of 67 M pixels miss the scene's box -- that launching them is what the frame costs)
+    // Compiled in only where the host asks for it (-DRTC_SPEC_BLOCKS_Y=1): the loop's carried state costs other kernels
+    // registers (first_patterns: 6 -> 18 spilled VGPRs, +45 %).
+#if defined(RTC_SPEC_BLOCKS_Y) && RTC_SPEC_BLOCKS_Y
+    const uint32_t blocks_y = A.tiles != nullptr ? 1u : A.blocks_y;
+#else
+    constexpr uint32_t blocks_y = 1u;
+#endif
+    // Where this lane's pixel is.  (These kernels are compiled to the last register of their occupancy, and what is added in
+    // front of color_at decides on which side of a cliff the allocation lands -- reflect_refract's kernel, 102 registers: 21
+    // spilled with the block list's entry fetched by a scalar load, 69 with the same entry fetched by a vector load, 69 with a
+    // clock read at the wave's start.  Hence: a plain load here, and wave times only in the kernels that cut their lists.)
+    struct Where {
+        uint32_t x, yl, sl, grid_y;
+        bool fills;
+    };
+    auto where = [&](uint32_t rep) {
+        Where w;
+        w.sl = Counters::SHARE_LANES ? A.share_log2 : 0u;  // lanes per pixel (log2)
+        w.fills = false;
+        w.grid_y = blockIdx.y;
+        uint32_t bx0, by0;  // pixel origin of this workgroup's block
+        if (A.tiles != nullptr) {
+            const uint32_t t = A.tiles[blockIdx.x];  // wave-uniform: a scalar load
+            if (Counters::SHARE_LANES) w.sl = t >> 30;  // (a kernel without lane sharing is only ever given lists of whole blocks)
+            bx0 = ((t >> 16) & 0x3fffu) << 2;
+            by0 = (t & 0xffffu) << 2;
+        } else {
+            uint32_t block_x0 = 0u, block_y0 = 0u;
+            if constexpr (RECT_LAUNCH) {
+                block_x0 = A.block_x0, block_y0 = A.block_y0;
+                if (A.fill_wg_rows != 0u) {
+                    const uint32_t j = blockIdx.y / A.fill_period;
+                    w.fills = j < A.fill_wg_rows && blockIdx.y == j * A.fill_period;
+                    if (w.fills) w.grid_y = j;
+                    else w.grid_y = blockIdx.y - min(A.fill_wg_rows, j + 1u);
+                }
             }
-            bx0 = (blockIdx.x + A.block_x0) << (4u - (sl >> 1));
-            by0 = (grid_y + block_y0) << (4u - ((sl + 1u) >> 1));
+            bx0 = (blockIdx.x + block_x0) << (4u - (w.sl >> 1));
+            by0 = (w.grid_y * blocks_y + rep + block_y0) << (4u - ((w.sl + 1u) >> 1));
         }
-    }
-    const uint32_t q = lane >> sl;  // q: the pixel's slot in the wave's tile
-    const uint32_t tw_log2 = 3u - (sl >> 1), th_log2 = 3u - ((sl + 1u) >> 1);
-    const uint32_t x = bx0 + ((wave & 1u) << tw_log2) + (q & ((1u << tw_log2) - 1u));
+        const uint32_t q = lane >> w.sl;  // q: the pixel's slot in the wave's tile
+        const uint32_t tw_log2 = 3u - (w.sl >> 1), th_log2 = 3u - ((w.sl + 1u) >> 1);
+        w.x = bx0 + ((wave & 1u) << tw_log2) + (q & ((1u << tw_log2) - 1u));
+        w.yl = by0 + ((wave >> 1) << th_log2) + (q >> tw_log2);
+        return w;
+    };
+    const Where w0 = where(0u);
+    const uint32_t sl = w0.sl;
     Counters cnt = {0u, 0u, sl};
-    const bool timed = Counters::SHARE_LANES && A.tiles != nullptr && A.wave_ticks != nullptr;  // wave-uniform
+    const bool timed = Counters::SHARE_LANES && A.wave_ticks != nullptr;  // wave-uniform
     uint32_t ticks0 = 0u;
     if (timed) ticks0 = (uint32_t)wall_clock64();
 #ifdef RTC_DEBUG_TIMELINE  // development (tools/wave_timeline.py): the frame holds each wave's start / end / place instead of colours
@@ -2960,21 +2984,13 @@ DI void render_body(const RenderArgs& A) {
         if (threadIdx.x == 0) waves_done = 0u;
         __syncthreads();
     }
-    // A workgroup of the regular grid renders `blocks_y` blocks, one below the other (host: frames whose waves are so
-    // short -- C5: 95 % of 67 M pixels miss the scene's box -- that launching them is what the frame costs)
-    // Compiled in only where the host asks for it (-DRTC_SPEC_BLOCKS_Y=1): the loop's carried state costs other kernels
-    // registers (first_patterns: 6 -> 18 spilled VGPRs, +45 %).
-#if defined(RTC_SPEC_BLOCKS_Y) && RTC_SPEC_BLOCKS_Y
-    const uint32_t blocks_y = A.tiles != nullptr ? 1u : A.blocks_y;
-#else
-    constexpr uint32_t blocks_y = 1u;
-#endif
     if constexpr (RECT_LAUNCH) {
-        if (fills) fill_outside(A, grid_y);
+        if (w0.fills) fill_outside(A, w0.grid_y);
     }
     for (uint32_t rep = 0; rep < blocks_y; rep++) {
-    const uint32_t yl = (A.tiles != nullptr ? by0 : (grid_y * blocks_y + rep + block_y0) << (4u - ((sl + 1u) >> 1))) + ((wave >> 1) << th_log2) + (q >> tw_log2);
-    if ((!RECT_LAUNCH || !fills) && x < H.width && yl < A.rows) {
+    const Where w = where(rep);
+    const uint32_t x = w.x, yl = w.yl;
+    if ((!RECT_LAUNCH || !w.fills) && x < H.width && yl < A.rows) {
         // compact local row -> global row of the image
         const uint32_t band = yl / A.band_rows;
         const uint32_t y = (band * A.n_parts + A.part) * A.band_rows + (yl - band * A.band_rows);
@@ -3020,8 +3036,9 @@ DI void render_body(const RenderArgs& A) {
 #endif
         if (cnt.lead()) {
             const bool through = A.progress != nullptr;  // wave-uniform: write-through stores (RenderArgs::progress)
+            const Where ws = where(rep);
             if (A.out_u8 != nullptr) {  // wave-uniform: scale_color on the way out (the arithmetic of quantize_kernel)
-                uint8_t* dst = A.out_u8 + ((size_t)yl * H.width + x) * 3;
+                uint8_t* dst = A.out_u8 + ((size_t)ws.yl * H.width + ws.x) * 3;
                 const uint8_t r = (uint8_t)fmaxf(fminf(col.x * 255.0f, 255.0f), 0.0f), g = (uint8_t)fmaxf(fminf(col.y * 255.0f, 255.0f), 0.0f),
                               b = (uint8_t)fmaxf(fminf(col.z * 255.0f, 255.0f), 0.0f);
                 if (through) {
@@ -3032,7 +3049,7 @@ DI void render_body(const RenderArgs& A) {
                     dst[0] = r, dst[1] = g, dst[2] = b;
                 }
             } else {
-                float* dst = A.out + ((size_t)yl * H.width + x) * 3;
+                float* dst = A.out + ((size_t)ws.yl * H.width + ws.x) * 3;
                 if (through) {
                     __hip_atomic_store(dst, col.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     __hip_atomic_store(dst + 1, col.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -36,14 +36,16 @@ def feedback_env():
     set_(saved)
 
 
-@pytest.mark.parametrize("name,size", [("mesh", (320, 240)), ("mesh", (1024, 768)), ("here_be_dragons", (500, 200))])
+@pytest.mark.parametrize("name,size", [("mesh", (320, 240)), ("mesh", (1024, 768)), ("here_be_dragons", (500, 200)),
+                                       # regular grids (flat worlds, trees without mesh runs): the same 16 x 16 blocks, ordered
+                                       ("glass_and_mirror", (520, 392)), ("soft_shadows", (600, 248)), ("reflect_refract", (648, 328)),
+                                       ("hexagons", (600, 300)), ("first_textures", (512, 256)), ("sphere_grid", (1024, 1024))])
 def test_every_frame_of_a_sequence_equals_the_oracle(feedback_env, name, size):
     world, camera, depth = getattr(scenes, name)(*size)
     exp, exp_rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=THREADS)
     for mode in (None, "0"):  # the library's default (feedback on), and off
         feedback_env(mode)
         r = _renderer(world, camera)  # (switches are read when the context is created)
-        assert r.kernel_name.startswith("render_kernel_spec[tree"), r.kernel_name
         for frame in range(5):
             image = r.render(depth).cpu().numpy()
             st = r.stats()
@@ -54,9 +56,10 @@ def test_every_frame_of_a_sequence_equals_the_oracle(feedback_env, name, size):
         r.close()
 
 
-def test_partitions_refine_their_own_lists(feedback_env):
+@pytest.mark.parametrize("name,size", [("mesh", (640, 480)), ("glass_and_mirror", (640, 480))])
+def test_partitions_refine_their_own_lists(feedback_env, name, size):
     feedback_env(None)
-    world, camera, depth = scenes.mesh(640, 480)
+    world, camera, depth = getattr(scenes, name)(*size)
     exp, exp_rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=THREADS)
     r = _renderer(world, camera)
     n_parts, band = 2, 48
