@@ -273,7 +273,7 @@ struct Policy {
     std::string jit_source, jit_flags;  // RTC_AMD_JIT_SOURCE=<path of rtc_kernel_core.h>, RTC_AMD_JIT_FLAGS="-D... -m..."
     bool jit_print = false, cluster_stats = false, tri_naive = false, block_order = true;
     int tree_waves = 6, reg_levels = 0, blocks_y = 0, block_s = -1, block_s_top = -1;  // (0 / -1: the library's own choice)
-    uint32_t fill_wgs = 0u, cluster_min_run = 0u, cluster_leaf = 0u, feedback_pct = 85u, feedback_down_pct = 40u, feedback_passes = 2u, feedback_interleave_pct = 0u;
+    uint32_t fill_wgs = 0u, cluster_min_run = 0u, cluster_leaf = 0u, feedback_pct = 85u, feedback_down_pct = 40u, feedback_passes = 2u;
     double cluster_gmax = -1.0;
 
     static Policy from_env() {
@@ -311,7 +311,6 @@ struct Policy {
         if (const char* e = RTC_DEV_ENV("RTC_AMD_FEEDBACK_PCT")) p.feedback_pct = std::max(1u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_FEEDBACK_DOWN_PCT")) p.feedback_down_pct = (uint32_t)std::atoi(e);
         if (const char* e = RTC_DEV_ENV("RTC_AMD_FEEDBACK_PASSES")) p.feedback_passes = std::max(1u, (uint32_t)std::atoi(e));
-        if (const char* e = RTC_DEV_ENV("RTC_AMD_FEEDBACK_INTERLEAVE_PCT")) p.feedback_interleave_pct = (uint32_t)std::atoi(e);
         if (const char* e = RTC_DEV_ENV("RTC_AMD_FILL_WGS")) p.fill_wgs = std::max(1u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_CLUSTER_MIN_RUN")) p.cluster_min_run = std::max(3u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_CLUSTER_LEAF")) p.cluster_leaf = std::min(64u, std::max(2u, (uint32_t)std::atoi(e)));
@@ -1613,7 +1612,7 @@ static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t w
 // longest wave.  Which lanes trace a pixel and when changes nothing about its value (tests/test_gpu_fullsize.py compares first
 // and later frames with the oracle).
 static void refine_block_list(const std::vector<uint32_t>& list, const std::vector<uint32_t>& ticks, uint32_t width, uint32_t rows, double wave_slots,
-                              double threshold, double down, double interleave, std::vector<uint32_t>* out) {
+                              double threshold, double down, std::vector<uint32_t>* out) {
     struct Tile {
         uint32_t x0, y0, s;
         uint64_t longest = 0;
@@ -1648,26 +1647,6 @@ static void refine_block_list(const std::vector<uint32_t>& list, const std::vect
     std::vector<uint32_t> order(tiles.size());
     for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return tiles[a].predicted > tiles[b].predicted; });
-    if (interleave > 0.0 && !order.empty()) {
-        // the tiles that cost next to nothing (sky) would all come at the end, where starting their waves is all the chip does:
-        // spread them evenly among the others instead
-        const double mean = total / (4.0 * std::max<size_t>(1, list.size()));
-        size_t head = order.size();
-        while (head > 0 && tiles[order[head - 1]].predicted < interleave * mean) head--;
-        const size_t tail = order.size() - head;
-        if (head > 0 && tail > 0) {
-            std::vector<uint32_t> mixed;
-            mixed.reserve(order.size());
-            size_t t = 0;
-            for (size_t h = 0; h < head; h++) {
-                mixed.push_back(order[h]);
-                const size_t upto = (size_t)((double)(h + 1) * (double)tail / (double)head);
-                while (t < upto && t < tail) mixed.push_back(order[head + t++]);
-            }
-            while (t < tail) mixed.push_back(order[head + t++]);
-            order.swap(mixed);
-        }
-    }
     out->clear();
     for (uint32_t i : order) {
         const Tile& t = tiles[i];
@@ -2201,7 +2180,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             HIP_TRY(hipMemcpy(ticks.data(), bl.d_ticks, ticks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
             hipDeviceProp_t prop;
             HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-            refine_block_list(bl.host, ticks, c->hdr.width, rows, 0.85 * 4.0 * prop.multiProcessorCount * P.tree_waves, 0.01 * P.feedback_pct, 0.01 * P.feedback_down_pct, 0.01 * P.feedback_interleave_pct, &refined);
+            refine_block_list(bl.host, ticks, c->hdr.width, rows, 0.85 * 4.0 * prop.multiProcessorCount * P.tree_waves, 0.01 * P.feedback_pct, 0.01 * P.feedback_down_pct, &refined);
             (void)hipFree(bl.d_ticks);
             bl.d_ticks = nullptr;
             uint32_t* d_new = nullptr;
@@ -2381,7 +2360,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             const double wave_slots = 0.85 * 4.0 * prop.multiProcessorCount * 6.0;
             bl.state = BlockList::REFINED;
             if ((double)longest >= 0.1 * total / wave_slots) {
-                refine_block_list(raster, ticks, c->hdr.width, rows, wave_slots, INFINITY, 0.0, 0.01 * P.feedback_interleave_pct, &ordered);
+                refine_block_list(raster, ticks, c->hdr.width, rows, wave_slots, INFINITY, 0.0, &ordered);
                 if (ordered.size() == bl.n) {
                     HIP_TRY(hipMalloc(&bl.d, bl.n * sizeof(uint32_t)));
                     hipError_t ce = hipMemcpy(bl.d, ordered.data(), bl.n * sizeof(uint32_t), hipMemcpyHostToDevice);
