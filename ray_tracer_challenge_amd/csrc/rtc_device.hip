@@ -265,6 +265,7 @@ struct Policy {
     int clusters = -1;    // RTC_AMD_CLUSTERS: nodes over long triangle runs -- 0 never, 1 always, -1 by frame size
     int share_log2 = -1;  // RTC_AMD_SHARE_LOG2 = 0..3: lanes per pixel (log2) pinned for every frame; -1: by frame size
     int scene_rect = 1;   // RTC_AMD_SCENE_RECT: 0 never launch the scene's rectangle only, 2 whenever there is one, 1 under half the frame
+    bool swizzle = true;         // RTC_AMD_SWIZZLE: a regular grid's blocks permuted within four rows (RenderArgs::swizzle)
     bool grid_feedback = true;   // RTC_AMD_GRID_FEEDBACK: ... and so do the frames of a regular grid: their blocks start longest first
     bool block_feedback = true;  // RTC_AMD_BLOCK_FEEDBACK: a block list's second and later frames go by the first one's wave times (refine_block_list)
     int wavefront = 0;    // RTC_AMD_WAVEFRONT=1: tree worlds are rendered by the level-by-level renderer (rtc_wavefront.h); default: never
@@ -291,6 +292,7 @@ struct Policy {
         p.block_list = flag(std::getenv("RTC_AMD_BLOCK_LIST"), true);
         p.block_feedback = flag(std::getenv("RTC_AMD_BLOCK_FEEDBACK"), true);
         p.grid_feedback = flag(std::getenv("RTC_AMD_GRID_FEEDBACK"), true);
+        p.swizzle = flag(std::getenv("RTC_AMD_SWIZZLE"), true);
         p.quiet = flag(std::getenv("RTC_AMD_QUIET"), false);
         if (const char* e = std::getenv("RTC_AMD_CLUSTERS")) p.clusters = *e ? (e[0] != '0' ? 1 : 0) : -1;
         p.share_log2 = digit(std::getenv("RTC_AMD_SHARE_LOG2"), 0, 3, -1);
@@ -1134,11 +1136,11 @@ struct rtc_ctx_tiles {
 };
 struct BlockList {  // RenderArgs::tiles of one partition (build_block_list), resident on the device
     uint32_t* d = nullptr;
-    size_t n = 0;
+    size_t n = 0, n_listed = 0;  // (n_listed: a grid's list leaves the padding out)
     // feedback (refine_block_list): the list as built, where its first launch leaves its waves' running times, and how far it is
     std::vector<uint32_t> host;
     uint32_t* d_ticks = nullptr;  // [4 n] wave times -- or, for kernels that do not time their waves, [4 n] uint4 work counts (a copy of block_counts)
-    bool counts = false;
+    bool counts = false, swizzled = false;
     enum { FRESH, TIMED, REFINED } state = FRESH;
     uint32_t passes = 0;  // refinements so far
 };
@@ -1624,6 +1626,7 @@ static void refine_block_list(const std::vector<uint32_t>& list, const std::vect
     double total = 0.0;
     for (size_t b = 0; b < list.size(); b++) {
         const uint32_t t = list[b], x0 = ((t >> 16) & 0x3fffu) << 2, y0 = (t & 0xffffu) << 2;
+        if (x0 >= width || y0 >= rows) continue;  // (a padded grid's blocks outside the image)
         int32_t& slot = index[(size_t)(y0 / 16u) * tw + x0 / 16u];
         if (slot < 0) {
             slot = (int32_t)tiles.size();
@@ -2314,6 +2317,10 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         }
         grid.y += fill_wg_rows;
     }
+    // the plain regular grid: blocks permuted within four rows (RenderArgs::swizzle), the grid padded to what that needs --
+    // workgroups of the padding find no pixel of theirs inside the image
+    const bool swizzle = P.swizzle && d_tiles == nullptr && rows > 0u && !rect_launch && blocks_y == 1u;
+    if (swizzle) grid = dim3((grid.x + 1u) & ~1u, (grid.y + 3u) & ~3u);
     // A regular grid's frames after the first: the same 16 x 16 blocks, started in the order of their longest wave in the frame
     // before (refine_block_list: a list of one lane per pixel throughout).  Where the grid is the plain one -- one block per
     // workgroup, no scene rectangle, nobody waiting for rows in image order (rtc_render_ex's progress words) -- and the frame
@@ -2351,7 +2358,15 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             (void)hipFree(bl.d_ticks);
             bl.d_ticks = nullptr;
             for (uint32_t by = 0; by < grid.y; by++)
-                for (uint32_t bx = 0; bx < grid.x; bx++) raster[(size_t)by * grid.x + bx] = (bx * 4u) << 16 | (by * 4u);
+                for (uint32_t bx = 0; bx < grid.x; bx++) {  // the block workgroup (bx, by) rendered: the kernel's permutation
+                    uint32_t gx = bx, gy = by;
+                    if (bl.swizzled) {
+                        const uint32_t j = (by & 3u) * grid.x + bx, r = j & 7u;
+                        gy = (by & ~3u) + (r >> 1);
+                        gx = 2u * (j >> 3) + (r & 1u);
+                    }
+                    raster[(size_t)by * grid.x + bx] = (gx * 4u) << 16 | (gy * 4u);
+                }
             uint64_t longest = 0;
             double total = 0.0;
             for (uint32_t t : ticks) longest = std::max<uint64_t>(longest, t), total += t;
@@ -2361,9 +2376,10 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             bl.state = BlockList::REFINED;
             if ((double)longest >= 0.1 * total / wave_slots) {
                 refine_block_list(raster, ticks, c->hdr.width, rows, wave_slots, INFINITY, 0.0, &ordered);
-                if (ordered.size() == bl.n) {
-                    HIP_TRY(hipMalloc(&bl.d, bl.n * sizeof(uint32_t)));
-                    hipError_t ce = hipMemcpy(bl.d, ordered.data(), bl.n * sizeof(uint32_t), hipMemcpyHostToDevice);
+                if (!ordered.empty() && ordered.size() <= bl.n) {
+                    bl.n_listed = ordered.size();
+                    HIP_TRY(hipMalloc(&bl.d, bl.n_listed * sizeof(uint32_t)));
+                    hipError_t ce = hipMemcpy(bl.d, ordered.data(), bl.n_listed * sizeof(uint32_t), hipMemcpyHostToDevice);
                     if (ce != hipSuccess) {
                         (void)hipFree(bl.d);
                         bl.d = nullptr;
@@ -2375,6 +2391,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         }
         if (bl.state == BlockList::FRESH && bl.n == (size_t)grid.x * grid.y) {
             bl.counts = !(spec_fn && c->spec_shares);
+            bl.swizzled = swizzle;
             HIP_TRY(hipMalloc(&bl.d_ticks, 4u * bl.n * (bl.counts ? sizeof(uint4) : sizeof(uint32_t))));
             if (bl.counts) {
                 copy_counts_to = bl.d_ticks;  // (after the launch, on its stream)
@@ -2385,7 +2402,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             bl.state = BlockList::TIMED;
         } else if (bl.state == BlockList::REFINED && bl.d != nullptr) {
             d_tiles = bl.d;
-            grid = dim3((uint32_t)bl.n, 1);
+            grid = dim3((uint32_t)bl.n_listed, 1);
         }
     }
     const size_t n_blocks = (size_t)grid.x * grid.y * 4;  // partial counts: one per wave
@@ -2400,6 +2417,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     if (plan && plan->d_done && rows > 0u && d_tiles == nullptr && !rect_launch && blocks_y == 1u) {
         const uint32_t want = std::max(1u, std::min(plan->want_chunks, PROGRESS_MAX_CHUNKS));
         chunk_block_rows = (grid.y + want - 1u) / want;
+        if (swizzle) chunk_block_rows = (chunk_block_rows + 3u) & ~3u;  // (block rows finish four at a time)
         n_chunks = (grid.y + chunk_block_rows - 1u) / chunk_block_rows;
         const size_t words = ((size_t)grid.y + n_chunks) * PROGRESS_STRIDE;
         if (words > c->progress_cap) {
@@ -2438,6 +2456,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     a.tiles = d_tiles;
     a.wave_ticks = d_ticks;
     a.blocks_y = blocks_y;
+    a.swizzle = (swizzle && d_tiles == nullptr) ? 1u : 0u;
     a.block_x0 = block_x0;
     a.block_y0 = block_y0;
     a.fill_wg_rows = fill_wg_rows, a.fill_rows = fill_rows, a.fill_period = fill_period;

@@ -2849,6 +2849,15 @@ struct RenderArgs {
     // and cuts the NEXT frames' list by.  (The other kernels' lists are ordered by the waves' work counts, block_counts.)
     uint32_t* wave_ticks;
     uint32_t blocks_y;  // regular grid: blocks rendered by one workgroup, stacked vertically (>= 1)
+    // Regular grid, not 0: which block a workgroup renders is not (blockIdx.x, blockIdx.y) but a permutation of it within four
+    // rows of the grid (an even number of columns, a multiple of four rows: the host pads).  Workgroups are started in index
+    // order and dealt to the eight XCDs round robin; in image order XCD r gets every eighth block of a row, and all eight sweep
+    // the same few rows at the same time.  Here workgroup j of a group of four rows renders row j mod 8 / 2, column 2 (j / 8) +
+    // j mod 2: an XCD works along half a row of its own.  Measured as fixed block lists first (profiles/r03_ab_block_orders.txt:
+    // first_textures 1.07 -> 0.92 ms, reflect_refract 0.98 -> 0.92, hexagons 0.50 -> 0.475, C3 0.897 -> 0.870; eight bands or 4 x 2
+    // regions, one per XCD: 1.9 and 2.4 ms -- the XCDs' shares must be alike); rows still finish four at a time from the
+    // top, which is all rtc_render_ex's progress words need.
+    uint32_t swizzle;
     // regular grid: the launch covers the blocks from (block_x0, block_y0) on -- of a frame whose scene can only be seen
     // inside a rectangle of pixel columns [fill_x0, fill_x1) x local rows [fill_y0, fill_y1) only that rectangle is rendered
     // (rtc_device.hip: scene rectangle); fill_wg_rows rows of the grid, spread evenly among the rendering ones, are
@@ -2956,8 +2965,14 @@ DI void render_body(const RenderArgs& A) {
                     else w.grid_y = blockIdx.y - min(A.fill_wg_rows, j + 1u);
                 }
             }
-            bx0 = (blockIdx.x + block_x0) << (4u - (w.sl >> 1));
-            by0 = (w.grid_y * blocks_y + rep + block_y0) << (4u - ((w.sl + 1u) >> 1));
+            uint32_t gx = blockIdx.x, gy = w.grid_y;
+            if (A.swizzle != 0u) {  // (RenderArgs::swizzle; never together with a rectangle, fills or several blocks per workgroup)
+                const uint32_t j = (gy & 3u) * gridDim.x + gx, r = j & 7u;
+                gy = (gy & ~3u) + (r >> 1);
+                gx = 2u * (j >> 3) + (r & 1u);
+            }
+            bx0 = (gx + block_x0) << (4u - (w.sl >> 1));
+            by0 = (gy * blocks_y + rep + block_y0) << (4u - ((w.sl + 1u) >> 1));
         }
         const uint32_t q = lane >> w.sl;  // q: the pixel's slot in the wave's tile
         const uint32_t tw_log2 = 3u - (w.sl >> 1), th_log2 = 3u - ((w.sl + 1u) >> 1);
