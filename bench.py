@@ -384,8 +384,9 @@ def main(argv=None):
                            world_size + extra_parts, (", rank 0 renders %d of them; RCCL gather of f32 rows to rank 0"
                                                       % (extra_parts + 1)) if world_size > 1 else "")},
             "tested_rays_per_s": round((rays - culled) / (elapsed / args.steps), 1),
-            "schedule": {"blocks": "16x16-pixel blocks; first frame of a scene in image order, later frames longest first by the "
-                                   "work counts (rays, shade points) of the frame before -- every frame traces every ray",
+            "schedule": {"blocks": "16x16-pixel blocks; first frame of a scene in image order permuted within four block rows (each XCD "
+                                   "along half a row), later frames longest first by the work counts (rays, shade points) of the frame "
+                                   "before -- every frame traces every ray",
                          "first_frame_kernel_ms": round(first["kernel_ms"], 4) if first else None,
                          "off_switch": "RTC_AMD_BLOCK_FEEDBACK=0"},
             "roofline": valu_roofline(pmc, st["kernel_ms"], renderer),
