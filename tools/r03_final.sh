@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 3, final evidence set in one GPU call: profiles (kernel trace + PMC) of eight scenes, timelines, configuration table, whole-frame verification, bench line
+TAG=${1:-r03}
+mkdir -p gpurun_out/$TAG
+bash profiles/run_all.sh $TAG > gpurun_out/$TAG/run_all.log 2>&1
+for s in c3 c4 c5 hexagons mesh dragons reflect_refract first_textures; do python profiles/summarize.py ${TAG}_$s > gpurun_out/$TAG/summary_$s.json 2> gpurun_out/$TAG/summary_$s.err || echo "summarize $s failed"; done
+cp profiles/${TAG}_* gpurun_out/$TAG/   # (summarize.py writes beside itself; only gpurun_out/ travels back)
+echo profiles done
+for s in "reflect_refract 4096 2048" "first_textures 4096 2048" "mesh 2048 2048" "soft_shadows 4096 4096" "glass_and_mirror 4096 4096" "here_be_dragons 4000 1600"; do set -- $s
+  python tools/wave_timeline.py --scene $1 --size $2 --height $3 2>&1 | grep -v amdgpu > gpurun_out/$TAG/timeline_$1.txt; done
+echo timelines done
+python tools/time_configs.py 2>&1 | grep -v amdgpu > gpurun_out/$TAG/time_configs.txt
+echo table done
+python bench.py > gpurun_out/$TAG/bench_line.json 2> gpurun_out/$TAG/bench.err
+tail -c 300 gpurun_out/$TAG/bench_line.json
+python tools/verify_configs.py 2>&1 | grep -v amdgpu > gpurun_out/$TAG/verify_configs.txt
+tail -3 gpurun_out/$TAG/verify_configs.txt
