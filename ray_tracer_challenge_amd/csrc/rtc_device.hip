@@ -14,6 +14,8 @@
 
 #include <algorithm>
 #include <array>
+#include <functional>
+#include <queue>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1659,6 +1661,21 @@ static void refine_block_list(const std::vector<uint32_t>& list, const std::vect
     }
 }
 
+// How long a frame takes whose blocks start in the given order: every block goes to the workgroup slot that is free first and
+// keeps it for as long as its longest wave ran (what the dispatcher does, with costs in whatever unit `cost` is in).
+static double simulate_dispatch(const std::vector<uint32_t>& cost, size_t slots) {
+    std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+    for (size_t i = 0; i < std::max<size_t>(1, slots); i++) free_at.push(0.0);
+    double end = 0.0;
+    for (uint32_t c : cost) {
+        const double t = free_at.top() + (double)c;
+        free_at.pop();
+        free_at.push(t);
+        end = std::max(end, t);
+    }
+    return end;
+}
+
 // The policy wanted a scene-compiled kernel and hiprtc did not deliver one.  RTC_AMD_SPECIALIZE=1: an error.  Default
 // policy: the ahead-of-time kernel renders the same image -- several times slower on area-light scenes -- so say so:
 // rtc_ctx_jit_status(), rtc_stats.flags, one line on stderr per process.
@@ -2144,8 +2161,12 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     const uint32_t* d_tiles = nullptr;
     uint32_t* d_ticks = nullptr;
     void* copy_counts_to = nullptr;
-    if (spec_fn && c->spec_shares && !c->heavy_tiles.empty() && c->hdr.light_kind == RTC_LIGHT_POINT && P.share_log2 < 0 &&
-        c->hdr.width <= 65532u && rows <= 262140u && rows > 0u) {
+    const bool mesh_list = spec_fn && c->spec_shares && !c->heavy_tiles.empty() && c->hdr.light_kind == RTC_LIGHT_POINT;
+    // ... and frames that share an area light's cells between a pixel's lanes (small frames: choose_share_log2), when there is a
+    // frame before to go by: the list starts with the frame's one lane count everywhere, and the feedback gives the tiles in the
+    // penumbra more lanes, the lit and the empty ones fewer (refine_block_list).  Not for rtc_render_ex, whose rows leave in order.
+    const bool area_list = spec_fn && c->spec_shares && c->hdr.light_kind == RTC_LIGHT_RECT && share_log2 != 0u && P.block_feedback && plan == nullptr;
+    if ((mesh_list || area_list) && P.share_log2 < 0 && c->hdr.width <= 65532u && rows <= 262140u && rows > 0u) {
         // one list per partition, built on first use and kept until the scene changes: rtc_render_ex renders a frame as
         // several partitions of one context, frame after frame (a single cached list meant a device synchronisation, a
         // rebuild and a blocking copy per chunk launch)
@@ -2162,7 +2183,16 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             }
             const rtc_ctx_tiles T = {c->heavy_tiles.data(), c->heavy_w, c->heavy_h};
             std::vector<uint32_t> host;
-            build_block_list(P, T, c->hdr.width, share_log2, rows, q, &host);
+            if (mesh_list) {
+                build_block_list(P, T, c->hdr.width, share_log2, rows, q, &host);
+            } else {  // every tile with the frame's lane count, in image order
+                const uint32_t hbw = 16u >> (share_log2 >> 1), hbh = 16u >> ((share_log2 + 1u) >> 1);
+                for (uint32_t y0 = 0; y0 < rows; y0 += 16u)
+                    for (uint32_t x0 = 0; x0 < c->hdr.width; x0 += 16u)
+                        for (uint32_t dy = 0; dy < 16u && y0 + dy < rows; dy += hbh)
+                            for (uint32_t dx = 0; dx < 16u && x0 + dx < c->hdr.width; dx += hbw)
+                                host.push_back(share_log2 << 30 | ((x0 + dx) / 4u) << 16 | ((y0 + dy) / 4u));
+            }
             BlockList bl;
             bl.n = host.size();
             if (P.block_feedback) bl.host = host;
@@ -2374,7 +2404,19 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             HIP_TRY(hipGetDeviceProperties(&prop, c->device));
             const double wave_slots = 0.85 * 4.0 * prop.multiProcessorCount * 6.0;
             bl.state = BlockList::REFINED;
-            if ((double)longest >= 0.1 * total / wave_slots) {
+            // is the order worth a list?  Both orders through a model of the dispatcher, with what the blocks counted as their
+            // cost: the list is taken when it ends the frame at least 3 % earlier (reflect_refract, first_textures, hexagons:
+            // yes; the frames of short, even waves: no -- there the list's scalar load and the lost neighbourhood of blocks
+            // in flight cost a few per cent, profiles/r03_time_configs.txt)
+            std::vector<uint32_t> block_cost(bl.n), sorted_cost;
+            for (size_t b = 0; b < bl.n; b++) block_cost[b] = std::max(std::max(ticks[4 * b], ticks[4 * b + 1]), std::max(ticks[4 * b + 2], ticks[4 * b + 3]));
+            sorted_cost = block_cost;
+            std::sort(sorted_cost.begin(), sorted_cost.end(), std::greater<uint32_t>());
+            const size_t wg_slots = (size_t)(wave_slots / 4.0);
+            const double in_order = simulate_dispatch(block_cost, wg_slots), longest_first = simulate_dispatch(sorted_cost, wg_slots);
+            if (P.jit_print) std::fprintf(stderr, "librtc_amd: grid of %zu blocks: modelled frame %.4g in image order, %.4g longest first\n", bl.n, in_order, longest_first);
+            (void)longest;
+            if (longest_first < 0.97 * in_order) {
                 refine_block_list(raster, ticks, c->hdr.width, rows, wave_slots, INFINITY, 0.0, &ordered);
                 if (!ordered.empty() && ordered.size() <= bl.n) {
                     bl.n_listed = ordered.size();

@@ -39,7 +39,9 @@ def feedback_env():
 @pytest.mark.parametrize("name,size", [("mesh", (320, 240)), ("mesh", (1024, 768)), ("here_be_dragons", (500, 200)),
                                        # regular grids (flat worlds, trees without mesh runs): the same 16 x 16 blocks, ordered
                                        ("glass_and_mirror", (520, 392)), ("soft_shadows", (600, 248)), ("reflect_refract", (648, 328)),
-                                       ("hexagons", (600, 300)), ("first_textures", (512, 256)), ("sphere_grid", (1024, 1024))])
+                                       ("hexagons", (600, 300)), ("first_textures", (512, 256)), ("sphere_grid", (1024, 1024)),
+                                       # frames that share an area light's cells between lanes: a list of one lane count, re-cut by the feedback
+                                       ("soft_shadows", (1000, 400)), ("patterns_medley", (256, 192)), ("groups_medley", (256, 192))])
 def test_every_frame_of_a_sequence_equals_the_oracle(feedback_env, name, size):
     world, camera, depth = getattr(scenes, name)(*size)
     exp, exp_rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=THREADS)

@@ -1,5 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out/r03z
-for sc in "soft_shadows 4096 4096" "glass_and_mirror 4096 4096" "first_scene 4096 2048"; do set -- $sc
-timeout -k 10 300 python tools/ab_env.py --scene $1 --size $2 --height $3 --steps 10 --rounds 2 "raster|RTC_AMD_GRID_FEEDBACK=0|RTC_AMD_SWIZZLE=0" "blocks_y 2|RTC_AMD_GRID_FEEDBACK=0|RTC_AMD_BLOCKS_Y=2" "blocks_y 4|RTC_AMD_GRID_FEEDBACK=0|RTC_AMD_BLOCKS_Y=4" "blocks_y 1 compiled in|RTC_AMD_GRID_FEEDBACK=0|RTC_AMD_BLOCKS_Y=1" 2>&1 | grep -v amdgpu | tee -a gpurun_out/r03z/ab9.txt || exit 1
+for sc in "soft_shadows 1000 400" "soft_shadows 512 512" "soft_shadows 1024 1024" "soft_shadows 1536 1536" "soft_shadows 2048 2048" "patterns_medley 1024 1024"; do set -- $sc
+timeout -k 10 300 python tools/ab_env.py --scene $1 --size $2 --height $3 --steps 10 --rounds 2 "default" "no feedback|RTC_AMD_BLOCK_FEEDBACK=0" 2>&1 | grep -v amdgpu | tee -a gpurun_out/r03z/ab10.txt || exit 1
 done
