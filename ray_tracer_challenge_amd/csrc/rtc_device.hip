@@ -276,7 +276,7 @@ struct Policy {
     std::string jit_source, jit_flags;  // RTC_AMD_JIT_SOURCE=<path of rtc_kernel_core.h>, RTC_AMD_JIT_FLAGS="-D... -m..."
     bool jit_print = false, cluster_stats = false, tri_naive = false, block_order = true;
     int tree_waves = 6, reg_levels = 0, blocks_y = 0, block_s = -1, block_s_top = -1;  // (0 / -1: the library's own choice)
-    uint32_t fill_wgs = 0u, cluster_min_run = 0u, cluster_leaf = 0u, feedback_pct = 85u, feedback_down_pct = 40u, feedback_passes = 2u;
+    uint32_t fill_wgs = 0u, cluster_min_run = 0u, cluster_leaf = 0u, area_share_waves = 0u, feedback_pct = 85u, feedback_down_pct = 40u, feedback_passes = 2u;
     double cluster_gmax = -1.0;
 
     static Policy from_env() {
@@ -315,6 +315,7 @@ struct Policy {
         if (const char* e = RTC_DEV_ENV("RTC_AMD_FEEDBACK_PCT")) p.feedback_pct = std::max(1u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_FEEDBACK_DOWN_PCT")) p.feedback_down_pct = (uint32_t)std::atoi(e);
         if (const char* e = RTC_DEV_ENV("RTC_AMD_FEEDBACK_PASSES")) p.feedback_passes = std::max(1u, (uint32_t)std::atoi(e));
+        if (const char* e = RTC_DEV_ENV("RTC_AMD_AREA_SHARE_WAVES")) p.area_share_waves = (uint32_t)std::atoi(e);
         if (const char* e = RTC_DEV_ENV("RTC_AMD_FILL_WGS")) p.fill_wgs = std::max(1u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_CLUSTER_MIN_RUN")) p.cluster_min_run = std::max(3u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_CLUSTER_LEAF")) p.cluster_leaf = std::min(64u, std::max(2u, (uint32_t)std::atoi(e)));
@@ -330,7 +331,7 @@ struct Policy {
 // runs of leaves a divided mesh leaves at every level (for_each_leaf_shared) -- there a frame's time is that of its
 // slowest wave, whatever the frame's size.  RTC_AMD_SHARE_LOG2=0..3 overrides.
 static uint32_t choose_share_log2_runs(uint64_t waves) { return waves <= 12000u ? 3u : waves <= 40000u ? 2u : 1u; }
-static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows, const Policy& P) {
+static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows, const Policy& P, bool lists = true) {
     const bool area = hdr.light_kind == RTC_LIGHT_RECT && hdr.u_steps * hdr.v_steps >= 8;
     const bool runs = hdr.n_trav != 0u && hdr.max_leaf_run >= 16u && !area;
     if (!area && !runs) return 0u;
@@ -344,7 +345,10 @@ static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows, const Poli
     // 1000 x 400 (6 k) - / 0.193 / 0.134 / 0.145; 700^2 (8 k) 0.396 / 0.242 / 0.158 / 0.130; 1024^2 (16 k) 0.317 / 0.204 / 0.150 / -;
     // 1536^2 (37 k) 0.346 / 0.248 / 0.308 / 0.49; 2048^2 (66 k) 0.366 / 0.38 / 0.50 / 0.81: a frame's time is its throughput or
     // its longest wave, whichever is longer, and a wave of 64 pixels x 100 samples is long
-    return waves < 6144u ? 3u : waves < 24000u ? 2u : waves < 50000u ? 1u : 0u;
+    // (`lists`: the frame's lane count is only where the feedback starts from -- rtc_device.hip refine_block_list cuts it per tile
+    // from the second frame on, which pays up to larger frames: 2048^2 0.288 -> 0.250 ms, 3072^2 0.511 -> 0.525)
+    const uint32_t one_lane_from = P.area_share_waves ? P.area_share_waves : (lists && P.block_feedback) ? 100000u : 50000u;
+    return waves < 6144u ? 3u : waves < 24000u ? 2u : waves < one_lane_from ? 1u : 0u;
 }
 
 // An internal bounding-volume hierarchy for FLAT worlds (World.objects without GroupShapes) of many bounded objects:
@@ -2141,7 +2145,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         rtc_status dst = deep_kernel(c, depth, &spec_fn);
         if (dst != RTC_OK) return dst;
     }
-    const uint32_t share_log2 = (spec_fn && c->spec_shares) ? choose_share_log2(c->hdr, rows, P) : 0u;  // only kernels compiled for it share lanes
+    const uint32_t share_log2 = (spec_fn && c->spec_shares) ? choose_share_log2(c->hdr, rows, P, plan == nullptr) : 0u;  // only kernels compiled for it share lanes
     const uint32_t bw = 16u >> (share_log2 >> 1), bh = 16u >> ((share_log2 + 1u) >> 1);  // pixels per workgroup (2x2 wave tiles)
     dim3 grid((c->hdr.width + bw - 1) / bw, (rows + bh - 1) / bh), block(256);
     // Frames of very many very short waves: several blocks per workgroup (RTC_AMD_BLOCKS_Y=1..8 overrides)
