@@ -29,8 +29,12 @@ def test_one_gpu_line_and_self_launched_two_rank_line_agree():
     two = _bench(["--gpus", "2", "--backend", "gloo", "--size", "512", "--steps", "3", "--warmup", "1"])
     assert two["n_gpus"] == 2 and two["steps"] == 3 and two["value"] > 0 and two["ms_per_step"] > 0
     # the job is one image whatever N is: same rays, same shaded hits, same pixels
-    for key in ("rays_per_frame", "shaded_hits_per_frame", "pixels_per_frame", "shadow_rays_resolved_by_light_cone_cull"):
+    for key in ("rays_per_frame", "shaded_hits_per_frame", "pixels_per_frame"):
         assert two["config"][key] == one["config"][key], key
+    # (how many of those rays the light-cone cull answered is decided per WAVE -- a vote over its 64 lanes -- and which pixels
+    # share a wave differs between the two runs: their block lists are cut by their own frames' wave times)
+    a, b = one["config"]["shadow_rays_resolved_by_light_cone_cull"], two["config"]["shadow_rays_resolved_by_light_cone_cull"]
+    assert abs(a - b) <= 0.01 * a, (a, b)
     assert two["parity_check"]["rows_checked_bit_exact_vs_oracle"]  # rows of the GATHERED frame against the oracle
     mg = two["multi_gpu"]
     assert mg["calibration"]["render_ms_even_share"] > 0 and mg["calibration"]["gather_ms_even_share_unoverlapped"] > 0
