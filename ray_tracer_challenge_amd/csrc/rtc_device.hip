@@ -1213,6 +1213,15 @@ struct rtc_ctx {
     uint64_t last_pixels = 0;
 };
 
+// every block list of the context, with what its feedback holds (the caller knows that no launch is reading them)
+static void drop_block_lists(rtc_ctx* c) {
+    for (auto& bl : c->block_lists) {
+        if (bl.second.d) (void)hipFree(bl.second.d);
+        if (bl.second.d_ticks) (void)hipFree(bl.second.d_ticks);
+    }
+    c->block_lists.clear();
+}
+
 // ============================================================================
 //  Scene-specialised kernels (hiprtc)
 //
@@ -1490,8 +1499,7 @@ void rtc_ctx_destroy(rtc_ctx* c) {
     if (c->d_total) (void)hipFree(c->d_total);
     if (c->d_ppm_rows) (void)hipFree(c->d_ppm_rows);
     if (c->d_ppm_bits) (void)hipFree(c->d_ppm_bits);
-    for (auto& bl : c->block_lists)
-        if (bl.second.d) (void)hipFree(bl.second.d);
+    drop_block_lists(c);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -1756,11 +1764,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     c->has_scene = true;
     c->soa_host = soa;
     c->texels_host = texels;
-    for (auto& bl : c->block_lists) {  // (nothing is in flight any more: the synchronisation above)
-        if (bl.second.d) (void)hipFree(bl.second.d);
-        if (bl.second.d_ticks) (void)hipFree(bl.second.d_ticks);
-    }
-    c->block_lists.clear();
+    drop_block_lists(c);  // (nothing is in flight any more: the synchronisation above)
     c->deep_fn.clear();
     c->spec_defs.clear();
     project_heavy_boxes(P, heavy_boxes, camera, &c->heavy_tiles, &c->heavy_w, &c->heavy_h);
@@ -2179,11 +2183,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         if (it == c->block_lists.end()) {
             if (c->block_lists.size() >= 256u) {  // a caller cycling through partitions without end: start over (nothing may be in flight)
                 HIP_TRY(hipDeviceSynchronize());
-                for (auto& bl : c->block_lists) {
-                    if (bl.second.d) (void)hipFree(bl.second.d);
-                    if (bl.second.d_ticks) (void)hipFree(bl.second.d_ticks);
-                }
-                c->block_lists.clear();
+                drop_block_lists(c);
             }
             const rtc_ctx_tiles T = {c->heavy_tiles.data(), c->heavy_w, c->heavy_h};
             std::vector<uint32_t> host;
@@ -2366,11 +2366,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         if (it == c->block_lists.end()) {
             if (c->block_lists.size() >= 256u) {
                 HIP_TRY(hipDeviceSynchronize());
-                for (auto& bl : c->block_lists) {
-                    if (bl.second.d) (void)hipFree(bl.second.d);
-                    if (bl.second.d_ticks) (void)hipFree(bl.second.d_ticks);
-                }
-                c->block_lists.clear();
+                drop_block_lists(c);
             }
             BlockList bl;
             bl.n = (size_t)grid.x * grid.y;
