@@ -14,26 +14,33 @@ CASES = [("C1 soft_shadows 1000x400", "soft_shadows", (1000, 400)), ("C2 single_
          ("grouped_grid 4096^2", "grouped_grid", (4096, 4096)), ("mesh 2048^2", "mesh", (2048, 2048)),
          ("mesh 512x384", "mesh", (512, 384)), ("here_be_dragons 1000x400 (17.9 k triangles)", "here_be_dragons", (1000, 400)),
          ("here_be_dragons 4000x1600", "here_be_dragons", (4000, 1600))]
-def timed(world, camera, depth):
-    r = Renderer(world, camera, device=0); out = r.alloc()
-    for _ in range(10): r.render(depth, out=out)   # (ten warm-up launches: after a run of tiny kernels the clocks need them -- with two,
-    r.stats()                                       #  C3 read 0.917 ms where bench.py on the same box measured 0.826)
-    for _ in range(10): r.render(depth, out=out)
-    st = r.stats()
-    name = r.kernel_name
-    r.close()
-    return st, name
+def make(world, camera, feedback):
+    if feedback: os.environ.pop("RTC_AMD_BLOCK_FEEDBACK", None)
+    else: os.environ["RTC_AMD_BLOCK_FEEDBACK"] = "0"   # (switches are read when a context is created)
+    r = Renderer(world, camera, device=0)
+    os.environ.pop("RTC_AMD_BLOCK_FEEDBACK", None)
+    return r
 
 
 print("| scene | kernel | kernel ms (frames scheduled by the frame before) | kernel ms (every frame like the first: RTC_AMD_BLOCK_FEEDBACK=0) | rays per frame | Grays/s | Gpixel/s |")
 print("|---|---|---|---|---|---|---|")
 for label, name, size in CASES:
     world, camera, depth = getattr(scenes, name)(*size)
-    os.environ.pop("RTC_AMD_BLOCK_FEEDBACK", None)
-    st, kernel = timed(world, camera, depth)
-    os.environ["RTC_AMD_BLOCK_FEEDBACK"] = "0"   # (switches are read when a context is created)
-    st0, _ = timed(world, camera, depth)
-    os.environ.pop("RTC_AMD_BLOCK_FEEDBACK", None)
-    assert st0["rays"] == st["rays"]
-    print("| %s | %s | %.3f | %.3f | %d | %.1f | %.2f |" % (label, kernel, st["kernel_ms"], st0["kernel_ms"], st["rays"], st["rays"] / st["kernel_ms"] / 1e6,
-                                                         st["pixels"] / st["kernel_ms"] / 1e6), flush=True)
+    # both contexts side by side, their measurements interleaved (one after the other, the second read 2 - 4 % faster on
+    # scenes where both run the very same launches: clocks), ten warm-up launches each, the median of five rounds of ten
+    rs = [make(world, camera, True), make(world, camera, False)]
+    outs = [r.alloc() for r in rs]
+    for r, out in zip(rs, outs):
+        for _ in range(10): r.render(depth, out=out)
+        r.stats()
+    ms = [[], []]
+    for _ in range(5):
+        for k in (0, 1):
+            for _ in range(10): rs[k].render(depth, out=outs[k])
+            st = rs[k].stats()
+            ms[k].append(st["kernel_ms"])
+            last = st
+    kernel = rs[0].kernel_name
+    for r in rs: r.close()
+    a, b = sorted(ms[0])[2], sorted(ms[1])[2]
+    print("| %s | %s | %.3f | %.3f | %d | %.1f | %.2f |" % (label, kernel, a, b, last["rays"], last["rays"] / a / 1e6, last["pixels"] / a / 1e6), flush=True)
