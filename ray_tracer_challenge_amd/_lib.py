@@ -178,7 +178,11 @@ EXTRA = {"rtc_powf_host": (None, [FP, FP, C.c_uint32, FP]),
          # 1 in librtc_amd_dev.so (built with -DRTC_DEV_SWITCHES), 0 in the library that ships
          "rtc_dev_switches": (C.c_int32, []),
          # the level-by-level renderer's counters after a context's last frame (tools / tests)
-         "rtc_ctx_wavefront_counters": (C.c_uint32, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32])}
+         "rtc_ctx_wavefront_counters": (C.c_uint32, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]),
+         # the block-list feedback's two host functions as rtc_ctx_render uses them (tests/test_block_lists.py)
+         "rtc_diag_refine_block_list": (C.c_uint32, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
+                                                     C.c_double, C.c_double, C.POINTER(C.c_uint32), C.c_uint32]),
+         "rtc_diag_simulate_dispatch": (C.c_double, [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32])}
 
 _lib = None
 _loaded = {}  # path -> CDLL

@@ -2563,6 +2563,19 @@ rtc_status rtc::ctx_collect(rtc_ctx* c, uint32_t n_slots, rtc_stats* out) {
 
 extern "C" {
 
+// Diagnostics (not in rtc.h; tests/test_block_lists.py, no device needed): refine_block_list and simulate_dispatch as
+// rtc_ctx_render uses them.  -> the number of blocks of the new list (its first min(that, cap) are written to `out`).
+uint32_t rtc_diag_refine_block_list(const uint32_t* list, const uint32_t* ticks, uint32_t n, uint32_t width, uint32_t rows, double wave_slots,
+                                    double threshold, double down, uint32_t* out, uint32_t cap) {
+    std::vector<uint32_t> l(list, list + n), t(ticks, ticks + 4u * (size_t)n), refined;
+    refine_block_list(l, t, width, rows, wave_slots, threshold, down, &refined);
+    for (size_t i = 0; i < refined.size() && i < cap; i++) out[i] = refined[i];
+    return (uint32_t)refined.size();
+}
+double rtc_diag_simulate_dispatch(const uint32_t* cost, uint32_t n, uint32_t slots) {
+    return simulate_dispatch(std::vector<uint32_t>(cost, cost + n), slots);
+}
+
 rtc_status rtc_ctx_render(rtc_ctx* c, int32_t depth, const rtc_partition* part, void* d_out_rgb, void* stream) {
     return rtc::ctx_render_slot(c, depth, part, d_out_rgb, stream, 0u);
 }
