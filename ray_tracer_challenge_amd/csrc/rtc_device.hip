@@ -1688,6 +1688,97 @@ static double simulate_dispatch(const std::vector<uint32_t>& cost, size_t slots)
     return end;
 }
 
+// A block list's first launch has left its waves' times (BlockList::TIMED): the list of this and every later frame is made from
+// them (refine_block_list); feedback_passes times over.
+static rtc_status recut_block_list(rtc_ctx* c, BlockList& bl, uint32_t rows) {
+    const Policy& P = c->policy;
+    HIP_TRY(hipDeviceSynchronize());  // (once per scene, partition and pass; the launch may be on any stream)
+    std::vector<uint32_t> ticks(4u * bl.n), refined;
+    HIP_TRY(hipMemcpy(ticks.data(), bl.d_ticks, ticks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    refine_block_list(bl.host, ticks, c->hdr.width, rows, 0.85 * 4.0 * prop.multiProcessorCount * P.tree_waves, 0.01 * P.feedback_pct, 0.01 * P.feedback_down_pct,
+                      &refined);
+    (void)hipFree(bl.d_ticks);
+    bl.d_ticks = nullptr;
+    uint32_t* d_new = nullptr;
+    HIP_TRY(hipMalloc(&d_new, std::max<size_t>(1, refined.size()) * sizeof(uint32_t)));
+    hipError_t ce = hipMemcpy(d_new, refined.data(), refined.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (ce != hipSuccess) {
+        (void)hipFree(d_new);
+        return fail(RTC_ERR_DEVICE, "block list upload failed: %s", hipGetErrorString(ce));
+    }
+    (void)hipFree(bl.d);  // (nothing is in flight: the synchronisation above)
+    bl.d = d_new;
+    bl.n = refined.size();
+    bl.passes++;
+    if (bl.passes < P.feedback_passes) {
+        bl.host = refined;
+        bl.state = BlockList::FRESH;  // time this list's first launch as well
+    } else {
+        bl.host.clear();
+        bl.host.shrink_to_fit();
+        bl.state = BlockList::REFINED;
+    }
+    if (P.jit_print) std::fprintf(stderr, "librtc_amd: block list made from the frame before's wave times: %zu blocks\n", bl.n);
+    return RTC_OK;
+}
+
+// A regular grid's first frame has left what its waves cost (BlockList::TIMED): their times, or -- kernels that do not time
+// their waves -- their work counts.  Is the order worth a list?  Both orders go through a model of the dispatcher with the blocks'
+// costs: the list is taken when it ends the frame at least 3 % earlier (reflect_refract 9 %, first_textures 20 %, hexagons 8 %:
+// yes; the frames of short, even waves -- C3 1 %, first_scene 0 % -- no: there a list's scalar load and the lost neighbourhood of
+// the blocks in flight cost more than the order gives).  gx x gy: the launched (padded) grid.
+static rtc_status order_grid(rtc_ctx* c, BlockList& bl, uint32_t gx, uint32_t gy, uint32_t rows) {
+    const Policy& P = c->policy;
+    HIP_TRY(hipDeviceSynchronize());  // (once per scene and partition)
+    std::vector<uint32_t> ticks(4u * bl.n), raster(bl.n), ordered;
+    if (bl.counts) {
+        // what a wave cost, from what it counted: rays that met objects, and shade points (each a light-cone cull, a Phong
+        // evaluation, a push or pop of the recursion) at sixteen rays apiece
+        std::vector<uint4> counts(4u * bl.n);
+        HIP_TRY(hipMemcpy(counts.data(), bl.d_ticks, counts.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < counts.size(); i++) ticks[i] = (counts[i].x - std::min(counts[i].x, counts[i].z)) + 16u * counts[i].y + counts[i].z / 8u;
+    } else {
+        HIP_TRY(hipMemcpy(ticks.data(), bl.d_ticks, ticks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(bl.d_ticks);
+    bl.d_ticks = nullptr;
+    for (uint32_t by = 0; by < gy; by++)
+        for (uint32_t bx = 0; bx < gx; bx++) {  // the block workgroup (bx, by) rendered: the kernel's permutation
+            uint32_t x = bx, y = by;
+            if (bl.swizzled) {
+                const uint32_t j = (by & 3u) * gx + bx, r = j & 7u;
+                y = (by & ~3u) + (r >> 1);
+                x = 2u * (j >> 3) + (r & 1u);
+            }
+            raster[(size_t)by * gx + bx] = (x * 4u) << 16 | (y * 4u);
+        }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    const double wave_slots = 0.85 * 4.0 * prop.multiProcessorCount * 6.0;
+    bl.state = BlockList::REFINED;
+    std::vector<uint32_t> block_cost(bl.n), sorted_cost;
+    for (size_t b = 0; b < bl.n; b++) block_cost[b] = std::max(std::max(ticks[4 * b], ticks[4 * b + 1]), std::max(ticks[4 * b + 2], ticks[4 * b + 3]));
+    sorted_cost = block_cost;
+    std::sort(sorted_cost.begin(), sorted_cost.end(), std::greater<uint32_t>());
+    const size_t wg_slots = (size_t)(wave_slots / 4.0);
+    const double in_order = simulate_dispatch(block_cost, wg_slots), longest_first = simulate_dispatch(sorted_cost, wg_slots);
+    if (P.jit_print) std::fprintf(stderr, "librtc_amd: grid of %zu blocks: modelled frame %.4g in image order, %.4g longest first\n", bl.n, in_order, longest_first);
+    if (!(longest_first < 0.97 * in_order)) return RTC_OK;
+    refine_block_list(raster, ticks, c->hdr.width, rows, wave_slots, INFINITY, 0.0, &ordered);
+    if (ordered.empty() || ordered.size() > bl.n) return RTC_OK;
+    bl.n_listed = ordered.size();
+    HIP_TRY(hipMalloc(&bl.d, bl.n_listed * sizeof(uint32_t)));
+    hipError_t ce = hipMemcpy(bl.d, ordered.data(), bl.n_listed * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (ce != hipSuccess) {
+        (void)hipFree(bl.d);
+        bl.d = nullptr;
+        return fail(RTC_ERR_DEVICE, "block list upload failed: %s", hipGetErrorString(ce));
+    }
+    return RTC_OK;
+}
+
 // The policy wanted a scene-compiled kernel and hiprtc did not deliver one.  RTC_AMD_SPECIALIZE=1: an error.  Default
 // policy: the ahead-of-time kernel renders the same image -- several times slower on area-light scenes -- so say so:
 // rtc_ctx_jit_status(), rtc_stats.flags, one line on stderr per process.
@@ -2211,35 +2302,8 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         }
         BlockList& bl = it->second;
         if (P.block_feedback && bl.state == BlockList::TIMED) {
-            // the list's first launch has left its waves' times: the list of this and every later frame is made from them
-            HIP_TRY(hipDeviceSynchronize());  // (once per scene and partition; the launch may be on any stream)
-            std::vector<uint32_t> ticks(4u * bl.n), refined;
-            HIP_TRY(hipMemcpy(ticks.data(), bl.d_ticks, ticks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            hipDeviceProp_t prop;
-            HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-            refine_block_list(bl.host, ticks, c->hdr.width, rows, 0.85 * 4.0 * prop.multiProcessorCount * P.tree_waves, 0.01 * P.feedback_pct, 0.01 * P.feedback_down_pct, &refined);
-            (void)hipFree(bl.d_ticks);
-            bl.d_ticks = nullptr;
-            uint32_t* d_new = nullptr;
-            HIP_TRY(hipMalloc(&d_new, std::max<size_t>(1, refined.size()) * sizeof(uint32_t)));
-            hipError_t ce = hipMemcpy(d_new, refined.data(), refined.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            if (ce != hipSuccess) {
-                (void)hipFree(d_new);
-                return fail(RTC_ERR_DEVICE, "block list upload failed: %s", hipGetErrorString(ce));
-            }
-            (void)hipFree(bl.d);  // (nothing is in flight: the synchronisation above)
-            bl.d = d_new;
-            bl.n = refined.size();
-            bl.passes++;
-            if (bl.passes < P.feedback_passes) {
-                bl.host = refined;
-                bl.state = BlockList::FRESH;  // time this list's first launch as well
-            } else {
-                bl.host.clear();
-                bl.host.shrink_to_fit();
-                bl.state = BlockList::REFINED;
-            }
-            if (P.jit_print) std::fprintf(stderr, "librtc_amd: block list refined from the first frame's wave times: %zu blocks\n", bl.n);
+            const rtc_status st = recut_block_list(c, bl, rows);
+            if (st != RTC_OK) return st;
         }
         if (P.block_feedback && bl.state == BlockList::FRESH && bl.n != 0) {
             HIP_TRY(hipMalloc(&bl.d_ticks, 4u * bl.n * sizeof(uint32_t)));
@@ -2374,62 +2438,8 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         }
         BlockList& bl = it->second;
         if (bl.state == BlockList::TIMED) {
-            HIP_TRY(hipDeviceSynchronize());  // (once per scene and partition)
-            std::vector<uint32_t> ticks(4u * bl.n), raster(bl.n), ordered;
-            if (bl.counts) {
-                // a kernel that does not time its waves: what a wave cost, from what it counted -- rays that met objects, and
-                // shade points (each a light-cone cull, a Phong evaluation, a push or pop of the recursion) at sixteen rays apiece
-                std::vector<uint4> counts(4u * bl.n);
-                HIP_TRY(hipMemcpy(counts.data(), bl.d_ticks, counts.size() * sizeof(uint4), hipMemcpyDeviceToHost));
-                for (size_t i = 0; i < counts.size(); i++) ticks[i] = (counts[i].x - std::min(counts[i].x, counts[i].z)) + 16u * counts[i].y + counts[i].z / 8u;
-            } else {
-                HIP_TRY(hipMemcpy(ticks.data(), bl.d_ticks, ticks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            }
-            (void)hipFree(bl.d_ticks);
-            bl.d_ticks = nullptr;
-            for (uint32_t by = 0; by < grid.y; by++)
-                for (uint32_t bx = 0; bx < grid.x; bx++) {  // the block workgroup (bx, by) rendered: the kernel's permutation
-                    uint32_t gx = bx, gy = by;
-                    if (bl.swizzled) {
-                        const uint32_t j = (by & 3u) * grid.x + bx, r = j & 7u;
-                        gy = (by & ~3u) + (r >> 1);
-                        gx = 2u * (j >> 3) + (r & 1u);
-                    }
-                    raster[(size_t)by * grid.x + bx] = (gx * 4u) << 16 | (gy * 4u);
-                }
-            uint64_t longest = 0;
-            double total = 0.0;
-            for (uint32_t t : ticks) longest = std::max<uint64_t>(longest, t), total += t;
-            hipDeviceProp_t prop;
-            HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-            const double wave_slots = 0.85 * 4.0 * prop.multiProcessorCount * 6.0;
-            bl.state = BlockList::REFINED;
-            // is the order worth a list?  Both orders through a model of the dispatcher, with what the blocks counted as their
-            // cost: the list is taken when it ends the frame at least 3 % earlier (reflect_refract, first_textures, hexagons:
-            // yes; the frames of short, even waves: no -- there the list's scalar load and the lost neighbourhood of blocks
-            // in flight cost a few per cent, profiles/r03_time_configs.txt)
-            std::vector<uint32_t> block_cost(bl.n), sorted_cost;
-            for (size_t b = 0; b < bl.n; b++) block_cost[b] = std::max(std::max(ticks[4 * b], ticks[4 * b + 1]), std::max(ticks[4 * b + 2], ticks[4 * b + 3]));
-            sorted_cost = block_cost;
-            std::sort(sorted_cost.begin(), sorted_cost.end(), std::greater<uint32_t>());
-            const size_t wg_slots = (size_t)(wave_slots / 4.0);
-            const double in_order = simulate_dispatch(block_cost, wg_slots), longest_first = simulate_dispatch(sorted_cost, wg_slots);
-            if (P.jit_print) std::fprintf(stderr, "librtc_amd: grid of %zu blocks: modelled frame %.4g in image order, %.4g longest first\n", bl.n, in_order, longest_first);
-            (void)longest;
-            if (longest_first < 0.97 * in_order) {
-                refine_block_list(raster, ticks, c->hdr.width, rows, wave_slots, INFINITY, 0.0, &ordered);
-                if (!ordered.empty() && ordered.size() <= bl.n) {
-                    bl.n_listed = ordered.size();
-                    HIP_TRY(hipMalloc(&bl.d, bl.n_listed * sizeof(uint32_t)));
-                    hipError_t ce = hipMemcpy(bl.d, ordered.data(), bl.n_listed * sizeof(uint32_t), hipMemcpyHostToDevice);
-                    if (ce != hipSuccess) {
-                        (void)hipFree(bl.d);
-                        bl.d = nullptr;
-                        return fail(RTC_ERR_DEVICE, "block list upload failed: %s", hipGetErrorString(ce));
-                    }
-                }
-            }
-            if (P.jit_print) std::fprintf(stderr, "librtc_amd: grid of %zu blocks %s by the first frame's wave %s\n", bl.n, bl.d ? "ordered" : "left as it is", bl.counts ? "counts" : "times");
+            const rtc_status st = order_grid(c, bl, grid.x, grid.y, rows);
+            if (st != RTC_OK) return st;
         }
         if (bl.state == BlockList::FRESH && bl.n == (size_t)grid.x * grid.y) {
             bl.counts = !(spec_fn && c->spec_shares);
