@@ -1180,7 +1180,8 @@ struct rtc_ctx {
     // (row-major bitmap, empty: no block list), and the list last built -- for the partition it was built for
     std::vector<uint8_t> heavy_tiles;
     uint32_t heavy_w = 0, heavy_h = 0;
-    std::map<std::array<uint32_t, 4>, BlockList> block_lists;  // key: band_rows, n_parts, part, lanes per pixel (log2)
+    // key: band_rows, n_parts, part, lanes per pixel (log2; ~0: a regular grid's order), depth (what a block costs depends on it)
+    std::map<std::array<uint32_t, 5>, BlockList> block_lists;
     float scene_box_coverage = 1.0f;  // share of the image the scene's box projects to (1: unknown / all of it)
     uint32_t scene_rect[4] = {0u, 0u, 0u, 0u};  // the 16 x 16 tiles outside which no primary ray sees anything: [x0, x1) x [y0, y1); empty: unknown
     float scene_rect_coverage = 1.0f;           // ... and its share of the frame
@@ -2269,7 +2270,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         // one list per partition, built on first use and kept until the scene changes: rtc_render_ex renders a frame as
         // several partitions of one context, frame after frame (a single cached list meant a device synchronisation, a
         // rebuild and a blocking copy per chunk launch)
-        const std::array<uint32_t, 4> key = {q.band_rows, q.n_parts, q.part, share_log2};
+        const std::array<uint32_t, 5> key = {q.band_rows, q.n_parts, q.part, share_log2, P.block_feedback ? (uint32_t)depth : 0u};
         auto it = c->block_lists.find(key);
         if (it == c->block_lists.end()) {
             if (c->block_lists.size() >= 256u) {  // a caller cycling through partitions without end: start over (nothing may be in flight)
@@ -2425,7 +2426,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     // has a tail worth the list: its longest wave is a tenth of its throughput time or more.
     if (d_tiles == nullptr && P.block_feedback && P.grid_feedback && plan == nullptr && rows > 0u && !rect_launch && blocks_y == 1u && share_log2 == 0u &&
         c->hdr.width <= 65532u && rows <= 262140u && !(c->hdr.n_trav != 0u && c->policy.wavefront)) {
-        const std::array<uint32_t, 4> key = {q.band_rows, q.n_parts, q.part, 0xffffffffu};
+        const std::array<uint32_t, 5> key = {q.band_rows, q.n_parts, q.part, 0xffffffffu, (uint32_t)depth};
         auto it = c->block_lists.find(key);
         if (it == c->block_lists.end()) {
             if (c->block_lists.size() >= 256u) {

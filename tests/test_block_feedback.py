@@ -82,3 +82,20 @@ def test_partitions_refine_their_own_lists(feedback_env, name, size):
             H.assert_images_equal(image, exp, "two partitions, frame %d" % frame)
         assert rays == exp_rays, (frame, rays, exp_rays)
     r.close()
+
+
+@pytest.mark.parametrize("name,size", [("mesh", (320, 240)), ("glass_and_mirror", (400, 300))])
+def test_a_change_of_depth_between_frames(feedback_env, name, size):
+    """What a block costs depends on the recursion depth: lists are kept per depth, and a frame at another depth is its depth's
+    first frame."""
+    feedback_env(None)
+    world, camera, _ = getattr(scenes, name)(*size)
+    expected = {d: H.oracle_camera(camera).render(H.oracle_world(world), d, threads=THREADS) for d in (5, 1, 0)}
+    r = _renderer(world, camera)
+    for frame, d in enumerate((5, 5, 5, 1, 1, 5, 0, 1, 5, 0)):
+        image = r.render(d).cpu().numpy()
+        exp, exp_rays = expected[d]
+        if not np.array_equal(image, exp):
+            H.assert_images_equal(image, exp, "%s frame %d at depth %d" % (name, frame, d))
+        assert r.stats()["rays"] == exp_rays, (frame, d)
+    r.close()
