@@ -188,9 +188,12 @@ def test_random_worlds_match_the_oracle(seed, monkeypatch):
         monkeypatch.setenv("RTC_AMD_SPECIALIZE", specialise)
         r = Renderer(world, camera, device=0)
         names.append(r.kernel_name)
-        img = r.render(depth).cpu().numpy()
-        H.assert_images_equal(img, exp, "seed %d (%s)" % (seed, r.kernel_name))
-        assert r.stats()["rays"] == rays, (seed, r.kernel_name)
+        # a scene's first frame, and three of the later ones, whose blocks are scheduled -- and, with several lanes per pixel,
+        # re-cut -- by the frames before (rtc_device.hip refine_block_list, order_grid)
+        for frame in range(4):
+            img = r.render(depth).cpu().numpy()
+            H.assert_images_equal(img, exp, "seed %d (%s) frame %d" % (seed, r.kernel_name, frame))
+            assert r.stats()["rays"] == rays, (seed, r.kernel_name, frame)
         r.close()
 
 
@@ -203,9 +206,10 @@ def test_random_worlds_at_a_size_that_takes_the_default_fast_paths(seed):
     camera = P.Camera(640, 420, cam[2], cam[3])
     exp, rays = H.oracle_camera(camera).render(own, depth, threads=8)
     r = Renderer(world, camera, device=0)
-    img = r.render(depth).cpu().numpy()
-    H.assert_images_equal(img, exp, "seed %d (%s)" % (seed, r.kernel_name))
-    assert r.stats()["rays"] == rays
+    for frame in range(4):  # (the first frame and frames scheduled by the frames before)
+        img = r.render(depth).cpu().numpy()
+        H.assert_images_equal(img, exp, "seed %d (%s) frame %d" % (seed, r.kernel_name, frame))
+        assert r.stats()["rays"] == rays
     r.close()
 
 
