@@ -9,7 +9,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="python3 bench.py --steps 10 --warmup 3 --cpu-seconds 0 --no-verify --no-one-shot ${2:-}"
+BENCH="python3 bench.py --steps ${PROFILE_STEPS:-10} --warmup ${PROFILE_WARMUP:-3} --cpu-seconds 0 --no-verify --no-one-shot ${2:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace exit $?"
 if [ "${3:-}" = "trace" ]; then find "$OUT" -name "*.csv" | head; exit 0; fi
