@@ -276,7 +276,7 @@ struct Policy {
     std::string jit_source, jit_flags;  // RTC_AMD_JIT_SOURCE=<path of rtc_kernel_core.h>, RTC_AMD_JIT_FLAGS="-D... -m..."
     bool jit_print = false, cluster_stats = false, tri_naive = false, block_order = true;
     int tree_waves = 6, reg_levels = 0, blocks_y = 0, block_s = -1, block_s_top = -1;  // (0 / -1: the library's own choice)
-    uint32_t fill_wgs = 0u, cluster_min_run = 0u, cluster_leaf = 0u, area_share_waves = 0u, feedback_pct = 85u, feedback_down_pct = 40u, feedback_passes = 2u;
+    uint32_t fill_wgs = 0u, cluster_min_run = 0u, cluster_leaf = 0u, area_share_waves = 0u, feedback_pct = 85u, feedback_down_pct = 40u, feedback_passes = 2u, feedback_max_s = 4u;
     double cluster_gmax = -1.0;
 
     static Policy from_env() {
@@ -316,6 +316,7 @@ struct Policy {
         if (const char* e = RTC_DEV_ENV("RTC_AMD_FEEDBACK_DOWN_PCT")) p.feedback_down_pct = (uint32_t)std::atoi(e);
         if (const char* e = RTC_DEV_ENV("RTC_AMD_FEEDBACK_PASSES")) p.feedback_passes = std::max(1u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_AREA_SHARE_WAVES")) p.area_share_waves = (uint32_t)std::atoi(e);
+        if (const char* e = RTC_DEV_ENV("RTC_AMD_FEEDBACK_MAX_S")) p.feedback_max_s = std::min(4u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_FILL_WGS")) p.fill_wgs = std::max(1u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_CLUSTER_MIN_RUN")) p.cluster_min_run = std::max(3u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_CLUSTER_LEAF")) p.cluster_leaf = std::min(64u, std::max(2u, (uint32_t)std::atoi(e)));
@@ -1584,6 +1585,11 @@ static void mark_plane_side(const std::array<double, 4>& row, const rtc_camera* 
         for (long tx = tx0; tx <= tx1; tx++) (*tiles)[(size_t)ty * tw + tx] = 1;
 }
 
+// RenderArgs::tiles' words: lanes per pixel 2^s (s = 0 .. 4), pixel origin (multiples of 4; local rows below 2^17)
+static inline uint32_t tile_word(uint32_t s, uint32_t x0, uint32_t y0) { return (s & 3u) << 30 | (x0 / 4u) << 16 | (s >> 2) << 15 | (y0 / 4u); }
+static inline uint32_t tile_s(uint32_t t) { return (t >> 30) | ((t >> 13) & 4u); }
+static inline uint32_t tile_x0(uint32_t t) { return ((t >> 16) & 0x3fffu) << 2; }
+static inline uint32_t tile_y0(uint32_t t) { return (t & 0x7fffu) << 2; }
 // The block list of one partition (RenderArgs::tiles): the 16 x 16 tiles of the partition's compact rows, those a mesh
 // projects to first and cut into blocks of 2^mesh_share_log2 lanes per pixel (8 x 8 or 8 x 4 pixels), the others after
 // them, whole, one lane per pixel.
@@ -1609,9 +1615,9 @@ static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t w
                 if (r != 0u && (ordered ? r == rank : rank == 1u)) {
                     for (uint32_t dy = 0; dy < 16u && yl0 + dy < rows; dy += hbh)
                         for (uint32_t dx = 0; dx < 16u && x0 + dx < width; dx += hbw)
-                            out->push_back(s << 30 | ((x0 + dx) / 4u) << 16 | ((yl0 + dy) / 4u));
+                            out->push_back(tile_word(s, x0 + dx, yl0 + dy));
                 } else if (rank == 1u && r == 0u) {
-                    light.push_back(0u << 30 | (x0 / 4u) << 16 | (yl0 / 4u));
+                    light.push_back(tile_word(0u, x0, yl0));
                 }
             }
         }
@@ -1629,7 +1635,7 @@ static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t w
 // longest wave.  Which lanes trace a pixel and when changes nothing about its value (tests/test_gpu_fullsize.py compares first
 // and later frames with the oracle).
 static void refine_block_list(const std::vector<uint32_t>& list, const std::vector<uint32_t>& ticks, uint32_t width, uint32_t rows, double wave_slots,
-                              double threshold, double down, std::vector<uint32_t>* out) {
+                              double threshold, double down, std::vector<uint32_t>* out, uint32_t max_s = 4u) {
     struct Tile {
         uint32_t x0, y0, s;
         uint64_t longest = 0;
@@ -1640,13 +1646,13 @@ static void refine_block_list(const std::vector<uint32_t>& list, const std::vect
     std::vector<int32_t> index((size_t)tw * ((rows + 15u) / 16u), -1);
     double total = 0.0;
     for (size_t b = 0; b < list.size(); b++) {
-        const uint32_t t = list[b], x0 = ((t >> 16) & 0x3fffu) << 2, y0 = (t & 0xffffu) << 2;
+        const uint32_t t = list[b], x0 = tile_x0(t), y0 = tile_y0(t);
         if (x0 >= width || y0 >= rows) continue;  // (a padded grid's blocks outside the image)
         int32_t& slot = index[(size_t)(y0 / 16u) * tw + x0 / 16u];
         if (slot < 0) {
             slot = (int32_t)tiles.size();
             Tile n;
-            n.x0 = x0 & ~15u, n.y0 = y0 & ~15u, n.s = t >> 30;
+            n.x0 = x0 & ~15u, n.y0 = y0 & ~15u, n.s = tile_s(t);
             tiles.push_back(n);
         }
         Tile& tile = tiles[(size_t)slot];
@@ -1659,7 +1665,7 @@ static void refine_block_list(const std::vector<uint32_t>& list, const std::vect
     const double throughput = total / std::max(1.0, wave_slots);  // ticks the frame takes if the work were spread evenly
     for (Tile& t : tiles) {
         t.predicted = (double)t.longest;
-        while (t.s < 3u && t.predicted > threshold * throughput) t.s++, t.predicted *= 0.7;
+        while (t.s < max_s && t.predicted > threshold * throughput) t.s++, t.predicted *= 0.7;  // (up to sixteen lanes per pixel)
         while (t.s > 0u && t.predicted / 0.7 < down * throughput) t.s--, t.predicted /= 0.7;
     }
     std::vector<uint32_t> order(tiles.size());
@@ -1670,7 +1676,7 @@ static void refine_block_list(const std::vector<uint32_t>& list, const std::vect
         const Tile& t = tiles[i];
         const uint32_t hbw = 16u >> (t.s >> 1), hbh = 16u >> ((t.s + 1u) >> 1);
         for (uint32_t dy = 0; dy < 16u && t.y0 + dy < rows; dy += hbh)
-            for (uint32_t dx = 0; dx < 16u && t.x0 + dx < width; dx += hbw) out->push_back(t.s << 30 | ((t.x0 + dx) / 4u) << 16 | ((t.y0 + dy) / 4u));
+            for (uint32_t dx = 0; dx < 16u && t.x0 + dx < width; dx += hbw) out->push_back(tile_word(t.s, t.x0 + dx, t.y0 + dy));
     }
 }
 
@@ -1699,7 +1705,7 @@ static rtc_status recut_block_list(rtc_ctx* c, BlockList& bl, uint32_t rows) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     refine_block_list(bl.host, ticks, c->hdr.width, rows, 0.85 * 4.0 * prop.multiProcessorCount * P.tree_waves, 0.01 * P.feedback_pct, 0.01 * P.feedback_down_pct,
-                      &refined);
+                      &refined, P.feedback_max_s);
     (void)hipFree(bl.d_ticks);
     bl.d_ticks = nullptr;
     uint32_t* d_new = nullptr;
@@ -1753,7 +1759,7 @@ static rtc_status order_grid(rtc_ctx* c, BlockList& bl, uint32_t gx, uint32_t gy
                 y = (by & ~3u) + (r >> 1);
                 x = 2u * (j >> 3) + (r & 1u);
             }
-            raster[(size_t)by * gx + bx] = (x * 4u) << 16 | (y * 4u);
+            raster[(size_t)by * gx + bx] = tile_word(0u, 16u * x, 16u * y);
         }
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
@@ -2266,7 +2272,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     // frame before to go by: the list starts with the frame's one lane count everywhere, and the feedback gives the tiles in the
     // penumbra more lanes, the lit and the empty ones fewer (refine_block_list).  Not for rtc_render_ex, whose rows leave in order.
     const bool area_list = spec_fn && c->spec_shares && c->hdr.light_kind == RTC_LIGHT_RECT && share_log2 != 0u && P.block_feedback && plan == nullptr;
-    if ((mesh_list || area_list) && P.share_log2 < 0 && c->hdr.width <= 65532u && rows <= 262140u && rows > 0u) {
+    if ((mesh_list || area_list) && P.share_log2 < 0 && c->hdr.width <= 65532u && rows <= 131068u && rows > 0u) {
         // one list per partition, built on first use and kept until the scene changes: rtc_render_ex renders a frame as
         // several partitions of one context, frame after frame (a single cached list meant a device synchronisation, a
         // rebuild and a blocking copy per chunk launch)
@@ -2287,7 +2293,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
                     for (uint32_t x0 = 0; x0 < c->hdr.width; x0 += 16u)
                         for (uint32_t dy = 0; dy < 16u && y0 + dy < rows; dy += hbh)
                             for (uint32_t dx = 0; dx < 16u && x0 + dx < c->hdr.width; dx += hbw)
-                                host.push_back(share_log2 << 30 | ((x0 + dx) / 4u) << 16 | ((y0 + dy) / 4u));
+                                host.push_back(tile_word(share_log2, x0 + dx, y0 + dy));
             }
             BlockList bl;
             bl.n = host.size();
@@ -2425,7 +2431,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     // workgroup, no scene rectangle, nobody waiting for rows in image order (rtc_render_ex's progress words) -- and the frame
     // has a tail worth the list: its longest wave is a tenth of its throughput time or more.
     if (d_tiles == nullptr && P.block_feedback && P.grid_feedback && plan == nullptr && rows > 0u && !rect_launch && blocks_y == 1u && share_log2 == 0u &&
-        c->hdr.width <= 65532u && rows <= 262140u && !(c->hdr.n_trav != 0u && c->policy.wavefront)) {
+        c->hdr.width <= 65532u && rows <= 131068u && !(c->hdr.n_trav != 0u && c->policy.wavefront)) {
         const std::array<uint32_t, 5> key = {q.band_rows, q.n_parts, q.part, 0xffffffffu, (uint32_t)depth};
         auto it = c->block_lists.find(key);
         if (it == c->block_lists.end()) {

@@ -2837,9 +2837,9 @@ struct RenderArgs {
     uint32_t band_rows, n_parts, part;
     int32_t depth;
     uint32_t share_log2;   // 2^share_log2 lanes per pixel (see Counters): > 0 only for area lights on small images
-    // Block list: workgroup b renders the block tiles[b] = s << 30 | (x0 / 4) << 16 | (y0 / 4) -- pixel origin (x0, local row y0)
-    // and, in kernels compiled for lane sharing, ITS OWN lanes-per-pixel 2^s -- instead of block (blockIdx.x, blockIdx.y) of a
-    // regular grid.  For tree worlds with long leaf runs the host lists the blocks of image regions a mesh projects to first and
+    // Block list: workgroup b renders the block tiles[b] = (s & 3) << 30 | (x0 / 4) << 16 | (s >> 2) << 15 | (y0 / 4) -- pixel origin
+    // (x0, local row y0 < 2^17) and, in kernels compiled for lane sharing, ITS OWN lanes-per-pixel 2^s, s = 0 .. 4 -- instead of block
+    // (blockIdx.x, blockIdx.y) of a regular grid.  For tree worlds with long leaf runs the host lists the blocks of image regions a mesh projects to first and
     // with more lanes per pixel, the rest after them with one (rtc_device.hip build_block_list): such a frame's time is that of
     // its slowest waves, so those start first and are cut up.  From a scene's second frame on, any list is made from the wave
     // times of the frame before (refine_block_list).  nullptr: regular grid.
@@ -2951,9 +2951,9 @@ DI void render_body(const RenderArgs& A) {
         uint32_t bx0, by0;  // pixel origin of this workgroup's block
         if (A.tiles != nullptr) {
             const uint32_t t = A.tiles[blockIdx.x];  // wave-uniform: a scalar load
-            if (Counters::SHARE_LANES) w.sl = t >> 30;  // (a kernel without lane sharing is only ever given lists of whole blocks)
+            if (Counters::SHARE_LANES) w.sl = (t >> 30) | ((t >> 13) & 4u);  // (a kernel without lane sharing is only ever given lists of whole blocks)
             bx0 = ((t >> 16) & 0x3fffu) << 2;
-            by0 = (t & 0xffffu) << 2;
+            by0 = (t & 0x7fffu) << 2;
         } else {
             uint32_t block_x0 = 0u, block_y0 = 0u;
             if constexpr (RECT_LAUNCH) {

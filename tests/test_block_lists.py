@@ -1,7 +1,7 @@
 """The host side of the frame-to-frame feedback (rtc_device.hip refine_block_list, simulate_dispatch) -- no device needed.
 
 Whatever the wave times say, the list made from them must render every pixel of the partition exactly once: a block list is a
-tiling of the frame by blocks of 16 x 16, 16 x 8, 8 x 8 or 8 x 4 pixels (1, 2, 4, 8 lanes per pixel), one size per 16 x 16 tile.
+tiling of the frame by blocks of 16 x 16, 16 x 8, 8 x 8, 8 x 4 or 4 x 4 pixels (1, 2, 4, 8, 16 lanes per pixel), one size per 16 x 16 tile.
 """
 import ctypes as C
 
@@ -26,7 +26,7 @@ def _list(width, rows, s_of_tile):
             for dy in range(0, 16, bh):
                 for dx in range(0, 16, bw):
                     if y0 + dy < rows and x0 + dx < width:
-                        out.append(s << 30 | ((x0 + dx) // 4) << 16 | ((y0 + dy) // 4))
+                        out.append((s & 3) << 30 | ((x0 + dx) // 4) << 16 | (s >> 2) << 15 | ((y0 + dy) // 4))
     return np.array(out, dtype=np.uint32)
 
 
@@ -43,7 +43,7 @@ def _coverage(lst, width, rows):
     cover = np.zeros((rows, width), dtype=np.int32)
     lanes = {}
     for t in lst.tolist():
-        s, x0, y0 = t >> 30, ((t >> 16) & 0x3fff) << 2, (t & 0xffff) << 2
+        s, x0, y0 = (t >> 30) | ((t >> 13) & 4), ((t >> 16) & 0x3fff) << 2, (t & 0x7fff) << 2
         bw, bh = _block(s)
         assert x0 % bw == 0 and y0 % bh == 0 and x0 < width and y0 < rows, (s, x0, y0)
         cover[y0:y0 + bh, x0:x0 + bw] += 1
@@ -55,7 +55,7 @@ def _coverage(lst, width, rows):
 def test_a_refined_list_tiles_the_partition(width, rows, seed):
     rng = np.random.default_rng(seed)
     tiles_x = (width + 15) // 16
-    start = rng.integers(0, 4, size=((rows + 15) // 16, tiles_x))
+    start = rng.integers(0, 5, size=((rows + 15) // 16, tiles_x))
     lst = _list(width, rows, lambda tx, ty: int(start[ty, tx]))
     for trial in range(6):
         kind = trial % 3
