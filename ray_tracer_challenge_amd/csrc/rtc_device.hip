@@ -331,10 +331,15 @@ struct Policy {
 // cells (intensity_at), while the frame would otherwise be fewer than ~4 waves per SIMD; and, in a tree walk, the long
 // runs of leaves a divided mesh leaves at every level (for_each_leaf_shared) -- there a frame's time is that of its
 // slowest wave, whatever the frame's size.  RTC_AMD_SHARE_LOG2=0..3 overrides.
-static uint32_t choose_share_log2_runs(uint64_t waves) { return waves <= 12000u ? 3u : waves <= 40000u ? 2u : 1u; }
+// (beyond 200 k waves a first frame is better off with one lane everywhere -- mesh 4096^2, 262 k: 8.1 ms with two lanes in the mesh
+// tiles, 6.3 with one; here_be_dragons 4000 x 1600, 100 k: 2.9 / 3.8 -- and the feedback finds the few tiles that want more)
+static uint32_t choose_share_log2_runs(uint64_t waves) { return waves <= 12000u ? 3u : waves <= 40000u ? 2u : waves <= 200000u ? 1u : 0u; }
+static bool has_leaf_runs(const SceneHdr& hdr) {  // a tree walk with the long runs of leaves a divided mesh leaves: lanes can split them
+    return hdr.n_trav != 0u && hdr.max_leaf_run >= 16u && !(hdr.light_kind == RTC_LIGHT_RECT && hdr.u_steps * hdr.v_steps >= 8);
+}
 static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows, const Policy& P, bool lists = true) {
     const bool area = hdr.light_kind == RTC_LIGHT_RECT && hdr.u_steps * hdr.v_steps >= 8;
-    const bool runs = hdr.n_trav != 0u && hdr.max_leaf_run >= 16u && !area;
+    const bool runs = has_leaf_runs(hdr);
     if (!area && !runs) return 0u;
     if (P.share_log2 >= 0) return (uint32_t)P.share_log2;
     const uint64_t waves = ((uint64_t)hdr.width * rows + 63) / 64;
@@ -1706,6 +1711,15 @@ static rtc_status recut_block_list(rtc_ctx* c, BlockList& bl, uint32_t rows) {
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     refine_block_list(bl.host, ticks, c->hdr.width, rows, 0.85 * 4.0 * prop.multiProcessorCount * P.tree_waves, 0.01 * P.feedback_pct, 0.01 * P.feedback_down_pct,
                       &refined, P.feedback_max_s);
+    if (P.jit_print) {
+        size_t by_s[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};  // blocks by lanes per pixel (log2), before and after
+        for (uint32_t t : bl.host.empty() ? refined : bl.host) by_s[0][tile_s(t)]++;
+        for (uint32_t t : refined) by_s[1][tile_s(t)]++;
+        std::fprintf(stderr, "librtc_amd: block list made from the frame before's wave times: %zu blocks; pixels by lanes per pixel 1/2/4/8/16: "
+                             "%zu/%zu/%zu/%zu/%zu -> %zu/%zu/%zu/%zu/%zu k\n", bl.n, by_s[0][0] * 256 / 1000, by_s[0][1] * 128 / 1000, by_s[0][2] * 64 / 1000,
+                     by_s[0][3] * 32 / 1000, by_s[0][4] * 16 / 1000, by_s[1][0] * 256 / 1000, by_s[1][1] * 128 / 1000, by_s[1][2] * 64 / 1000, by_s[1][3] * 32 / 1000,
+                     by_s[1][4] * 16 / 1000);
+    }
     (void)hipFree(bl.d_ticks);
     bl.d_ticks = nullptr;
     uint32_t* d_new = nullptr;
@@ -1727,7 +1741,7 @@ static rtc_status recut_block_list(rtc_ctx* c, BlockList& bl, uint32_t rows) {
         bl.host.shrink_to_fit();
         bl.state = BlockList::REFINED;
     }
-    if (P.jit_print) std::fprintf(stderr, "librtc_amd: block list made from the frame before's wave times: %zu blocks\n", bl.n);
+
     return RTC_OK;
 }
 
@@ -1870,7 +1884,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     // which kernel will render this scene
     c->spec_fn = nullptr;
     // sample-parallel rendering (render_body): compiled in when this frame is small enough to want it
-    c->spec_shares = choose_share_log2(hdr, hdr.height, P) != 0u;
+    c->spec_shares = choose_share_log2(hdr, hdr.height, P) != 0u || has_leaf_runs(hdr);  // (kernels of mesh scenes always: their block lists)
     // several blocks per workgroup (render_body) where most workgroups see nothing but the sky: the scene's box projects to
     // less than a quarter of the image
     c->scene_box_coverage = 1.0f;
