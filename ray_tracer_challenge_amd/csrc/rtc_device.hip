@@ -1602,11 +1602,15 @@ static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t w
     out->clear();
     std::vector<uint32_t> light;
     uint32_t hs = mesh_share_log2;  // lanes per pixel (log2) in the mesh tiles; RTC_AMD_BLOCK_S=0..3: development
-    if (P.block_s >= 0) hs = (uint32_t)P.block_s;
     // the dearest tiles first (rank 3: glass that also reflects), or the frame ends waiting for a few waves that started
     // late (RTC_AMD_BLOCK_ORDER=0: image order; RTC_AMD_BLOCK_S_TOP=0..3: lanes per pixel of rank 3 alone -- development)
     const bool ordered = P.block_order;
     uint32_t hs_top = hs;
+    // large frames at two lanes: only the glass keeps them, the other meshes' tiles take one (first frames of here_be_dragons
+    // 4000 x 1600 2.87 -> 2.68 ms, mesh 2048^2 3.47 -> 3.24; at 1024^2 and below the other way round: 2.38 -> 2.70,
+    // profiles/r03_ab_first_frame_lanes.txt)
+    if (hs == 1u && ((uint64_t)width * rows + 63u) / 64u > 60000u) hs = 0u;
+    if (P.block_s >= 0) hs = hs_top = (uint32_t)P.block_s;
     if (P.block_s_top >= 0) hs_top = (uint32_t)P.block_s_top;
     for (uint32_t rank = 3u; rank >= 1u; rank--) {
         const uint32_t s = rank == 3u ? hs_top : hs;
