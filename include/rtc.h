@@ -332,7 +332,11 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* ctx, const rtc_scene* scene, const rtc_cam
 uint32_t rtc_partition_rows(uint32_t height, const rtc_partition* part);
 /* Launches the render kernel on `stream` (a hipStream_t; NULL = default
  * stream) and returns without synchronising.  d_out_rgb: DEVICE pointer to
- * rtc_partition_rows()*width*3 f32.  part may be NULL (whole image). */
+ * rtc_partition_rows()*width*3 f32.  part may be NULL (whole image).
+ * "Returns without synchronising" has one exception per scene, partition and depth: the context schedules a frame by what
+ * the frame before it measured (which blocks of pixels start first, how many lanes trace a pixel of each),
+ * and the second -- for block lists also the third -- call reads those measurements back, which waits for the device.
+ * Every frame traces every ray and returns the same values.  RTC_AMD_BLOCK_FEEDBACK=0: every frame like the first. */
 rtc_status rtc_ctx_render(rtc_ctx* ctx, int32_t depth, const rtc_partition* part, void* d_out_rgb, void* stream);
 /* Waits for every rtc_ctx_render issued on this context so far and reports the
  * last launch's counters plus the mean kernel time since the previous call. */
