@@ -99,3 +99,18 @@ def test_a_change_of_depth_between_frames(feedback_env, name, size):
             H.assert_images_equal(image, exp, "%s frame %d at depth %d" % (name, frame, d))
         assert r.stats()["rays"] == exp_rays, (frame, d)
     r.close()
+
+
+@pytest.mark.parametrize("size", [(2, 2), (17, 9), (16, 16), (33, 65), (130, 3), (257, 129)])
+@pytest.mark.parametrize("name", ["soft_shadows", "glass_and_mirror", "mesh"])
+def test_odd_and_tiny_frames(feedback_env, name, size):
+    feedback_env(None)
+    world, camera, depth = getattr(scenes, name)(*size)
+    exp, exp_rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=THREADS)
+    r = _renderer(world, camera)
+    for frame in range(4):
+        image = r.render(depth).cpu().numpy()
+        if not np.array_equal(image, exp):
+            H.assert_images_equal(image, exp, "%s %dx%d frame %d" % (name, size[0], size[1], frame))
+        assert r.stats()["rays"] == exp_rays, (name, size, frame)
+    r.close()
