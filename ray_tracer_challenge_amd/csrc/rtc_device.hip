@@ -1151,10 +1151,13 @@ struct BlockList {  // RenderArgs::tiles of one partition (build_block_list), re
     size_t n = 0, n_listed = 0;  // (n_listed: a grid's list leaves the padding out)
     // feedback (refine_block_list): the list as built, where its first launch leaves its waves' running times, and how far it is
     std::vector<uint32_t> host;
+    size_t d_cap = 0, ticks_cap = 0;  // bytes behind d / d_ticks: grown, never shrunk (hipMalloc / hipFree cost the animation's frames milliseconds)
     uint32_t* d_ticks = nullptr;  // [4 n] wave times -- or, for kernels that do not time their waves, [4 n] uint4 work counts (a copy of block_counts)
-    bool counts = false, swizzled = false;
-    enum { FRESH, TIMED, REFINED } state = FRESH;
+    bool counts = false, swizzled = false, listed = false;  // (listed: a grid whose frames run from `d`, its blocks in order)
+    // IDLE (regular grids): a scene's first frame -- nothing is measured before a second frame of the SAME scene shows that frames repeat
+    enum { FRESH, TIMED, REFINED, IDLE } state = FRESH;
     uint32_t passes = 0;  // refinements so far
+    uint32_t scene_changes = 0;  // restart_block_lists
 };
 struct rtc_ctx {
     int device = 0;
@@ -1171,6 +1174,7 @@ struct rtc_ctx {
     unsigned long long* d_ppm_rows = nullptr;  // per-row length, then offset; [h] is the total
     uint32_t* d_ppm_bits = nullptr;
     size_t ppm_rows_cap = 0, ppm_bits_cap = 0;
+    int n_cus = 0;                    // compute_units()
     bool spec_shares = false;         // spec_fn was compiled with -DRTC_SPEC_SHARE=1
     bool spec_blocks_y = false;       // ... with -DRTC_SPEC_BLOCKS_Y=1 (several blocks per workgroup)
     bool spec_rect = false;           // ... with -DRTC_SPEC_RECT=1 (scene rectangle launches: block offsets, zero-filling workgroups)
@@ -1220,6 +1224,29 @@ struct rtc_ctx {
     uint64_t last_pixels = 0;
 };
 
+// A new scene of the same frame size (an animation: the camera or an object has moved): what a tile cost in the frame before is
+// still the best guess for what it costs now, and any list is a valid tiling for any scene.  The lists that cut tiles into lanes
+// (divided meshes, lane-sharing area lights) stay; every eighth scene a refined one is timed again by its next frame (which runs
+// from it as it is) and re-cut for the one after -- a re-cut costs the host about a millisecond, the lists age slowly (mesh 2048^2,
+// a quarter of a degree per frame: kernel 3.87 -> 3.3 - 3.6 ms; here_be_dragons 2000 x 800 2.69 -> 2.16; soft_shadows 1000 x 400 0.19 ->
+// 0.10; re-cut every other scene: mesh 3.00, and a millisecond of host time each).  A list whose timed frame belonged to the old scene is re-cut from that: it is the frame before.  A regular grid's
+// ORDER does not survive: a stale order was slightly worse than the permuted image order (reflect_refract 0.839 -> 0.860 ms).
+static void restart_block_lists(rtc_ctx* c) {
+    for (auto it = c->block_lists.begin(); it != c->block_lists.end();) {
+        BlockList& bl = it->second;
+        if (it->first[3] == 0xffffffffu) {  // (its buffers stay for the next scene that repeats)
+            bl.state = BlockList::IDLE;
+            bl.listed = false;
+            ++it;
+            continue;
+        }
+        if (bl.state == BlockList::REFINED && (++bl.scene_changes & 7u) == 0u) {
+            bl.state = BlockList::FRESH;
+            bl.passes = c->policy.feedback_passes ? c->policy.feedback_passes - 1u : 0u;
+        }
+        ++it;
+    }
+}
 // every block list of the context, with what its feedback holds (the caller knows that no launch is reading them)
 static void drop_block_lists(rtc_ctx* c) {
     for (auto& bl : c->block_lists) {
@@ -1704,6 +1731,24 @@ static double simulate_dispatch(const std::vector<uint32_t>& cost, size_t slots)
     return end;
 }
 
+// a device buffer of at least `bytes` (nothing may be in flight that reads the old one)
+static hipError_t grow(uint32_t** p, size_t* cap, size_t bytes) {
+    if (*p != nullptr && *cap >= bytes) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr, *cap = 0;
+    const size_t want = std::max<size_t>(256, bytes + bytes / 2);
+    hipError_t e = hipMalloc(p, want);
+    if (e == hipSuccess) *cap = want;
+    return e;
+}
+static int compute_units(rtc_ctx* c) {  // of the context's device (asked once: the query takes a fraction of a millisecond)
+    if (c->n_cus == 0) {
+        hipDeviceProp_t prop;
+        c->n_cus = hipGetDeviceProperties(&prop, c->device) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    return c->n_cus;
+}
+
 // A block list's first launch has left its waves' times (BlockList::TIMED): the list of this and every later frame is made from
 // them (refine_block_list); feedback_passes times over.
 static rtc_status recut_block_list(rtc_ctx* c, BlockList& bl, uint32_t rows) {
@@ -1711,9 +1756,7 @@ static rtc_status recut_block_list(rtc_ctx* c, BlockList& bl, uint32_t rows) {
     HIP_TRY(hipDeviceSynchronize());  // (once per scene, partition and pass; the launch may be on any stream)
     std::vector<uint32_t> ticks(4u * bl.n), refined;
     HIP_TRY(hipMemcpy(ticks.data(), bl.d_ticks, ticks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-    refine_block_list(bl.host, ticks, c->hdr.width, rows, 0.85 * 4.0 * prop.multiProcessorCount * P.tree_waves, 0.01 * P.feedback_pct, 0.01 * P.feedback_down_pct,
+    refine_block_list(bl.host, ticks, c->hdr.width, rows, 0.85 * 4.0 * compute_units(c) * P.tree_waves, 0.01 * P.feedback_pct, 0.01 * P.feedback_down_pct,
                       &refined, P.feedback_max_s);
     if (P.jit_print) {
         size_t by_s[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};  // blocks by lanes per pixel (log2), before and after
@@ -1724,27 +1767,12 @@ static rtc_status recut_block_list(rtc_ctx* c, BlockList& bl, uint32_t rows) {
                      by_s[0][3] * 32 / 1000, by_s[0][4] * 16 / 1000, by_s[1][0] * 256 / 1000, by_s[1][1] * 128 / 1000, by_s[1][2] * 64 / 1000, by_s[1][3] * 32 / 1000,
                      by_s[1][4] * 16 / 1000);
     }
-    (void)hipFree(bl.d_ticks);
-    bl.d_ticks = nullptr;
-    uint32_t* d_new = nullptr;
-    HIP_TRY(hipMalloc(&d_new, std::max<size_t>(1, refined.size()) * sizeof(uint32_t)));
-    hipError_t ce = hipMemcpy(d_new, refined.data(), refined.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (ce != hipSuccess) {
-        (void)hipFree(d_new);
-        return fail(RTC_ERR_DEVICE, "block list upload failed: %s", hipGetErrorString(ce));
-    }
-    (void)hipFree(bl.d);  // (nothing is in flight: the synchronisation above)
-    bl.d = d_new;
+    HIP_TRY(grow(&bl.d, &bl.d_cap, refined.size() * sizeof(uint32_t)));  // (nothing is in flight: the synchronisation above)
+    HIP_TRY(hipMemcpy(bl.d, refined.data(), refined.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     bl.n = refined.size();
     bl.passes++;
-    if (bl.passes < P.feedback_passes) {
-        bl.host = refined;
-        bl.state = BlockList::FRESH;  // time this list's first launch as well
-    } else {
-        bl.host.clear();
-        bl.host.shrink_to_fit();
-        bl.state = BlockList::REFINED;
-    }
+    bl.host = refined;  // (kept: a later scene of this size starts from it, restart_block_lists)
+    bl.state = bl.passes < P.feedback_passes ? BlockList::FRESH /* time this list's first launch as well */ : BlockList::REFINED;
 
     return RTC_OK;
 }
@@ -1757,18 +1785,17 @@ static rtc_status recut_block_list(rtc_ctx* c, BlockList& bl, uint32_t rows) {
 static rtc_status order_grid(rtc_ctx* c, BlockList& bl, uint32_t gx, uint32_t gy, uint32_t rows) {
     const Policy& P = c->policy;
     HIP_TRY(hipDeviceSynchronize());  // (once per scene and partition)
-    std::vector<uint32_t> ticks(4u * bl.n), raster(bl.n), ordered;
+    const size_t nt = bl.n;  // the blocks of the timed launch: the (padded) grid's
+    std::vector<uint32_t> ticks(4u * nt), launched(nt), ordered;
     if (bl.counts) {
         // what a wave cost, from what it counted: rays that met objects, and shade points (each a light-cone cull, a Phong
         // evaluation, a push or pop of the recursion) at sixteen rays apiece
-        std::vector<uint4> counts(4u * bl.n);
+        std::vector<uint4> counts(4u * nt);
         HIP_TRY(hipMemcpy(counts.data(), bl.d_ticks, counts.size() * sizeof(uint4), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < counts.size(); i++) ticks[i] = (counts[i].x - std::min(counts[i].x, counts[i].z)) + 16u * counts[i].y + counts[i].z / 8u;
     } else {
         HIP_TRY(hipMemcpy(ticks.data(), bl.d_ticks, ticks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
-    (void)hipFree(bl.d_ticks);
-    bl.d_ticks = nullptr;
     for (uint32_t by = 0; by < gy; by++)
         for (uint32_t bx = 0; bx < gx; bx++) {  // the block workgroup (bx, by) rendered: the kernel's permutation
             uint32_t x = bx, y = by;
@@ -1777,30 +1804,27 @@ static rtc_status order_grid(rtc_ctx* c, BlockList& bl, uint32_t gx, uint32_t gy
                 y = (by & ~3u) + (r >> 1);
                 x = 2u * (j >> 3) + (r & 1u);
             }
-            raster[(size_t)by * gx + bx] = tile_word(0u, 16u * x, 16u * y);
+            launched[(size_t)by * gx + bx] = tile_word(0u, 16u * x, 16u * y);
         }
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-    const double wave_slots = 0.85 * 4.0 * prop.multiProcessorCount * 6.0;
+    const double wave_slots = 0.85 * 4.0 * compute_units(c) * 6.0;
     bl.state = BlockList::REFINED;
-    std::vector<uint32_t> block_cost(bl.n), sorted_cost;
-    for (size_t b = 0; b < bl.n; b++) block_cost[b] = std::max(std::max(ticks[4 * b], ticks[4 * b + 1]), std::max(ticks[4 * b + 2], ticks[4 * b + 3]));
-    sorted_cost = block_cost;
-    std::sort(sorted_cost.begin(), sorted_cost.end(), std::greater<uint32_t>());
-    const size_t wg_slots = (size_t)(wave_slots / 4.0);
-    const double in_order = simulate_dispatch(block_cost, wg_slots), longest_first = simulate_dispatch(sorted_cost, wg_slots);
-    if (P.jit_print) std::fprintf(stderr, "librtc_amd: grid of %zu blocks: modelled frame %.4g in image order, %.4g longest first\n", bl.n, in_order, longest_first);
-    if (!(longest_first < 0.97 * in_order)) return RTC_OK;
-    refine_block_list(raster, ticks, c->hdr.width, rows, wave_slots, INFINITY, 0.0, &ordered);
-    if (ordered.empty() || ordered.size() > bl.n) return RTC_OK;
-    bl.n_listed = ordered.size();
-    HIP_TRY(hipMalloc(&bl.d, bl.n_listed * sizeof(uint32_t)));
-    hipError_t ce = hipMemcpy(bl.d, ordered.data(), bl.n_listed * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (ce != hipSuccess) {
-        (void)hipFree(bl.d);
-        bl.d = nullptr;
-        return fail(RTC_ERR_DEVICE, "block list upload failed: %s", hipGetErrorString(ce));
+    bl.listed = false;
+    {
+        std::vector<uint32_t> block_cost(nt), sorted_cost;
+        for (size_t b = 0; b < nt; b++) block_cost[b] = std::max(std::max(ticks[4 * b], ticks[4 * b + 1]), std::max(ticks[4 * b + 2], ticks[4 * b + 3]));
+        sorted_cost = block_cost;
+        std::sort(sorted_cost.begin(), sorted_cost.end(), std::greater<uint32_t>());
+        const size_t wg_slots = (size_t)(wave_slots / 4.0);
+        const double in_order = simulate_dispatch(block_cost, wg_slots), longest_first = simulate_dispatch(sorted_cost, wg_slots);
+        if (P.jit_print) std::fprintf(stderr, "librtc_amd: grid of %zu blocks: modelled frame %.4g in image order, %.4g longest first\n", nt, in_order, longest_first);
+        if (!(longest_first < 0.97 * in_order)) return RTC_OK;  // (the grid stays)
     }
+    refine_block_list(launched, ticks, c->hdr.width, rows, wave_slots, INFINITY, 0.0, &ordered);
+    if (ordered.empty() || ordered.size() > bl.n) return RTC_OK;
+    HIP_TRY(grow(&bl.d, &bl.d_cap, ordered.size() * sizeof(uint32_t)));  // (nothing is in flight: the synchronisation above)
+    HIP_TRY(hipMemcpy(bl.d, ordered.data(), ordered.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    bl.n_listed = ordered.size();
+    bl.listed = true;
     return RTC_OK;
 }
 
@@ -1845,6 +1869,7 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     // against them), and a render still in flight reads the records and the counters this call replaces.  Wait for
     // everything the context has launched before touching them.  (rtc.h: one stream at a time per context.)
     HIP_TRY(hipDeviceSynchronize());
+    const bool same_frame = c->has_scene && c->hdr.width == hdr.width && c->hdr.height == hdr.height;  // (block lists: below)
     // until the new scene is fully resident the context has none: a failed allocation below must not leave a stale
     // capacity beside a null pointer, nor a render path that believes the old scene is still there
     c->has_scene = false;
@@ -1880,7 +1905,8 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     c->has_scene = true;
     c->soa_host = soa;
     c->texels_host = texels;
-    drop_block_lists(c);  // (nothing is in flight any more: the synchronisation above)
+    if (same_frame && P.block_feedback) restart_block_lists(c);
+    else drop_block_lists(c);  // (nothing is in flight any more: the synchronisation above)
     c->deep_fn.clear();
     c->spec_defs.clear();
     project_heavy_boxes(P, heavy_boxes, camera, &c->heavy_tiles, &c->heavy_w, &c->heavy_h);
@@ -2316,7 +2342,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             BlockList bl;
             bl.n = host.size();
             if (P.block_feedback) bl.host = host;
-            HIP_TRY(hipMalloc(&bl.d, std::max<size_t>(1, host.size()) * sizeof(uint32_t)));
+            HIP_TRY(grow(&bl.d, &bl.d_cap, host.size() * sizeof(uint32_t)));
             // (a new buffer: no launch in flight can be reading it; the copy is complete when the call returns)
             hipError_t ce = hipMemcpy(bl.d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
             if (ce != hipSuccess) {
@@ -2331,7 +2357,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             if (st != RTC_OK) return st;
         }
         if (P.block_feedback && bl.state == BlockList::FRESH && bl.n != 0) {
-            HIP_TRY(hipMalloc(&bl.d_ticks, 4u * bl.n * sizeof(uint32_t)));
+            HIP_TRY(grow(&bl.d_ticks, &bl.ticks_cap, 4u * bl.n * sizeof(uint32_t)));
             HIP_TRY(hipMemsetAsync(bl.d_ticks, 0, 4u * bl.n * sizeof(uint32_t), stream));
             d_ticks = bl.d_ticks;
             bl.state = BlockList::TIMED;
@@ -2459,6 +2485,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             }
             BlockList bl;
             bl.n = (size_t)grid.x * grid.y;
+            bl.state = BlockList::IDLE;
             it = c->block_lists.emplace(key, bl).first;
         }
         BlockList& bl = it->second;
@@ -2466,18 +2493,21 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             const rtc_status st = order_grid(c, bl, grid.x, grid.y, rows);
             if (st != RTC_OK) return st;
         }
-        if (bl.state == BlockList::FRESH && bl.n == (size_t)grid.x * grid.y) {
+        if (bl.state == BlockList::IDLE) {
+            bl.state = BlockList::FRESH;  // (the next frame of this scene, if there is one, is measured)
+        } else if (bl.state == BlockList::FRESH && bl.n == (size_t)grid.x * grid.y) {
             bl.counts = !(spec_fn && c->spec_shares);
             bl.swizzled = swizzle;
-            HIP_TRY(hipMalloc(&bl.d_ticks, 4u * bl.n * (bl.counts ? sizeof(uint4) : sizeof(uint32_t))));
+            const size_t nt = bl.n;
+            HIP_TRY(grow(&bl.d_ticks, &bl.ticks_cap, 4u * nt * (bl.counts ? sizeof(uint4) : sizeof(uint32_t))));
             if (bl.counts) {
                 copy_counts_to = bl.d_ticks;  // (after the launch, on its stream)
             } else {
-                HIP_TRY(hipMemsetAsync(bl.d_ticks, 0, 4u * bl.n * sizeof(uint32_t), stream));
+                HIP_TRY(hipMemsetAsync(bl.d_ticks, 0, 4u * nt * sizeof(uint32_t), stream));
                 d_ticks = bl.d_ticks;
             }
             bl.state = BlockList::TIMED;
-        } else if (bl.state == BlockList::REFINED && bl.d != nullptr) {
+        } else if (bl.state == BlockList::REFINED && bl.listed) {
             d_tiles = bl.d;
             grid = dim3((uint32_t)bl.n_listed, 1);
         }

@@ -114,3 +114,26 @@ def test_odd_and_tiny_frames(feedback_env, name, size):
             H.assert_images_equal(image, exp, "%s %dx%d frame %d" % (name, size[0], size[1], frame))
         assert r.stats()["rays"] == exp_rays, (name, size, frame)
     r.close()
+
+
+@pytest.mark.parametrize("name,size", [("mesh", (320, 240)), ("glass_and_mirror", (400, 304)), ("soft_shadows", (600, 248)), ("reflect_refract", (648, 328))])
+def test_a_camera_that_moves(feedback_env, name, size):
+    """An animation: rtc_ctx_set_scene with a new camera before every frame.  The block lists outlive the change of scene (same
+    frame size: restart_block_lists) -- each frame runs from the list the frames before made, is timed, and re-cuts the next --
+    and every frame is the new scene's image."""
+    import ray_tracer_challenge_amd as P
+    feedback_env(None)
+    world, camera0, depth = getattr(scenes, name)(*size)
+    r = _renderer(world, camera0)
+    for frame in range(7):
+        a = 0.03 * frame
+        camera = P.Camera(size[0], size[1], scenes.PI / np.float32(3.0),
+                          P.view_transform(P.point(0.2 + 3.0 * np.sin(a), 2.2, -5.5 * np.cos(a)), P.point(0, 0.8, 0), P.vector(0, 1, 0)))
+        exp, exp_rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=THREADS)
+        r.set_scene(world, camera)
+        for again in range(2 if frame % 3 == 2 else 1):  # (now and then the same scene twice: the early return of set_scene)
+            image = r.render(depth).cpu().numpy()
+            if not np.array_equal(image, exp):
+                H.assert_images_equal(image, exp, "%s frame %d.%d" % (name, frame, again))
+            assert r.stats()["rays"] == exp_rays, (name, frame, again)
+    r.close()
