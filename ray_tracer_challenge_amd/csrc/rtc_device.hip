@@ -894,9 +894,21 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
                     const float lo = std::fabs(g.bounds_min[a]), hi = std::fabs(g.bounds_max[a]);
                     big = (lo != lo || hi != hi) ? NAN : std::fmax(big, std::fmax(lo, hi));
                 }
+                // q of the pruning margin (kernel: for_each_object): 1e-6 over the smallest size of a sphere, cylinder or cone below
+                // this group -- the unit shape under its transform is at least 1 / |inverse 3x3| (Frobenius) across
+                float q = 0.0f;
+                for (uint32_t i = g.first_object; i < g.first_object + g.n_objects; i++) {
+                    const rtc_object& o = scene->objects[i];
+                    if (o.kind != RTC_SPHERE && o.kind != RTC_CYLINDER && o.kind != RTC_CONE) continue;
+                    double f2 = 0.0;
+                    for (int r = 0; r < 3; r++)
+                        for (int cidx = 0; cidx < 3; cidx++) f2 += (double)o.inv[4 * r + cidx] * o.inv[4 * r + cidx];
+                    const float qi = (float)(1e-6 * std::sqrt(f2));
+                    q = (qi != qi) ? q : std::fmax(q, qi);
+                }
                 trav.push_back(make_float4(g.bounds_min[0], g.bounds_min[1], g.bounds_min[2], 0.0f));
                 trav.push_back(make_float4(g.bounds_max[0], g.bounds_max[1], g.bounds_max[2], loose_group[gi] ? INFINITY : 1e-3f * big));
-                trav.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                trav.push_back(make_float4(q, 0.0f, 0.0f, 0.0f));
                 any = true;
                 gi++;
             }

@@ -1163,7 +1163,7 @@ DI void for_each_leaf_shared(const SceneHdr& H, const SceneSoA& S, WorldRay& wr,
             } else if (active) {
                 float tmin;
                 inside = aabb_hit(wr.o, wr.inv, make_float4(r0.x, r0.y, r0.z, r0.w), make_float4(r1.x, r1.y, r1.z, r1.w), tmin);
-                if (inside && tmin > wr.limit + (r1.w + 1e-4f * fabsf(wr.limit))) inside = false;
+                if (inside && tmin > wr.limit + (r1.w + 1e-4f * fabsf(wr.limit)) + ep[2].x * tmin * tmin) inside = false;  // (see for_each_object)
                 if (!inside) resume = skip;
             }
             k = __any(inside) ? k + 1u : skip;
@@ -1225,7 +1225,11 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
         // rounded inverse transform: a relative ~1e-6 of the coordinates), the computed entry parameter tmin is within
         // 3 ulp of the exact one, and the group is only left closed when tmin exceeds the limit by 1e-3 of the box's
         // largest coordinate (its `slack`, stored with the entry; infinite or NaN bounds never prune) plus 1e-4 of
-        // the limit -- three orders of magnitude more than those errors.
+        // the limit -- three orders of magnitude more than those errors.  One error is not relative to the coordinates: the
+        // quadratic of a sphere, cylinder or cone of size r met from a distance D cancels to D^2 / r^2 of its terms, and the
+        // distance the reference's f32 evaluation reports is off by eps D^2 / 2r -- two units for a sphere of 0.25 seen from
+        // 4 000 (a shade point far out on a plane, the light beside the sphere: fuzz world 84).  The entry's third record holds
+        // q = 1e-6 / (the smallest such r below the group), and q tmin^2 -- sixteen times that error -- is part of the margin.
         uint32_t resume = 0;  // this lane ignores entries below `resume`
         for (uint32_t k = 0; k < H.n_trav;) {
             // one address computation for the entry's three records (the walk executes as many scalar as vector instructions)
@@ -1247,7 +1251,7 @@ DI void for_each_object(const SceneHdr& H, const SceneSoA& S, WorldRay& wr, F&& 
                 } else if (active) {
                     float tmin;
                     inside = aabb_hit(wr.o, wr.inv, e0, e1, tmin);
-                    if (inside && tmin > wr.limit + (e1.w + 1e-4f * fabsf(wr.limit))) inside = false;  // nothing of interest in there
+                    if (inside && tmin > wr.limit + (e1.w + 1e-4f * fabsf(wr.limit)) + e2.x * tmin * tmin) inside = false;  // nothing of interest in there
                     if (!inside) resume = skip;
                 }
                 k = __any(inside) ? k + 1u : skip;

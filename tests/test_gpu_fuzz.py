@@ -197,7 +197,9 @@ def test_random_worlds_match_the_oracle(seed, monkeypatch):
         r.close()
 
 
-@pytest.mark.parametrize("seed", [3, 9, 14, 21, 24, 33, 38, 47])
+# 84: a shade point 4 000 units out on a plane whose shadow ray ends beside a small sphere -- the f32 quadratic is off by two units
+# there, and distance pruning used to skip the sphere's group (rtc_kernel_core.h for_each_object, the q tmin^2 term)
+@pytest.mark.parametrize("seed", [3, 9, 14, 21, 24, 33, 38, 47, 84])
 def test_random_worlds_at_a_size_that_takes_the_default_fast_paths(seed):
     """The same worlds at 640x420 (> 2^18 pixels) with nothing forced: whatever the library's own policies choose
     -- scene-compiled kernels, lanes per pixel by frame size, ... -- must render the oracle's image."""
