@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""development: one pixel of a fuzz world, stage by stage, device against oracle:  python tools/fuzz_probe.py 84 318 12"""
+"""development: one pixel of a fuzz world (tests/test_gpu_fuzz.py, 640x420) stage by stage, device against oracle -- the ray, the
+oracle's intersections, color_at, the hit's precomputed values, intensity_at(over_point) and every shadow ray of an area light:
+    python tools/fuzz_probe.py 84 318 12
+(how the one-pixel difference of world 84 was traced to a shadow ray that ends beside a small sphere, LABNOTES round 3)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,36 +14,29 @@ seed, x, y = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 world, cam, depth = T._world(seed, P)
 own, _, _ = T._world(seed, O)
 camera = P.Camera(640, 420, cam[2], cam[3])
-oc = H.oracle_camera(camera)
-o, d = oc.ray_for_pixel(x, y)
-po, pd = camera.ray_for_pixel(x, y)
-print("ray oracle", o, d, "api", po, pd, "equal", np.array_equal(o, po) and np.array_equal(d, pd))
-own.set_pixel(y * 640 + x) if hasattr(own, "set_pixel") else None
+o, d = H.oracle_camera(camera).ray_for_pixel(x, y)
 ts, objs = own.intersect(o, d)
-print("oracle intersections (t, obj):", [(float(t), int(i)) for t, i in zip(ts, objs)][:12], "depth", depth)
-print("oracle color_at", own.color_at(o, d, depth), "device color_at", world.color_at(o[None], d[None], depth)[0])
-hit = [(t, i) for t, i in zip(ts, objs) if t >= 0]
-if hit:
-    t, i = hit[0]
-    p = o + d * t
-    print("hit t %r obj %d point %s" % (float(t), int(i), p))
-    print("oracle intensity_at(point)", own.intensity_at(p), "device", world.intensity_at(p[None])[0])
-    lp = own.light_info()[0]
-    print("light", own.light_info())
-if hit:
-    leaves = world._c().leaves if hasattr(world._c(), "leaves") else None
-    shape = leaves[int(i)] if leaves is not None else None
-    print("object", int(i), type(shape).__name__ if shape is not None else None)
-    if shape is not None:
-        m = shape.material
-        print("material color", m.color, "ambient", m.ambient, "diffuse", m.diffuse, "specular", m.specular, "shininess", m.shininess, "pattern", type(m.pattern).__name__ if m.pattern is not None else None)
-        # over_point as the renderers form it needs the normal; compare the pattern at the hit point itself and nearby
-        if m.pattern is not None:
-            oleaves = own._leaves() if hasattr(own, "_leaves") else None
-            for q in (p, p + np.array([0, 1e-3, 0, 0], dtype=np.float32)):
-                try:
-                    dv = m.pattern.color_at_object(q[None], shape)[0]
-                except Exception as e:
-                    dv = repr(e)
-                print("  device pattern at", q[:3], dv)
-        print("device normal_at", shape.normal_at(p[None])[0] if hasattr(shape, "normal_at") else None)
+print("ray", o, d, "depth", depth)
+print("oracle intersections (t, object):", [(float(t), int(i)) for t, i in zip(ts, objs)][:12])
+print("color_at: oracle", own.color_at(o, d, depth), "device", world.color_at(o[None], d[None], depth)[0])
+hits = [k for k, t in enumerate(ts) if t >= 0]
+if hits:
+    c = own.precompute_values(o, d, hits[0], [(float(t), int(i)) for t, i in zip(ts, objs)])
+    for k, _t in c._fields_:
+        v = getattr(c, k)
+        print("  comps.%s" % k, np.array(v[:]) if hasattr(v, "__len__") else v)
+    op = np.array(c.over_point[:], dtype=np.float32)
+    print("intensity_at(over_point): oracle", own.intensity_at(op), "device", world.intensity_at(op[None])[0])
+    pos, u, v, cells = own.light_info()
+    if cells > 1:
+        us, vs = world.light.u_steps, world.light.v_steps
+        for vv in range(vs):
+            for uu in range(us):
+                lp = own.point_on_light(uu, vv)
+                so, sd = own.is_shadowed(lp, op), bool(world.is_shadowed(lp[None], op[None])[0])
+                print("  cell", uu, vv, "oracle shadowed", so, "device", sd, "" if sd == so else "<-- DIFFER")
+                if sd != so:
+                    dirv = lp - op
+                    dist = np.sqrt((dirv[:3] * dirv[:3]).sum(dtype=np.float32), dtype=np.float32)
+                    xs = own.intersect(op, (dirv / dist).astype(np.float32))
+                    print("     oracle intersections of that shadow ray:", [(float(t), int(i)) for t, i in zip(*xs)][:10], "light at", dist)
