@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <cerrno>
+#include <chrono>
 
 #include <algorithm>
 #include <array>
@@ -1169,7 +1170,8 @@ struct BlockList {  // RenderArgs::tiles of one partition (build_block_list), re
     // IDLE (regular grids): a scene's first frame -- nothing is measured before a second frame of the SAME scene shows that frames repeat
     enum { FRESH, TIMED, REFINED, IDLE } state = FRESH;
     uint32_t passes = 0;  // refinements so far
-    uint32_t scene_changes = 0;  // restart_block_lists
+    uint32_t scene_changes = 0;  // restart_block_lists: scenes since the last re-cut, and how many there may be before the next
+    uint32_t recut_every = 8;    // (recut_block_list: what a re-cut cost the host against what a frame takes)
 };
 struct rtc_ctx {
     int device = 0;
@@ -1214,6 +1216,10 @@ struct rtc_ctx {
     std::vector<float> texels_host;
     uint4* d_block_counts = nullptr;
     size_t block_cap = 0;
+    // pinned host memory through which the feedback reads wave times back and sends lists out (grow-only: through pageable vectors
+    // the two copies of a 2048^2 frame's re-cut took longer than the frame)
+    void* h_feedback = nullptr;
+    size_t h_feedback_cap = 0;
     // the level-by-level renderer (rtc_wavefront.h): ray lists (two levels x reflection / refraction), the node pool, counters
     WfRay* d_wf_rays[4] = {nullptr, nullptr, nullptr, nullptr};
     WfNode* d_wf_nodes = nullptr;
@@ -1238,10 +1244,11 @@ struct rtc_ctx {
 
 // A new scene of the same frame size (an animation: the camera or an object has moved): what a tile cost in the frame before is
 // still the best guess for what it costs now, and any list is a valid tiling for any scene.  The lists that cut tiles into lanes
-// (divided meshes, lane-sharing area lights) stay; every eighth scene a refined one is timed again by its next frame (which runs
-// from it as it is) and re-cut for the one after -- a re-cut costs the host about a millisecond, the lists age slowly (mesh 2048^2,
-// a quarter of a degree per frame: kernel 3.87 -> 3.3 - 3.6 ms; here_be_dragons 2000 x 800 2.69 -> 2.16; soft_shadows 1000 x 400 0.19 ->
-// 0.10; re-cut every other scene: mesh 3.00, and a millisecond of host time each).  A list whose timed frame belonged to the old scene is re-cut from that: it is the frame before.  A regular grid's
+// (divided meshes, lane-sharing area lights) stay; every few scenes a refined one is timed again by its next frame (which runs
+// from it as it is) and re-cut for the one after -- how often, recut_block_list decides from what the re-cut cost the host (a
+// read-back, a sort, an upload: 0.2 - 0.5 ms) against what a frame takes: the lists age slowly (mesh 2048^2, a quarter of a degree
+// per frame: kernel 3.87 -> 3.0 ms re-cut every other scene, 3.3 every fourth, 3.6 every eighth; here_be_dragons 2000 x 800 2.69 ->
+// 2.16; soft_shadows 1000 x 400 0.19 -> 0.10).  A list whose timed frame belonged to the old scene is re-cut from that: it is the frame before.  A regular grid's
 // ORDER does not survive: a stale order was slightly worse than the permuted image order (reflect_refract 0.839 -> 0.860 ms).
 static void restart_block_lists(rtc_ctx* c) {
     for (auto it = c->block_lists.begin(); it != c->block_lists.end();) {
@@ -1252,7 +1259,8 @@ static void restart_block_lists(rtc_ctx* c) {
             ++it;
             continue;
         }
-        if (bl.state == BlockList::REFINED && (++bl.scene_changes & 7u) == 0u) {
+        if (bl.state == BlockList::REFINED && ++bl.scene_changes >= bl.recut_every) {
+            bl.scene_changes = 0u;
             bl.state = BlockList::FRESH;
             bl.passes = c->policy.feedback_passes ? c->policy.feedback_passes - 1u : 0u;
         }
@@ -1546,6 +1554,7 @@ void rtc_ctx_destroy(rtc_ctx* c) {
     if (c->d_ppm_rows) (void)hipFree(c->d_ppm_rows);
     if (c->d_ppm_bits) (void)hipFree(c->d_ppm_bits);
     drop_block_lists(c);
+    if (c->h_feedback) (void)hipHostFree(c->h_feedback);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -1682,8 +1691,8 @@ static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t w
 // taken to shorten its waves to 0.7 (measured: tools/sweep_block_s.sh), and the tiles start in the order of their predicted
 // longest wave.  Which lanes trace a pixel and when changes nothing about its value (tests/test_gpu_fullsize.py compares first
 // and later frames with the oracle).
-static void refine_block_list(const std::vector<uint32_t>& list, const std::vector<uint32_t>& ticks, uint32_t width, uint32_t rows, double wave_slots,
-                              double threshold, double down, std::vector<uint32_t>* out, uint32_t max_s = 4u) {
+static void refine_block_list(const std::vector<uint32_t>& list, const uint32_t* ticks /* [4 list.size()] */, uint32_t width, uint32_t rows, double wave_slots,
+                              double threshold, double down, std::vector<uint32_t>* out, uint32_t max_s = 4u, double* throughput_ticks = nullptr) {
     struct Tile {
         uint32_t x0, y0, s;
         uint64_t longest = 0;
@@ -1692,7 +1701,7 @@ static void refine_block_list(const std::vector<uint32_t>& list, const std::vect
     const uint32_t tw = (width + 15u) / 16u;
     std::vector<Tile> tiles;
     std::vector<int32_t> index((size_t)tw * ((rows + 15u) / 16u), -1);
-    double total = 0.0;
+    uint64_t total = 0u;  // (an integer: a chain of double additions, four per block, was most of this loop's time)
     for (size_t b = 0; b < list.size(); b++) {
         const uint32_t t = list[b], x0 = tile_x0(t), y0 = tile_y0(t);
         if (x0 >= width || y0 >= rows) continue;  // (a padded grid's blocks outside the image)
@@ -1704,21 +1713,42 @@ static void refine_block_list(const std::vector<uint32_t>& list, const std::vect
             tiles.push_back(n);
         }
         Tile& tile = tiles[(size_t)slot];
-        for (uint32_t w = 0; w < 4u; w++) {
-            const uint32_t d = ticks[4u * b + w];
-            tile.longest = std::max<uint64_t>(tile.longest, d);
-            total += d;
-        }
+        const uint32_t* d = ticks + 4u * b;  // (the block's four waves)
+        tile.longest = std::max<uint64_t>(tile.longest, std::max(std::max(d[0], d[1]), std::max(d[2], d[3])));
+        total += (uint64_t)d[0] + d[1] + d[2] + d[3];
     }
-    const double throughput = total / std::max(1.0, wave_slots);  // ticks the frame takes if the work were spread evenly
+    const double throughput = (double)total / std::max(1.0, wave_slots);  // ticks the frame takes if the work were spread evenly
+    if (throughput_ticks) *throughput_ticks = throughput;
     for (Tile& t : tiles) {
         t.predicted = (double)t.longest;
         while (t.s < max_s && t.predicted > threshold * throughput) t.s++, t.predicted *= 0.7;  // (up to sixteen lanes per pixel)
         while (t.s > 0u && t.predicted / 0.7 < down * throughput) t.s--, t.predicted /= 0.7;
     }
-    std::vector<uint32_t> order(tiles.size());
-    for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return tiles[a].predicted > tiles[b].predicted; });
+    // the tiles by predicted longest wave, longest first, equal ones in list order: a radix sort of the (non-negative) doubles' bit
+    // patterns, 16 bits a pass, passes whose digit is the same everywhere skipped -- a comparison sort of 16 384 tiles cost the host
+    // 2 ms in front of the frame that waits for the list, this a tenth of that
+    std::vector<uint32_t> order(tiles.size()), other(tiles.size());
+    {
+        std::vector<uint64_t> key(tiles.size());
+        uint64_t all_or = 0u, all_and = ~(uint64_t)0u;
+        for (uint32_t i = 0; i < order.size(); i++) {
+            const double pr = tiles[i].predicted > 0.0 ? tiles[i].predicted : 0.0;
+            uint64_t k;
+            std::memcpy(&k, &pr, sizeof(k));
+            key[i] = ~k;  // (ascending in ~k = descending in the prediction)
+            all_or |= key[i], all_and &= key[i];
+            order[i] = i;
+        }
+        std::vector<uint32_t> count(65537u);
+        for (uint32_t shift = 0u; shift < 64u; shift += 16u) {
+            if ((((all_or ^ all_and) >> shift) & 0xffffu) == 0u) continue;
+            std::fill(count.begin(), count.end(), 0u);
+            for (uint32_t i : order) count[((key[i] >> shift) & 0xffffu) + 1u]++;
+            for (uint32_t d = 0u; d < 65536u; d++) count[d + 1u] += count[d];
+            for (uint32_t i : order) other[count[(key[i] >> shift) & 0xffffu]++] = i;
+            order.swap(other);
+        }
+    }
     out->clear();
     for (uint32_t i : order) {
         const Tile& t = tiles[i];
@@ -1753,6 +1783,18 @@ static hipError_t grow(uint32_t** p, size_t* cap, size_t bytes) {
     if (e == hipSuccess) *cap = want;
     return e;
 }
+static hipError_t feedback_staging(rtc_ctx* c, size_t bytes, void** p) {  // (the caller has synchronised the device: nothing is using the old one)
+    if (c->h_feedback == nullptr || c->h_feedback_cap < bytes) {
+        if (c->h_feedback) (void)hipHostFree(c->h_feedback);
+        c->h_feedback = nullptr, c->h_feedback_cap = 0;
+        const size_t want = std::max<size_t>(1u << 16, bytes + bytes / 2);
+        hipError_t e = hipHostMalloc(&c->h_feedback, want, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        c->h_feedback_cap = want;
+    }
+    *p = c->h_feedback;
+    return hipSuccess;
+}
 static int compute_units(rtc_ctx* c) {  // of the context's device (asked once: the query takes a fraction of a millisecond)
     if (c->n_cus == 0) {
         hipDeviceProp_t prop;
@@ -1766,10 +1808,15 @@ static int compute_units(rtc_ctx* c) {  // of the context's device (asked once: 
 static rtc_status recut_block_list(rtc_ctx* c, BlockList& bl, uint32_t rows) {
     const Policy& P = c->policy;
     HIP_TRY(hipDeviceSynchronize());  // (once per scene, partition and pass; the launch may be on any stream)
-    std::vector<uint32_t> ticks(4u * bl.n), refined;
-    HIP_TRY(hipMemcpy(ticks.data(), bl.d_ticks, ticks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const auto host_t0 = std::chrono::steady_clock::now();  // (after the wait for the frame, which the caller's next step would have had anyway)
+    std::vector<uint32_t> refined;
+    double throughput_ticks = 0.0;
+    void* staging = nullptr;
+    HIP_TRY(feedback_staging(c, 4u * bl.n * sizeof(uint32_t), &staging));
+    const uint32_t* ticks = (const uint32_t*)staging;
+    HIP_TRY(hipMemcpy(staging, bl.d_ticks, 4u * bl.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     refine_block_list(bl.host, ticks, c->hdr.width, rows, 0.85 * 4.0 * compute_units(c) * P.tree_waves, 0.01 * P.feedback_pct, 0.01 * P.feedback_down_pct,
-                      &refined, P.feedback_max_s);
+                      &refined, P.feedback_max_s, &throughput_ticks);
     if (P.jit_print) {
         size_t by_s[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};  // blocks by lanes per pixel (log2), before and after
         for (uint32_t t : bl.host.empty() ? refined : bl.host) by_s[0][tile_s(t)]++;
@@ -1780,12 +1827,20 @@ static rtc_status recut_block_list(rtc_ctx* c, BlockList& bl, uint32_t rows) {
                      by_s[1][4] * 16 / 1000);
     }
     HIP_TRY(grow(&bl.d, &bl.d_cap, refined.size() * sizeof(uint32_t)));  // (nothing is in flight: the synchronisation above)
-    HIP_TRY(hipMemcpy(bl.d, refined.data(), refined.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(feedback_staging(c, refined.size() * sizeof(uint32_t), &staging));  // (the times have been used)
+    std::memcpy(staging, refined.data(), refined.size() * sizeof(uint32_t));
+    HIP_TRY(hipMemcpy(bl.d, staging, refined.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     bl.n = refined.size();
     bl.passes++;
     bl.host = refined;  // (kept: a later scene of this size starts from it, restart_block_lists)
     bl.state = bl.passes < P.feedback_passes ? BlockList::FRESH /* time this list's first launch as well */ : BlockList::REFINED;
-
+    // How often scenes that change (restart_block_lists) may have the list re-cut: what this re-cut cost the host may be a
+    // sixteenth of the frames between -- their time taken from below: the waves' times over the device's wave slots (the timer runs
+    // at 100 MHz).
+    const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+    const double frame_ms = std::max(1e-3, throughput_ticks * 1e-5);
+    bl.recut_every = (uint32_t)std::min(16.0, std::max(2.0, std::ceil(16.0 * host_ms / frame_ms)));
+    if (P.jit_print) std::fprintf(stderr, "librtc_amd: the re-cut took the host %.3f ms, a frame takes %.3f ms or more: scenes that change re-cut every %u\n", host_ms, frame_ms, bl.recut_every);
     return RTC_OK;
 }
 
@@ -1798,15 +1853,21 @@ static rtc_status order_grid(rtc_ctx* c, BlockList& bl, uint32_t gx, uint32_t gy
     const Policy& P = c->policy;
     HIP_TRY(hipDeviceSynchronize());  // (once per scene and partition)
     const size_t nt = bl.n;  // the blocks of the timed launch: the (padded) grid's
-    std::vector<uint32_t> ticks(4u * nt), launched(nt), ordered;
+    std::vector<uint32_t> launched(nt), ordered;
+    void* staging = nullptr;
+    HIP_TRY(feedback_staging(c, 4u * nt * sizeof(uint4), &staging));
+    uint32_t* ticks = (uint32_t*)staging;
     if (bl.counts) {
         // what a wave cost, from what it counted: rays that met objects, and shade points (each a light-cone cull, a Phong
         // evaluation, a push or pop of the recursion) at sixteen rays apiece
-        std::vector<uint4> counts(4u * nt);
-        HIP_TRY(hipMemcpy(counts.data(), bl.d_ticks, counts.size() * sizeof(uint4), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < counts.size(); i++) ticks[i] = (counts[i].x - std::min(counts[i].x, counts[i].z)) + 16u * counts[i].y + counts[i].z / 8u;
+        const uint4* counts = (const uint4*)staging;
+        HIP_TRY(hipMemcpy(staging, bl.d_ticks, 4u * nt * sizeof(uint4), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < 4u * nt; i++) {  // (in place: ticks[i] overwrites a word of counts[i / 4], which has been read)
+            const uint4 n = counts[i];
+            ticks[i] = (n.x - std::min(n.x, n.z)) + 16u * n.y + n.z / 8u;
+        }
     } else {
-        HIP_TRY(hipMemcpy(ticks.data(), bl.d_ticks, ticks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(staging, bl.d_ticks, 4u * nt * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     for (uint32_t by = 0; by < gy; by++)
         for (uint32_t bx = 0; bx < gx; bx++) {  // the block workgroup (bx, by) rendered: the kernel's permutation
@@ -1834,7 +1895,8 @@ static rtc_status order_grid(rtc_ctx* c, BlockList& bl, uint32_t gx, uint32_t gy
     refine_block_list(launched, ticks, c->hdr.width, rows, wave_slots, INFINITY, 0.0, &ordered);
     if (ordered.empty() || ordered.size() > bl.n) return RTC_OK;
     HIP_TRY(grow(&bl.d, &bl.d_cap, ordered.size() * sizeof(uint32_t)));  // (nothing is in flight: the synchronisation above)
-    HIP_TRY(hipMemcpy(bl.d, ordered.data(), ordered.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    std::memcpy(staging, ordered.data(), ordered.size() * sizeof(uint32_t));  // (the times have been used; ordered.size() <= nt)
+    HIP_TRY(hipMemcpy(bl.d, staging, ordered.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     bl.n_listed = ordered.size();
     bl.listed = true;
     return RTC_OK;
@@ -2644,8 +2706,8 @@ extern "C" {
 // rtc_ctx_render uses them.  -> the number of blocks of the new list (its first min(that, cap) are written to `out`).
 uint32_t rtc_diag_refine_block_list(const uint32_t* list, const uint32_t* ticks, uint32_t n, uint32_t width, uint32_t rows, double wave_slots,
                                     double threshold, double down, uint32_t* out, uint32_t cap) {
-    std::vector<uint32_t> l(list, list + n), t(ticks, ticks + 4u * (size_t)n), refined;
-    refine_block_list(l, t, width, rows, wave_slots, threshold, down, &refined);
+    std::vector<uint32_t> l(list, list + n), refined;
+    refine_block_list(l, ticks, width, rows, wave_slots, threshold, down, &refined);
     for (size_t i = 0; i < refined.size() && i < cap; i++) out[i] = refined[i];
     return (uint32_t)refined.size();
 }
