@@ -326,7 +326,9 @@ void rtc_host_free(void* p);
  * (it synchronises the device), so it may be called right after an asynchronous render. */
 rtc_status rtc_ctx_create(int32_t device, rtc_ctx** out);
 void rtc_ctx_destroy(rtc_ctx* ctx);
-/* Flattens the scene to structure-of-arrays records and uploads it. */
+/* Flattens the scene to structure-of-arrays records and uploads it.  Called again with the scene that is resident: nothing
+ * happens; with records that are resident and another camera (an animation's usual frame): nothing is uploaded; with a scene
+ * of the same frame size: what the frames before measured stays the schedule's starting point. */
 rtc_status rtc_ctx_set_scene(rtc_ctx* ctx, const rtc_scene* scene, const rtc_camera* camera);
 /* Rows this partition produces (sum of its bands' heights). */
 uint32_t rtc_partition_rows(uint32_t height, const rtc_partition* part);

@@ -1946,27 +1946,33 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     const bool same_frame = c->has_scene && c->hdr.width == hdr.width && c->hdr.height == hdr.height;  // (block lists: below)
     // until the new scene is fully resident the context has none: a failed allocation below must not leave a stale
     // capacity beside a null pointer, nor a render path that believes the old scene is still there
+    // (only the camera has moved -- an animation's usual frame: the records and texels that are resident stay)
+    const bool same_records = c->has_scene && soa.size() == c->soa_host.size() && texels.size() == c->texels_host.size() &&
+                              std::memcmp(soa.data(), c->soa_host.data(), soa.size() * sizeof(float4)) == 0 &&
+                              (texels.empty() || std::memcmp(texels.data(), c->texels_host.data(), texels.size() * sizeof(float)) == 0);
     c->has_scene = false;
     c->spec_fn = nullptr;
     c->jit_note.clear();
-    c->soa_host.clear();
-    c->texels_host.clear();
-    if (texels.size() > c->texel_cap) {
-        if (c->d_texels) (void)hipFree(c->d_texels);
-        c->d_texels = nullptr;
-        c->texel_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_texels, texels.size() * sizeof(float)));
-        c->texel_cap = texels.size();
+    if (!same_records) {
+        c->soa_host.clear();
+        c->texels_host.clear();
+        if (texels.size() > c->texel_cap) {
+            if (c->d_texels) (void)hipFree(c->d_texels);
+            c->d_texels = nullptr;
+            c->texel_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_texels, texels.size() * sizeof(float)));
+            c->texel_cap = texels.size();
+        }
+        if (!texels.empty()) HIP_TRY(hipMemcpy(c->d_texels, texels.data(), texels.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (soa.size() > c->soa_cap) {
+            if (c->d_soa) (void)hipFree(c->d_soa);
+            c->d_soa = nullptr;
+            c->soa_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_soa, soa.size() * sizeof(float4)));
+            c->soa_cap = soa.size();
+        }
+        HIP_TRY(hipMemcpy(c->d_soa, soa.data(), soa.size() * sizeof(float4), hipMemcpyHostToDevice));
     }
-    if (!texels.empty()) HIP_TRY(hipMemcpy(c->d_texels, texels.data(), texels.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (soa.size() > c->soa_cap) {
-        if (c->d_soa) (void)hipFree(c->d_soa);
-        c->d_soa = nullptr;
-        c->soa_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_soa, soa.size() * sizeof(float4)));
-        c->soa_cap = soa.size();
-    }
-    HIP_TRY(hipMemcpy(c->d_soa, soa.data(), soa.size() * sizeof(float4), hipMemcpyHostToDevice));
     c->hdr = hdr;
     c->n_objects = hdr.n_objects;
     c->simple = !hdr.has_patterns;
@@ -1977,8 +1983,10 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         if (!(bits & SHAPE_DIAG) || kind == RTC_CYLINDER || kind == RTC_CONE || kind == RTC_TRIANGLE) c->simple = false;
     }
     c->has_scene = true;
-    c->soa_host = soa;
-    c->texels_host = texels;
+    if (!same_records) {
+        c->soa_host = soa;
+        c->texels_host = texels;
+    }
     if (same_frame && P.block_feedback) restart_block_lists(c);
     else drop_block_lists(c);  // (nothing is in flight any more: the synchronisation above)
     c->deep_fn.clear();

@@ -30,6 +30,14 @@ class Renderer:
         L.check(self._lib.rtc_ctx_set_scene(self._ctx, C.byref(cs.scene), C.byref(camera._cam)))
         self.width, self.height = camera.width, camera.height
 
+    def set_camera(self, camera):
+        """Another camera on the world that is resident (an animation's usual frame): the world is not flattened again on the
+        Python side, and the library, finding the records unchanged, uploads none of them."""
+        cs = self._keep[0]
+        self._keep = (cs, camera)
+        L.check(self._lib.rtc_ctx_set_scene(self._ctx, C.byref(cs.scene), C.byref(camera._cam)))
+        self.width, self.height = camera.width, camera.height
+
     def close(self):
         if self._ctx:
             self._lib.rtc_ctx_destroy(self._ctx)

@@ -137,3 +137,34 @@ def test_a_camera_that_moves(feedback_env, name, size):
                 H.assert_images_equal(image, exp, "%s frame %d.%d" % (name, frame, again))
             assert r.stats()["rays"] == exp_rays, (name, frame, again)
     r.close()
+
+
+@pytest.mark.parametrize("name,size", [("soft_shadows", (600, 248)), ("mesh", (320, 240)), ("first_textures", (512, 256))])
+def test_cameras_and_objects_that_move_in_turn(feedback_env, name, size):
+    """Frames whose camera alone has moved keep the records that are resident (Renderer.set_camera; rtc_ctx_set_scene uploads
+    nothing when the records are the same); frames in which an object has moved replace them -- in turn, every frame against
+    the oracle."""
+    import ray_tracer_challenge_amd as P
+    feedback_env(None)
+    world, camera, depth = getattr(scenes, name)(*size)
+    r = _renderer(world, camera)
+    mover = [o for o in world.objects if not isinstance(o, P.GroupShape)][-1]
+    t0 = mover.transform.copy()
+    try:
+        for frame in range(8):
+            if frame % 3 == 1:  # an object moves (the camera stays)
+                mover.set_transformation(P.translation(0.05 * frame, 0.0, 0.02 * frame) @ t0)
+                r.set_scene(world, camera)
+            else:  # the camera moves (the world stays)
+                a = 0.03 * frame
+                camera = P.Camera(size[0], size[1], scenes.PI / np.float32(3.0),
+                                  P.view_transform(P.point(0.2 + 3.0 * np.sin(a), 2.2, -5.5 * np.cos(a)), P.point(0, 0.8, 0), P.vector(0, 1, 0)))
+                r.set_camera(camera)
+            exp, exp_rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=THREADS)
+            image = r.render(depth).cpu().numpy()
+            if not np.array_equal(image, exp):
+                H.assert_images_equal(image, exp, "%s frame %d" % (name, frame))
+            assert r.stats()["rays"] == exp_rays, (name, frame)
+    finally:
+        mover.set_transformation(t0)
+        r.close()
