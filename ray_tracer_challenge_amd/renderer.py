@@ -63,8 +63,9 @@ class Renderer:
         """Launches the render kernel on `stream` (default: torch's current stream); asynchronous."""
         if out is None:
             out = self.alloc(part)
-        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
-        assert out.numel() == self.rows(part) * self.width * 3
+        # (checked, not asserted: the raw pointer goes to a kernel that writes rows x width x 3 floats through it)
+        if not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == self.rows(part) * self.width * 3):
+            raise ValueError("out must be a contiguous float32 CUDA tensor of %d x %d x 3" % (self.rows(part), self.width))
         s = torch.cuda.current_stream(self.device) if stream is None else stream
         L.check(self._lib.rtc_ctx_render(self._ctx, int(depth), C.byref(part) if part is not None else None,
                                        C.c_void_p(out.data_ptr()), C.c_void_p(s.cuda_stream)))
@@ -94,7 +95,8 @@ class Renderer:
 
     def to_ppm(self, rgb, stream=None):
         """Canvas::to_ppm (canvas.rs:58-96) formatted on the device from an (h, w, 3) f32 tensor -> bytes."""
-        assert rgb.is_cuda and rgb.dtype == torch.float32 and rgb.is_contiguous() and rgb.dim() == 3
+        if not (rgb.is_cuda and rgb.dtype == torch.float32 and rgb.is_contiguous() and rgb.dim() == 3):
+            raise ValueError("rgb must be a contiguous float32 CUDA tensor (rows, width, 3)")
         h, w = int(rgb.shape[0]), int(rgb.shape[1])
         cap = int(self._lib.rtc_ppm_max_bytes(w, h))
         text = torch.empty(cap, dtype=torch.uint8, device=rgb.device)
@@ -108,7 +110,9 @@ class Renderer:
         """canvas.rs:39-43 scale_color on the device: f32 tensor -> u8 tensor of the same shape."""
         if out is None:
             out = torch.empty(rgb.shape, dtype=torch.uint8, device=rgb.device)
-        assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() == rgb.numel()
+        if not (rgb.is_cuda and rgb.dtype == torch.float32 and rgb.is_contiguous() and out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and
+                out.numel() == rgb.numel()):
+            raise ValueError("rgb: a contiguous float32 CUDA tensor; out: a contiguous uint8 CUDA tensor with one byte per colour value of rgb")
         s = torch.cuda.current_stream(self.device) if stream is None else stream
         L.check(self._lib.rtc_ctx_quantize(self._ctx, C.c_void_p(rgb.data_ptr()), rgb.numel(),
                                          C.c_void_p(out.data_ptr()), C.c_void_p(s.cuda_stream)))
