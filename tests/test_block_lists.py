@@ -86,6 +86,20 @@ def test_tiles_start_in_the_order_of_their_longest_wave():
     assert seq == sorted(seq, reverse=True) and len(new) == len(lst)
 
 
+@pytest.mark.parametrize("seed,top", [(1, 4), (2, 300), (3, 2 ** 31), (4, 2 ** 32 - 1)])
+def test_equal_tiles_keep_their_order_in_the_list(seed, top):
+    """The order is a stable one (a radix sort of the predictions' bit patterns): tiles of equal longest wave start in the order
+    the list had them -- few distinct values, and values across the whole range of the tick counter."""
+    width, rows = 512, 256
+    lst = _list(width, rows, lambda tx, ty: 0)
+    rng = np.random.default_rng(seed)
+    ticks = rng.integers(0, top, size=4 * len(lst), endpoint=True).astype(np.uint32)
+    new = _refine(lst, ticks, width, rows, 1e12, float("inf"), 0.0)
+    longest = [int(ticks[4 * i:4 * i + 4].max()) for i in range(len(lst))]
+    expected = [int(lst[i]) for i in sorted(range(len(lst)), key=lambda i: -longest[i])]  # (sorted() is stable)
+    assert new.tolist() == expected
+
+
 def test_blocks_of_a_padded_grid_outside_the_image_are_left_out():
     width, rows = 40, 24  # a grid padded to 4 x 4 blocks of 16 x 16 holds blocks that start outside the image
     lst = np.array([(bx * 4) << 16 | (by * 4) for by in range(4) for bx in range(4)], dtype=np.uint32)
