@@ -1170,8 +1170,14 @@ struct BlockList {  // RenderArgs::tiles of one partition (build_block_list), re
     // IDLE (regular grids): a scene's first frame -- nothing is measured before a second frame of the SAME scene shows that frames repeat
     enum { FRESH, TIMED, REFINED, IDLE } state = FRESH;
     uint32_t passes = 0;  // refinements so far
-    uint32_t scene_changes = 0;  // restart_block_lists: scenes since the last re-cut, and how many there may be before the next
-    uint32_t recut_every = 8;    // (recut_block_list: what a re-cut cost the host against what a frame takes)
+    // Scenes that change (restart_block_lists): once a scene has changed under a refined list, every frame from it leaves its waves'
+    // times and is bracketed by the list's own events; what the frames since the last re-cut took beyond the best of them adds up
+    // (loss_ms), and when that reaches what a re-cut costs the host (recut_host_ms, measured) the next frame re-cuts the list from
+    // the times of the frame before it -- at the latest after sixteen scenes.
+    uint32_t scene_changes = 0;
+    bool animated = false, ev_recorded = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double best_ms = 0.0, loss_ms = 0.0, recut_host_ms = 0.5;
 };
 struct rtc_ctx {
     int device = 0;
@@ -1244,11 +1250,12 @@ struct rtc_ctx {
 
 // A new scene of the same frame size (an animation: the camera or an object has moved): what a tile cost in the frame before is
 // still the best guess for what it costs now, and any list is a valid tiling for any scene.  The lists that cut tiles into lanes
-// (divided meshes, lane-sharing area lights) stay; every few scenes a refined one is timed again by its next frame (which runs
-// from it as it is) and re-cut for the one after -- how often, recut_block_list decides from what the re-cut cost the host (a
-// read-back, a sort, an upload: 0.2 - 0.5 ms) against what a frame takes: the lists age slowly (mesh 2048^2, a quarter of a degree
-// per frame: kernel 3.87 -> 3.0 ms re-cut every other scene, 3.3 every fourth, 3.6 every eighth; here_be_dragons 2000 x 800 2.69 ->
-// 2.16; soft_shadows 1000 x 400 0.19 -> 0.10).  A list whose timed frame belonged to the old scene is re-cut from that: it is the frame before.  A regular grid's
+// (divided meshes, lane-sharing area lights) stay, and from then on every frame from a refined list leaves its waves' times and is
+// bracketed by the list's own events: what the frames since the last re-cut took beyond the best of them adds up, and when that
+// reaches what a re-cut costs the host (a read-back, a sort, an upload: 0.2 - 0.5 ms, measured) the next frame starts with a re-cut
+// from the times of the frame before it -- rent until the rent equals the price.  Lists age at their own pace (mesh 2048^2, a
+// quarter of a degree per frame: 0.1 - 0.3 ms per frame, re-cut every 2 - 9 scenes, kernel 3.85 -> 2.97 ms; soft_shadows 2048^2:
+// hardly, every sixteenth -- the cap); a fixed period was wrong for one or the other (every eighth: mesh 3.57 with frames of 5).  A list whose timed frame belonged to the old scene is re-cut from that: it is the frame before.  A regular grid's
 // ORDER does not survive: a stale order was slightly worse than the permuted image order (reflect_refract 0.839 -> 0.860 ms).
 static void restart_block_lists(rtc_ctx* c) {
     for (auto it = c->block_lists.begin(); it != c->block_lists.end();) {
@@ -1259,10 +1266,26 @@ static void restart_block_lists(rtc_ctx* c) {
             ++it;
             continue;
         }
-        if (bl.state == BlockList::REFINED && ++bl.scene_changes >= bl.recut_every) {
-            bl.scene_changes = 0u;
-            bl.state = BlockList::FRESH;
-            bl.passes = c->policy.feedback_passes ? c->policy.feedback_passes - 1u : 0u;
+        if (bl.state == BlockList::REFINED) {
+            bl.animated = true;
+            bool recut = ++bl.scene_changes >= 16u, timed = false;
+            if (bl.ev_recorded) {  // the frame before ran from this list (rtc_ctx_set_scene has waited for it)
+                bl.ev_recorded = false;
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, bl.ev0, bl.ev1) == hipSuccess && ms > 0.0f) {
+                    timed = true;
+                    if (bl.best_ms == 0.0 || ms < bl.best_ms) bl.best_ms = ms;
+                    bl.loss_ms += ms - bl.best_ms;
+                    if (bl.loss_ms >= bl.recut_host_ms) recut = true;
+                }
+            }
+            if (recut) {
+                bl.scene_changes = 0u;
+                bl.best_ms = bl.loss_ms = 0.0;
+                // (timed: that frame's times are on the device -- the next frame starts with the re-cut; else it is timed first)
+                bl.state = timed ? BlockList::TIMED : BlockList::FRESH;
+                bl.passes = c->policy.feedback_passes ? c->policy.feedback_passes - 1u : 0u;
+            }
         }
         ++it;
     }
@@ -1272,6 +1295,8 @@ static void drop_block_lists(rtc_ctx* c) {
     for (auto& bl : c->block_lists) {
         if (bl.second.d) (void)hipFree(bl.second.d);
         if (bl.second.d_ticks) (void)hipFree(bl.second.d_ticks);
+        if (bl.second.ev0) (void)hipEventDestroy(bl.second.ev0);
+        if (bl.second.ev1) (void)hipEventDestroy(bl.second.ev1);
     }
     c->block_lists.clear();
 }
@@ -1839,8 +1864,8 @@ static rtc_status recut_block_list(rtc_ctx* c, BlockList& bl, uint32_t rows) {
     // at 100 MHz).
     const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     const double frame_ms = std::max(1e-3, throughput_ticks * 1e-5);
-    bl.recut_every = (uint32_t)std::min(16.0, std::max(2.0, std::ceil(16.0 * host_ms / frame_ms)));
-    if (P.jit_print) std::fprintf(stderr, "librtc_amd: the re-cut took the host %.3f ms, a frame takes %.3f ms or more: scenes that change re-cut every %u\n", host_ms, frame_ms, bl.recut_every);
+    bl.recut_host_ms = std::max(0.05, host_ms);
+    if (P.jit_print) std::fprintf(stderr, "librtc_amd: the re-cut took the host %.3f ms (a frame takes %.3f ms or more)\n", host_ms, frame_ms);
     return RTC_OK;
 }
 
@@ -2392,6 +2417,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     // lanes per pixel there and one elsewhere (build_block_list).  Not when RTC_AMD_SHARE_LOG2 pins one value for all.
     const uint32_t* d_tiles = nullptr;
     uint32_t* d_ticks = nullptr;
+    BlockList* timed_list = nullptr;  // a list whose own events bracket this launch
     void* copy_counts_to = nullptr;
     const bool mesh_list = spec_fn && c->spec_shares && !c->heavy_tiles.empty() && c->hdr.light_kind == RTC_LIGHT_POINT;
     // ... and frames that share an area light's cells between a pixel's lanes (small frames: choose_share_log2), when there is a
@@ -2438,11 +2464,20 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             const rtc_status st = recut_block_list(c, bl, rows);
             if (st != RTC_OK) return st;
         }
-        if (P.block_feedback && bl.state == BlockList::FRESH && bl.n != 0) {
+        // (a refined list under scenes that change: every frame is timed -- restart_block_lists decides from them when to re-cut)
+        if (P.block_feedback && (bl.state == BlockList::FRESH || (bl.state == BlockList::REFINED && bl.animated)) && bl.n != 0) {
             HIP_TRY(grow(&bl.d_ticks, &bl.ticks_cap, 4u * bl.n * sizeof(uint32_t)));
             HIP_TRY(hipMemsetAsync(bl.d_ticks, 0, 4u * bl.n * sizeof(uint32_t), stream));
             d_ticks = bl.d_ticks;
-            bl.state = BlockList::TIMED;
+            if (bl.state == BlockList::FRESH) {
+                bl.state = BlockList::TIMED;
+            } else {
+                if (bl.ev0 == nullptr) {
+                    HIP_TRY(hipEventCreate(&bl.ev0));
+                    HIP_TRY(hipEventCreate(&bl.ev1));
+                }
+                timed_list = &bl;
+            }
         }
         d_tiles = it->second.d;
         grid = dim3((uint32_t)it->second.n, 1);
@@ -2662,6 +2697,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     }
     auto& ev = c->events[c->events_used++];
     HIP_TRY(hipEventRecord(ev.first, stream));
+    if (timed_list) HIP_TRY(hipEventRecord(timed_list->ev0, stream));
     // instantiation: <= 4 / <= 8 objects get fully unrolled object loops (SIMPLE: all of them
     // scale+translate-only, no cylinder); anything larger takes the generic loop
     if (spec_fn) {
@@ -2674,6 +2710,10 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     else if (c->n_objects <= 8) hipLaunchKernelGGL((render_kernel<8, false>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, 0, stream, a);
     HIP_TRY(hipEventRecord(ev.second, stream));
+    if (timed_list) {
+        HIP_TRY(hipEventRecord(timed_list->ev1, stream));
+        timed_list->ev_recorded = true;
+    }
     if (copy_counts_to) HIP_TRY(hipMemcpyAsync(copy_counts_to, c->d_block_counts, n_blocks * sizeof(uint4), hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(sum_counts_kernel, dim3((uint32_t)((n_blocks + SUM_COUNTS_SLICE - 1) / SUM_COUNTS_SLICE)), dim3(1024), 0, stream,
                        c->d_block_counts, (uint32_t)n_blocks, c->d_total + 3 * (size_t)slot, extra_rays);

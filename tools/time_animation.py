@@ -39,6 +39,8 @@ for mode in ("1", "0", "1", "0"):
         wall.append((time.perf_counter() - t0) * 1e3)
         kernel.append(st["kernel_ms"])
     r.close()
+    if os.environ.get("ANIMATION_SERIES"):
+        print("feedback=%s kernel ms per frame:" % mode, " ".join("%.2f" % k for k in kernel), flush=True)
     wl = np.array(wall[4:])
     print("%s %dx%d feedback=%s: kernel ms per frame, frames 5..%d: mean %.3f (min %.3f max %.3f); wall ms incl. %s: median %.2f mean %.2f, the three longest %s (frames %s)" % (
         name, w, h, mode, frames, np.mean(kernel[4:]), np.min(kernel[4:]), np.max(kernel[4:]), "set_camera" if camera_only else "set_scene", np.median(wl), np.mean(wl),
