@@ -22,6 +22,9 @@ def camera(frame):
     return P.Camera(w, h, scenes.PI / np.float32(3.0), P.view_transform(P.point(0.2 + 3.0 * np.sin(a), 2.2, -5.5 * np.cos(a)), P.point(0, 0.8, 0), P.vector(0, 1, 0)))
 
 
+from ray_tracer_challenge_amd import _lib
+if os.environ.get("ANIMATION_DEV_LIB"):  # development switches (RTC_AMD_FEEDBACK_*) live in the development build only
+    _lib._lib = _lib.load(_lib.DEV_LIB_PATH)
 for mode in ("1", "0", "1", "0"):
     os.environ["RTC_AMD_BLOCK_FEEDBACK"] = mode
     r = Renderer(world, camera(0), device=0)
