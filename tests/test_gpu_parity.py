@@ -571,3 +571,25 @@ def test_nodes_at_a_frame_size_that_builds_them_by_default(name, monkeypatch):
     for y0, y1 in ((0, 4), (560, 572), (700, 708), (1290, 1296)):
         exp, _ = oc.render(ow, depth, threads=8, rows=(y0, y1))
         H.assert_images_equal(out["default"][0][y0:y1], exp[y0:y1], "%s rows %d..%d" % (name, y0, y1))
+
+
+def test_renderer_checks_the_buffers_it_hands_to_kernels():
+    """Renderer passes raw device pointers on: a buffer of the wrong size, type or place is refused (ValueError, also under
+    `python -O`), not written through."""
+    import torch
+    from ray_tracer_challenge_amd.renderer import Renderer
+    world, camera, depth = scenes.single_sphere(64, 48)
+    r = Renderer(world, camera, device=0)
+    good = r.alloc()
+    for bad in (torch.empty((47, 64, 3), dtype=torch.float32, device="cuda:0"), torch.empty((48, 64, 3), dtype=torch.float16, device="cuda:0"),
+                torch.empty((48, 64, 3), dtype=torch.float32), good.permute(1, 0, 2)):
+        with pytest.raises(ValueError):
+            r.render(depth, out=bad)
+    with pytest.raises(ValueError):
+        r.quantize(good, out=torch.empty(good.numel() - 1, dtype=torch.uint8, device="cuda:0"))
+    with pytest.raises(ValueError):
+        r.to_ppm(good.cpu())
+    img = r.render(depth, out=good).cpu().numpy()  # (and the good one still renders)
+    exp, _ = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=4)
+    H.assert_images_equal(img, exp, "single_sphere 64x48")
+    r.close()
