@@ -265,6 +265,7 @@ struct Policy {
     int specialise = 2;  // RTC_AMD_SPECIALIZE: 0 never, 1 always (a failed compile is an error), 2 by frame size
     bool light_cull = true, dark = true, fast_shadow = true;  // RTC_AMD_LIGHT_CULL / _DARK / _FAST_SHADOW (SceneHdr::cull_flags)
     bool bvh = true, scene_box = true, gates = true, tri_precull = true, block_list = true, quiet = false;
+    bool prune = true;    // RTC_AMD_PRUNE: groups / nodes a ray enters beyond what it still wants are left closed (for_each_object, ERROR_BUDGET.md B6)
     int clusters = -1;    // RTC_AMD_CLUSTERS: nodes over long triangle runs -- 0 never, 1 always, -1 by frame size
     int share_log2 = -1;  // RTC_AMD_SHARE_LOG2 = 0..3: lanes per pixel (log2) pinned for every frame; -1: by frame size
     int scene_rect = 1;   // RTC_AMD_SCENE_RECT: 0 never launch the scene's rectangle only, 2 whenever there is one, 1 under half the frame
@@ -292,6 +293,7 @@ struct Policy {
         p.scene_box = flag(std::getenv("RTC_AMD_SCENE_BOX"), true);
         p.gates = flag(std::getenv("RTC_AMD_GATES"), true);
         p.tri_precull = flag(std::getenv("RTC_AMD_TRI_PRECULL"), true);
+        p.prune = flag(std::getenv("RTC_AMD_PRUNE"), true);
         p.block_list = flag(std::getenv("RTC_AMD_BLOCK_LIST"), true);
         p.block_feedback = flag(std::getenv("RTC_AMD_BLOCK_FEEDBACK"), true);
         p.grid_feedback = flag(std::getenv("RTC_AMD_GRID_FEEDBACK"), true);
@@ -705,6 +707,11 @@ static rtc_status pack_uv_pattern(const rtc_uv_pattern& u, std::vector<float4>* 
 // (divided meshes) -- where a frame's slow waves are (rtc_ctx_render: block list).
 // What a primary ray can see at all, for the scene rectangle (rtc_ctx_set_scene): known when every top-level entry is
 // bounded -- their padded union is `box` -- or a plane, seen only by rays that point towards it.
+// RTC_AMD_PRUNE=0: every group / node entry gets an infinite slack, with which the walks' distance test never closes one
+static void no_distance_pruning(std::vector<float4>* trav) {
+    for (size_t e = 0, ne = trav->size() / TRAV_STRIDE; e < ne; e++)
+        if (!((*trav)[TRAV_STRIDE * e + 1].w < 0.0f)) (*trav)[TRAV_STRIDE * e + 1].w = INFINITY;
+}
 struct SceneRegion {
     bool known = false, has_box = false;
     double box[6] = {0, 0, 0, 0, 0, 0};
@@ -829,6 +836,7 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
             hdr->max_leaf_run = mark_leaf_runs(&trav, scene);
             hdr->internal_boxes = 1;
             hdr->n_trav = (uint32_t)(trav.size() / TRAV_STRIDE);
+            if (!P.prune) no_distance_pruning(&trav);
             soa->insert(soa->end(), trav.begin(), trav.end());
         }
     }
@@ -984,6 +992,7 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
             hdr->n_gates = n_gates;
         } else if (any) {
             hdr->n_trav = (uint32_t)(trav.size() / TRAV_STRIDE);
+            if (!P.prune) no_distance_pruning(&trav);
             soa->insert(soa->end(), trav.begin(), trav.end());
         }
     }
@@ -2922,7 +2931,17 @@ rtc_status rtc_intensity_at(const rtc_scene* scene, const float* points, uint32_
     HIP_TRY(d_p.alloc((size_t)n * 16));
     HIP_TRY(d_out.alloc((size_t)n * 4));
     HIP_TRY(hipMemcpy(d_p.p, points, (size_t)n * 16, hipMemcpyHostToDevice));
-    if (hdr.n_objects <= 4 && !hdr.n_trav)
+    bool simple = !hdr.has_patterns && hdr.n_objects <= 4 && !hdr.n_trav;  // (as rtc_ctx_set_scene decides it for the render kernels)
+    for (uint32_t i = 0; simple && i < hdr.n_objects; i++) {
+        const uint32_t kind = (uint32_t)scene->objects[i].kind;
+        const float* m = scene->objects[i].inv;
+        const bool diag = m[1] == 0.0f && m[2] == 0.0f && m[4] == 0.0f && m[6] == 0.0f && m[8] == 0.0f && m[9] == 0.0f;
+        if (!diag || kind == RTC_CYLINDER || kind == RTC_CONE || kind == RTC_TRIANGLE) simple = false;
+    }
+    if (simple)
+        hipLaunchKernelGGL(intensity_at_kernel_simple, dim3((n + 63) / 64), dim3(64), 0, nullptr, hdr,
+                           soa_view((const float4*)soa.p, hdr, (const float*)tex.p), (const float4*)d_p.p, n, (float*)d_out.p);
+    else if (hdr.n_objects <= 4 && !hdr.n_trav)
         hipLaunchKernelGGL(intensity_at_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, hdr,
                            soa_view((const float4*)soa.p, hdr, (const float*)tex.p), (const float4*)d_p.p, n, (float*)d_out.p);
     else

@@ -3325,6 +3325,16 @@ __global__ void intensity_at_kernel(SceneHdr H, SceneSoA S, const float4* __rest
     float4 p = points[i];
     out[i] = intensity_at<4, false>(H, S, v3(p.x, p.y, p.z), i, 1u, cnt);
 }
+// ... a world of at most four scale+translate-only spheres / planes / cubes without patterns: the SIMPLE instantiation, the
+// only one that takes the fast decision of a sample (shadow_fast) -- what the render kernels run for such a world
+__global__ void intensity_at_kernel_simple(SceneHdr H, SceneSoA S, const float4* __restrict__ points, uint32_t n,
+                                           float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Counters cnt = {0u, 0u};
+    float4 p = points[i];
+    out[i] = intensity_at<4, true>(H, S, v3(p.x, p.y, p.z), i, 1u, cnt);
+}
 __global__ void intensity_at_kernel_generic(SceneHdr H, SceneSoA S, const float4* __restrict__ points, uint32_t n,
                                             float* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
