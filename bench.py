@@ -63,6 +63,12 @@ def parse(argv=None):
                     "(N+E)-way band split; -1 = from the measured gather/render ratio, 0 = even split")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--force-dist", action="store_true", help="N=1: run the multi-GPU code path all the same -- init_process_group, the "
+                    "band gather through dist.gather on the communication stream, its calibration and the u8 wire pass -- with ONE "
+                    "rank (proves on a one-GPU box that RCCL loads, a communicator is created and the stream hand-off is right)")
+    ap.add_argument("--wire", default="f32", choices=["f32", "u8"], help="N>1: what travels to rank 0 in the measured steps: the f32 "
+                    "Canvas rows (12 B/pixel, the default) or the bytes Canvas::to_ppm prints (3 B/pixel, scale_color on the device); "
+                    "the other format is timed beside it")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N>1 started without a launcher: seconds the "
                     "parent waits for its ranks before ending them")
     args = ap.parse_args(argv)
@@ -199,8 +205,17 @@ def main(argv=None):
     dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world_size > 1:
+    dist_on = world_size > 1 or args.force_dist  # the collectives run (with --force-dist also among one rank)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # --force-dist without a launcher: a rendezvous of one
+            import socket
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            s_.close()
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -245,7 +260,7 @@ def main(argv=None):
 
     def fence():
         torch.cuda.synchronize()
-        if world_size > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -260,9 +275,11 @@ def main(argv=None):
                     tot[key] += st_[key]
         return tot
 
-    gather = BandGather(camera.height, camera.width, 3, torch.float32, device, rank, world_size)
+    wire_u8 = args.wire == "u8" and dist_on  # the measured steps move bytes instead of f32 rows
+    wire_dtype = torch.uint8 if wire_u8 else torch.float32
+    gather = BandGather(camera.height, camera.width, 3, wire_dtype, device, rank, world_size, force_collective=args.force_dist)
     assert gather.local_view(0).shape[0] == renderer_for(rank).rows(Renderer.partition(64, world_size, rank))
-    run = make_runner(gather)
+    run = make_runner(gather, quantise=wire_u8)
     # the first frame of a scene is rendered in image order; from the next one on the blocks start in the order of the work
     # the frame before counted in them (rtc_device.hip refine_block_list).  Every ray is traced in every frame all the same.
     first = None
@@ -280,7 +297,7 @@ def main(argv=None):
     # takes longer than rendering it, rank 0 -- whose rows never travel -- takes E extra parts of an (N + E)-way split
     # (dist.BandGather).  E comes from the measured ratio of an un-overlapped gather to a render of one even share.
     extra_parts, calib = 0, None
-    if world_size > 1 and args.steps > 0:
+    if dist_on and args.steps > 0:
         t0 = time.perf_counter()
         for _ in range(3):
             gather.start(0)
@@ -294,6 +311,8 @@ def main(argv=None):
             extra_parts = args.extra_parts
         elif k_ms > 0:
             extra_parts = max(0, min(6, int(round(g_ms / k_ms)) - 1))
+        if world_size == 1:
+            extra_parts = 0  # (--force-dist: one rank has nobody to take parts from)
         calib = {"render_ms_even_share": round(k_ms, 4), "gather_ms_even_share_unoverlapped": round(g_ms, 4)}
         if extra_parts > 0:
             # the even split, timed the same way as the split `value` is measured with: so that the first run on real xGMI
@@ -307,8 +326,8 @@ def main(argv=None):
             dist.all_reduce(e_even, op=dist.ReduceOp.MAX)
             calib["even_split_ms_per_step"] = round(float(e_even.item()) / args.steps * 1e3, 4)
             drain()
-            gather = BandGather(camera.height, camera.width, 3, torch.float32, device, rank, world_size, extra_parts=extra_parts)
-            run = make_runner(gather)
+            gather = BandGather(camera.height, camera.width, 3, wire_dtype, device, rank, world_size, extra_parts=extra_parts, force_collective=args.force_dist)
+            run = make_runner(gather, quantise=wire_u8)
             run(max(2, min(args.warmup, 3)))
         fence()
         drain()
@@ -324,7 +343,7 @@ def main(argv=None):
     counts = torch.tensor([st["rays"], st["shaded_hits"], st["pixels"], st["culled_shadow_rays"]], dtype=torch.float64,
                           device=device)
     kern = torch.tensor([st["kernel_ms"]], dtype=torch.float64, device=device)
-    if world_size > 1:
+    if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(kern, op=dist.ReduceOp.MAX)
@@ -336,10 +355,11 @@ def main(argv=None):
     # of the xGMI traffic of the f32 Canvas rows that `value` is measured with.  Never fatal: a failure is reported
     # in the field instead.
     wire = None
-    if world_size > 1 and args.steps > 0:
+    if dist_on and args.steps > 0:
         try:
-            gather8 = BandGather(camera.height, camera.width, 3, torch.uint8, device, rank, world_size)
-            run8 = make_runner(gather8, quantise=True)
+            other = torch.float32 if wire_u8 else torch.uint8  # the format the measured steps did NOT use
+            gather8 = BandGather(camera.height, camera.width, 3, other, device, rank, world_size, force_collective=args.force_dist)
+            run8 = make_runner(gather8, quantise=not wire_u8)
             run8(2)
             fence()
             drain()
@@ -351,10 +371,14 @@ def main(argv=None):
             drain()
             ok8 = None
             if rank == 0 and image is not None and img8 is not None:
-                ok8 = bool(torch.equal(img8, renderer.quantize(image.contiguous())))  # == bytes of the gathered f32 frame
-            wire = {"encoding": "u8 (scale_color on the device), even split", "ms_per_step": round(float(e8.item()) / args.steps * 1e3, 4),
+                f32_img, u8_img = (img8, image) if wire_u8 else (image, img8)
+                ok8 = bool(torch.equal(u8_img, renderer.quantize(f32_img.contiguous())))  # the bytes ARE the quantised f32 frame
+                if wire_u8:
+                    image = img8  # the frame whose rows are compared with the oracle below
+            wire = {"encoding": ("f32 Canvas rows" if wire_u8 else "u8 (scale_color on the device)") + ", even split",
+                    "ms_per_step": round(float(e8.item()) / args.steps * 1e3, 4),
                     "value": round(rays / (float(e8.item()) / args.steps) / 1e6, 2), "unit": "Mrays/s",
-                    "gathered_bytes_per_step": int(camera.height * camera.width * 3 * (world_size - 1) // world_size),
+                    "gathered_bytes_per_step": int(camera.height * camera.width * (12 if wire_u8 else 3) * (world_size - 1) // world_size),
                     "equals_quantised_f32_frame": ok8}
         except Exception as exc:  # noqa: BLE001
             wire = {"error": repr(exc)[:200]}
@@ -367,8 +391,8 @@ def main(argv=None):
         achieved = algo_bytes / (st["kernel_ms"] * 1e-3) / 1e9 if st["kernel_ms"] > 0 else 0.0
         pmc = matching_pmc_summary(renderer.kernel_id, args.scene, camera.width, camera.height) if world_size == 1 else None
         verify = None
-        if not args.no_verify:
-            verify = verify_rows(image, world, camera, depth)
+        if not args.no_verify and image is not None and image.dtype == torch.float32:
+            verify = verify_rows(image, world, camera, depth)  # (the GATHERED frame when the collectives ran)
         line = {
             "metric": "Mrays/s", "value": round(rays / (elapsed / args.steps) / 1e6, 2), "unit": "Mrays/s",
             "mpixels_per_s": round(pixels / (elapsed / args.steps) / 1e6, 3),
@@ -397,17 +421,24 @@ def main(argv=None):
                                             "tests are culled), so it exceeds the HBM peak; the roof that binds is in `roofline`"},
             "parity_check": verify,
         }
-        if world_size > 1:
-            # `value` gathers the f32 Canvas rows (12 B / pixel) to rank 0 over xGMI: one link per peer, so the step is
-            # max(render, rows_of_one_peer / link rate).  Render and transport separately:
+        if dist_on:
+            # `value` gathers the Canvas rows (f32: 12 B / pixel; --wire u8: 3) to rank 0 over xGMI: one link per peer, so the
+            # step is max(render, rows_of_one_peer / link rate).  Render and transport separately:
             n_parts = world_size + extra_parts
+            k_max = float(kern.item())
+            line["render_only"] = {"kernel_ms_max_over_ranks": round(k_max, 4),
+                                   "value": round(rays / (k_max * 1e-3) / 1e6, 2) if k_max > 0 else None, "unit": "Mrays/s",
+                                   "note": "the slowest rank's render kernels per frame (HIP events), no gather: what the band split "
+                                           "scales to when the rows stay where they are rendered"}
             if calib and "even_split_ms_per_step" in calib:
                 calib["even_split_value_Mrays_per_s"] = round(rays / (calib["even_split_ms_per_step"] * 1e-3) / 1e6, 2)
-            line["multi_gpu"] = {"gather": "f32 Canvas rows to rank 0, double-buffered (frame i's gather overlaps frame i+1's render)",
+            line["multi_gpu"] = {"backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""), "ranks": world_size,
+                                 "forced_with_one_rank": bool(args.force_dist and world_size == 1), "wire": args.wire,
+                                 "gather": "%s Canvas rows to rank 0 by dist.gather, double-buffered (frame i's gather overlaps frame i+1's render)" % args.wire,
                                  "split": "%d parts; rank 0 renders %d (its rows do not travel), each peer 1" % (n_parts, extra_parts + 1),
                                  "calibration": calib,
                                  "render_kernel_ms_max_over_ranks": round(float(kern.item()), 4),
-                                 "gathered_bytes_per_step": int(camera.height * camera.width * 12 * (world_size - 1) // n_parts),
+                                 "gathered_bytes_per_step": int(camera.height * camera.width * (3 if wire_u8 else 12) * (world_size - 1) // n_parts),
                                  "wire_format_gather": wire}
         if world_size == 1 and not args.no_one_shot:
             try:
@@ -419,7 +450,7 @@ def main(argv=None):
         elif world_size > 1:
             line["cpu_baseline"] = None  # measured on rank 0 at N=1 only
         print(json.dumps(line), flush=True)
-    if world_size > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

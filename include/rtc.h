@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTC_ABI_VERSION 7
+#define RTC_ABI_VERSION 8
 /* reflection_recursion_depth (camera.rs:76: any i16; reference default 5, constants.rs:4; its author renders
  * reflect_refract at 20).  Accepted: 0 .. RTC_MAX_DEPTH.  The kernels keep one frame per suspended shade_hit
  * (world.rs:62-86); up to RTC_STACK_DEPTH_BASE levels every kernel has them, above that the scene's kernel is compiled
@@ -68,7 +68,14 @@ enum { RTC_LIGHT_POINT = 0, RTC_LIGHT_RECT = 1 };
  * (rectangle_light.rs:27,44-47); a device cannot call one, so two pinned
  * sources are offered: the constant of test/utils.rs:15-17, and a counter-based
  * hash (DESIGN.md "Jitter") standing in for thread_rng(). */
-enum { RTC_JITTER_CONSTANT = 0, RTC_JITTER_HASHED = 2 };
+enum { RTC_JITTER_CONSTANT = 0, RTC_JITTER_HASHED = 2,
+       /* test/utils.rs:19-24 hardcoded_jitter: a short list of values handed out in a cycle.  The cycle is STATE that
+        * the reference carries from call to call (a RefCell inside the closure), serial across everything a light is
+        * asked: only the entry points that stand for ONE call on a freshly built light accept it -- rtc_intensity_at
+        * (every point is answered as by a new light: draw k of the call is value k mod n, two draws per cell in
+        * rectangle_light.rs:76-88's order) and rtc_point_on_light; rtc_render / rtc_ctx_set_scene / rtc_color_at refuse. */
+       RTC_JITTER_SEQUENCE = 3 };
+#define RTC_JITTER_SEQUENCE_MAX 16
 
 /* A boxed Pattern (pattern/pattern.rs:8-26) flattened: the two colours every pattern is built from and
  * BasePattern.t_inverse (pattern.rs:33,52-54).  Gradient and Sine2D keep `distance = b - a`
@@ -139,6 +146,8 @@ typedef struct rtc_light {
     int32_t jitter_mode;
     float jitter_const;
     uint32_t jitter_seed;
+    uint32_t jitter_seq_len;                      /* RTC_JITTER_SEQUENCE: 1 .. RTC_JITTER_SEQUENCE_MAX values ... */
+    float jitter_seq[RTC_JITTER_SEQUENCE_MAX];    /* ... set by rtc_light_set_jitter_sequence()                   */
 } rtc_light;
 
 /* One GroupShape (shape/group.rs:12-16) of the flattened world.  add_child / set_transformation bake a
@@ -282,6 +291,8 @@ void rtc_point_light(const float position[4], const float intensity[3], rtc_ligh
 rtc_status rtc_rectangle_light(const float intensity[3], const float corner[4], const float u_vec[4],
                                int32_t u_steps, const float v_vec[4], int32_t v_steps, int32_t jitter_mode,
                                float jitter_const, uint32_t jitter_seed, rtc_light* out); /* rectangle_light.rs:33-58 */
+/* hardcoded_jitter(values) of test/utils.rs:19-24 for a light built with jitter mode RTC_JITTER_SEQUENCE (see the enum) */
+rtc_status rtc_light_set_jitter_sequence(rtc_light* light, const float* values, uint32_t n);
 rtc_status rtc_camera_new(uint32_t width, uint32_t height, float field_of_view, const float transform[16],
                           rtc_camera* out);                                               /* camera.rs:23-56 */
 void rtc_ray_for_pixel(const rtc_camera* c, uint32_t x, uint32_t y, float origin[4], float direction[4]); /* camera.rs:60-74 */
@@ -376,6 +387,10 @@ rtc_status rtc_color_at(const rtc_scene* scene, const float* origins, const floa
 /* Batched Light::intensity_at (light.rs:10) for n world points (n*4 f32). */
 rtc_status rtc_intensity_at(const rtc_scene* scene, const float* points, uint32_t n, int32_t device,
                             float* out);
+/* Batched RectangleLight::point_on_light (rectangle_light.rs:60-66) on the device: n (u, v) cell pairs (n*2 int32), each
+ * answered as by a freshly built light (a sequence jitter's first two values; a hashed one's cell key with pixel 0, path
+ * 1); out n*4 f32 points. */
+rtc_status rtc_point_on_light(const rtc_light* light, const int32_t* cells_uv, uint32_t n, int32_t device, float* out);
 /* Batched World::is_shadowed (world.rs:104-119): light_positions, points n*4 f32; out n int32 (0/1). */
 rtc_status rtc_is_shadowed(const rtc_scene* scene, const float* light_positions, const float* points, uint32_t n,
                            int32_t device, int32_t* out);

@@ -364,18 +364,24 @@ struct PointLight : Light {
 };
 // RectangleLight::new(..., jitter_fn_opt).  `hashed(seed)` stands in for jitter_fn_opt = None (thread_rng);
 // `constant(c)` for test/utils.rs constant_jitter().  An arbitrary closure cannot run on a device.
+// `cycle(values)` is test/utils.rs hardcoded_jitter(): state carried from call to call, accepted by the batched
+// rtc_intensity_at / rtc_point_on_light only (each point answered as by a freshly built light).
 struct Jitter {
     int32_t mode;
     float value;
     uint32_t seed;
-    static Jitter hashed(uint32_t seed = 0x5EED5EEDu) { return {RTC_JITTER_HASHED, 0.0f, seed}; }
-    static Jitter constant(float c = 0.5f) { return {RTC_JITTER_CONSTANT, c, 0}; }
+    std::vector<float> sequence;
+    static Jitter hashed(uint32_t seed = 0x5EED5EEDu) { return {RTC_JITTER_HASHED, 0.0f, seed, {}}; }
+    static Jitter constant(float c = 0.5f) { return {RTC_JITTER_CONSTANT, c, 0, {}}; }
+    static Jitter cycle(std::vector<float> values) { return {RTC_JITTER_SEQUENCE, 0.0f, 0, std::move(values)}; }
 };
 struct RectangleLight : Light {
     RectangleLight(Color intensity, Tuple corner, Tuple u_vec, int32_t u_steps, Tuple v_vec, int32_t v_steps,
                    Jitter jitter = Jitter::hashed()) {  // rectangle_light.rs:33-58
         check(rtc_rectangle_light(intensity.data(), corner.data(), u_vec.data(), u_steps, v_vec.data(), v_steps,
                                   jitter.mode, jitter.value, jitter.seed, &l));
+        if (jitter.mode == RTC_JITTER_SEQUENCE)
+            check(rtc_light_set_jitter_sequence(&l, jitter.sequence.data(), (uint32_t)jitter.sequence.size()));
     }
 };
 

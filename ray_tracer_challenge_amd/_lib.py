@@ -20,7 +20,7 @@ RTC_SPHERE, RTC_PLANE, RTC_CUBE, RTC_CYLINDER, RTC_CONE, RTC_TRIANGLE = 0, 1, 2,
 RTC_UV_CHECKERS, RTC_UV_ALIGN_CHECK, RTC_UV_IMAGE = 1, 2, 3
 RTC_MAP_SPHERICAL, RTC_MAP_PLANAR, RTC_MAP_CYLINDRICAL = 1, 2, 3
 RTC_LIGHT_POINT, RTC_LIGHT_RECT = 0, 1
-RTC_JITTER_CONSTANT, RTC_JITTER_HASHED = 0, 2
+RTC_JITTER_CONSTANT, RTC_JITTER_HASHED, RTC_JITTER_SEQUENCE = 0, 2, 3
 RTC_MAX_DEPTH = 255        # accepted by rtc_render / rtc_ctx_render (above RTC_STACK_DEPTH_BASE: a scene kernel with a longer stack)
 RTC_STACK_DEPTH_BASE = 8   # ... and by rtc_color_at
 
@@ -53,7 +53,8 @@ class rtc_light(C.Structure):
     _fields_ = [("kind", C.c_int32), ("intensity", C.c_float * 3), ("position", C.c_float * 4),
                 ("corner", C.c_float * 4), ("u_vec", C.c_float * 4), ("v_vec", C.c_float * 4),
                 ("u_steps", C.c_int32), ("v_steps", C.c_int32), ("jitter_mode", C.c_int32),
-                ("jitter_const", C.c_float), ("jitter_seed", C.c_uint32)]
+                ("jitter_const", C.c_float), ("jitter_seed", C.c_uint32), ("jitter_seq_len", C.c_uint32),
+                ("jitter_seq", C.c_float * 16)]
 
 
 class rtc_group(C.Structure):
@@ -155,6 +156,8 @@ SIGNATURES = {
     "rtc_color_at": (C.c_int, [C.POINTER(rtc_scene), FP, FP, C.c_uint32, C.c_int32, C.c_int32, FP]),
     "rtc_intensity_at": (C.c_int, [C.POINTER(rtc_scene), FP, C.c_uint32, C.c_int32, FP]),
     "rtc_is_shadowed": (C.c_int, [C.POINTER(rtc_scene), FP, FP, C.c_uint32, C.c_int32, C.POINTER(C.c_int32)]),
+    "rtc_point_on_light": (C.c_int, [C.POINTER(rtc_light), C.POINTER(C.c_int32), C.c_uint32, C.c_int32, FP]),
+    "rtc_light_set_jitter_sequence": (C.c_int, [C.POINTER(rtc_light), FP, C.c_uint32]),
     "rtc_local_intersect": (C.c_int, [C.POINTER(rtc_object), FP, FP, C.c_uint32, C.c_int32, FP, C.POINTER(C.c_int32)]),
     "rtc_normal_at": (C.c_int, [C.POINTER(rtc_object), FP, C.c_uint32, C.c_int32, FP]),
     "rtc_pattern_color_at": (C.c_int, [C.POINTER(rtc_pattern), C.POINTER(rtc_object), FP, C.c_uint32, C.c_int32, FP]),

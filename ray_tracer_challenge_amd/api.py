@@ -699,7 +699,9 @@ class RectangleLight:
     -- light/rectangle_light.rs:33-58.
 
     jitter: ("constant", c) mirrors test/utils.rs constant_jitter();
-            ("hashed", seed) stands in for jitter_fn_opt = None (thread_rng).
+            ("hashed", seed) stands in for jitter_fn_opt = None (thread_rng);
+            ("cycle", [values]) mirrors test/utils.rs hardcoded_jitter(): state carried from call to call, so only
+            World.intensity_at and point_on_light -- each answered as by a freshly built light -- accept it.
             A Python callable (the closure form) cannot run on the device -> RtcError(UNSUPPORTED).
     """
 
@@ -710,6 +712,7 @@ class RectangleLight:
 
     def _c(self):
         l = L.rtc_light()
+        seq = None
         if callable(self.jitter):
             mode, const, seed = 1, 0.0, 0  # closure: rejected by the library
         else:
@@ -718,11 +721,24 @@ class RectangleLight:
                 mode, const, seed = L.RTC_JITTER_CONSTANT, float(f32(arg)), 0
             elif kind == "hashed":
                 mode, const, seed = L.RTC_JITTER_HASHED, 0.0, int(arg) & 0xFFFFFFFF
+            elif kind == "cycle":
+                mode, const, seed, seq = L.RTC_JITTER_SEQUENCE, 0.0, 0, _a(list(arg))
             else:
                 mode, const, seed = 1, 0.0, 0
         L.check(L.lib().rtc_rectangle_light(_p(self.intensity), _p(self.corner), _p(self.u_vec), self.u_steps,
                                             _p(self.v_vec), self.v_steps, mode, const, seed, C.byref(l)))
+        if seq is not None:
+            L.check(L.lib().rtc_light_set_jitter_sequence(C.byref(l), _p(seq), len(seq)))
         return l
+
+    def point_on_light(self, cells_uv, device=0):
+        """RectangleLight::point_on_light (rectangle_light.rs:60-66) on the device for (n, 2) cell pairs, each as the first
+        call on a freshly built light -> (n, 4) points."""
+        uv = np.ascontiguousarray(np.asarray(cells_uv, dtype=np.int32).reshape(-1, 2))
+        out = np.zeros((uv.shape[0], 4), dtype=f32)
+        l = self._c()
+        L.check(L.lib().rtc_point_on_light(C.byref(l), uv.ctypes.data_as(C.POINTER(C.c_int32)), uv.shape[0], device, _p(out)))
+        return out
 
     # fields the reference exposes after construction
     @property

@@ -158,8 +158,9 @@ static void singular_range(const double a[9], double* s_max, double* s_min) {
     *s_max = std::sqrt(std::fmax(e0, std::fmax(e1, e2)));
     *s_min = std::sqrt(std::fmin(e0, std::fmin(e1, e2)));
 }
-// World-space extent of a bounded object; false for unbounded / unsupported ones.
-static bool world_extent(const rtc_object& o, double lo[3], double hi[3]) {
+// World-space extent of a bounded object; false for unbounded / unsupported ones.  `grow_y` (object units): a cylinder's
+// y range widened by that much at either end (scene box: ERROR_BUDGET.md B8).
+static bool world_extent(const rtc_object& o, double lo[3], double hi[3], double grow_y = 0.0) {
     double F[9], f[3];
     if (!forward_affine(o.inv, F, f)) return false;
     double pts[8][3];
@@ -170,7 +171,7 @@ static bool world_extent(const rtc_object& o, double lo[3], double hi[3]) {
         double y0 = -1.0, y1 = 1.0;
         if (o.kind == RTC_CYLINDER || o.kind == RTC_CONE) {
             if (!std::isfinite(o.min_y) || !std::isfinite(o.max_y)) return false;
-            y0 = o.min_y, y1 = o.max_y;
+            y0 = o.min_y - grow_y, y1 = o.max_y + grow_y;
         } else if (o.kind != RTC_SPHERE && o.kind != RTC_CUBE) {
             return false;  // planes
         }
@@ -263,7 +264,7 @@ static void triangle_box(const rtc_object& o, const float4 tri[3], double d_worl
 #endif
 struct Policy {
     int specialise = 2;  // RTC_AMD_SPECIALIZE: 0 never, 1 always (a failed compile is an error), 2 by frame size
-    bool light_cull = true, dark = true, fast_shadow = true;  // RTC_AMD_LIGHT_CULL / _DARK / _FAST_SHADOW (SceneHdr::cull_flags)
+    bool light_cull = true, dark = true, fast_shadow = true, cell_cull = true;  // RTC_AMD_LIGHT_CULL / _DARK / _FAST_SHADOW / _CELL_CULL (SceneHdr::cull_flags)
     bool bvh = true, scene_box = true, gates = true, tri_precull = true, block_list = true, quiet = false;
     bool prune = true;    // RTC_AMD_PRUNE: groups / nodes a ray enters beyond what it still wants are left closed (for_each_object, ERROR_BUDGET.md B6)
     int clusters = -1;    // RTC_AMD_CLUSTERS: nodes over long triangle runs -- 0 never, 1 always, -1 by frame size
@@ -289,6 +290,7 @@ struct Policy {
         p.light_cull = flag(std::getenv("RTC_AMD_LIGHT_CULL"), true);
         p.dark = flag(std::getenv("RTC_AMD_DARK"), true);
         p.fast_shadow = flag(std::getenv("RTC_AMD_FAST_SHADOW"), true);
+        p.cell_cull = flag(std::getenv("RTC_AMD_CELL_CULL"), true);
         p.bvh = flag(std::getenv("RTC_AMD_BVH"), true);
         p.scene_box = flag(std::getenv("RTC_AMD_SCENE_BOX"), true);
         p.gates = flag(std::getenv("RTC_AMD_GATES"), true);
@@ -398,7 +400,13 @@ static bool build_flat_bvh(const rtc_scene* scene, const float cam_origin[4], st
     }
     float diag2 = 0.0f;
     for (int a = 0; a < 3; a++) diag2 += (all_hi[a] - all_lo[a]) * (all_hi[a] - all_lo[a]);
-    if (!(std::sqrt(diag2) < 100.0f * r_min)) return false;  // some ray could start more than 100 radii from an object
+    // ERROR_BUDGET.md B9: a ray is turned away from a box when it misses the box padded by 10 % of the object.  That is safe
+    // while (E2) no ray starts more than 100 radii -- of the object's SMALLEST axis: object-space units -- from an object, and
+    // (E1) the object-space origin M p + t is good to a hundredth of the padding: 3 u (|p| + |centre|) / r <= 1e-3.
+    if (!(std::sqrt(diag2) < 100.0f * r_min)) return false;
+    float far_coord = 0.0f;
+    for (int a = 0; a < 3; a++) far_coord = std::fmax(far_coord, std::fmax(std::fabs(all_lo[a]), std::fabs(all_hi[a])));
+    if (!(far_coord <= 2.5e3f * r_min)) return false;  // 3 u * 2 * 2.5e3 = 9e-4
     auto as_f = [](uint32_t u) {
         float f;
         std::memcpy(&f, &u, 4);
@@ -420,7 +428,7 @@ static bool build_flat_bvh(const rtc_scene* scene, const float cam_origin[4], st
             float big = 0.0f;
             for (int a = 0; a < 3; a++) big = std::fmax(big, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
             out->push_back(make_float4(lo[0], lo[1], lo[2], 0.0f));
-            out->push_back(make_float4(hi[0], hi[1], hi[2], 1e-3f * big));
+            out->push_back(make_float4(hi[0], hi[1], hi[2], 4e-3f * big));  // pruning slack, ERROR_BUDGET.md B6
             out->push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));
             if (e - b <= 2) {
                 for (size_t k = b; k < e; k++) {
@@ -718,7 +726,8 @@ struct SceneRegion {
     std::vector<std::array<double, 4>> planes;  // the plane's object-space y of a world point p: r[0] p.x + r[1] p.y + r[2] p.z + r[3]
 };
 static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_camera* cam, SceneHdr* hdr, std::vector<float4>* soa,
-                          std::vector<float>* texels, std::vector<float>* heavy_boxes = nullptr, SceneRegion* region = nullptr) {
+                          std::vector<float>* texels, std::vector<float>* heavy_boxes = nullptr, SceneRegion* region = nullptr,
+                          bool allow_sequence = false) {
     std::vector<float4> uvrec;
     std::vector<std::pair<const float*, size_t>> seen_images;
     if (!scene) return fail(RTC_ERR_INVALID_ARG, "scene is NULL");
@@ -820,9 +829,15 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
             hdr->cull_r2 = (float)(radius * radius);
             tbox.assign(3 * (size_t)n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
             TransformFacts tf;
+            // ERROR_BUDGET.md B7: the padding is derived from D, the distance between a ray's origin and a triangle -- and the ray's
+            // own transformation into object space is good to 3 u (|M| |origin| + |t|) (E1), which is relative to the
+            // COORDINATES: a mesh a thousand of its own sizes from the world's origin moves by that much more.  D stands for both.
+            double far_coord = 0.0;
+            for (int a = 0; a < 3; a++) far_coord = std::fmax(far_coord, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+            const double d_bound = std::fmax(2.0 * radius, far_coord + radius);
             for (uint32_t i = 0; i < n; i++)
                 if (scene->objects[i].kind == RTC_TRIANGLE)
-                    triangle_box(scene->objects[i], &(*soa)[12 * (size_t)np + 3 * (size_t)i], 2.0 * radius, TRI_GUARD, naive ? 0.0 : 1.0,
+                    triangle_box(scene->objects[i], &(*soa)[12 * (size_t)np + 3 * (size_t)i], d_bound, TRI_GUARD, naive ? 0.0 : 1.0,
                                  &tf, &tbox[3 * (size_t)i]);
         }
     }
@@ -898,7 +913,7 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
                                 gi, g.first_object, (unsigned)end);
                 if (open.empty()) top_level.push_back({trav.size() / TRAV_STRIDE, gi});
                 open.push_back({(uint32_t)end, trav.size() / TRAV_STRIDE});
-                float big = 0.0f;  // pruning slack: 1e-3 of the largest |coordinate| (NaN-propagating on purpose)
+                float big = 0.0f;  // pruning slack: 4e-3 of the largest |coordinate| (NaN-propagating on purpose; ERROR_BUDGET.md B6)
                 for (int a = 0; a < 3; a++) {
                     const float lo = std::fabs(g.bounds_min[a]), hi = std::fabs(g.bounds_max[a]);
                     big = (lo != lo || hi != hi) ? NAN : std::fmax(big, std::fmax(lo, hi));
@@ -916,7 +931,7 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
                     q = (qi != qi) ? q : std::fmax(q, qi);
                 }
                 trav.push_back(make_float4(g.bounds_min[0], g.bounds_min[1], g.bounds_min[2], 0.0f));
-                trav.push_back(make_float4(g.bounds_max[0], g.bounds_max[1], g.bounds_max[2], loose_group[gi] ? INFINITY : 1e-3f * big));
+                trav.push_back(make_float4(g.bounds_max[0], g.bounds_max[1], g.bounds_max[2], loose_group[gi] ? INFINITY : 4e-3f * big));
                 trav.push_back(make_float4(q, 0.0f, 0.0f, 0.0f));
                 any = true;
                 gi++;
@@ -1033,9 +1048,36 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
                     planes.push_back({(double)o.inv[4], (double)o.inv[5], (double)o.inv[6], (double)o.inv[7]});
                     known = known && std::isfinite(o.inv[4]) && std::isfinite(o.inv[5]) && std::isfinite(o.inv[6]) && std::isfinite(o.inv[7]);
                 } else {
+                    // ERROR_BUDGET.md B8.  The box asserts "a primary ray that misses it hits nothing", and the reference's f32
+                    // quadratic reports hits for lines that pass a sphere / cylinder wall at up to sqrt(1 + 16 u oo) of its radius
+                    // (E2; oo: squared distance of the ray's origin -- here always the camera -- in the OBJECT's space: a disc
+                    // scaled 1e-3 across, seen from ten world units, is ten thousand of its own units away and "grows" phantom
+                    // hits seven radii out: wide seeds 177, 217, 249).  So a leaf only counts as bounded when the camera is within
+                    // ~100 of its own units (32 u oo <= 0.02: the phantom rim is 1 % of the radius, the padding below 10 %), and
+                    // when the camera's object-space position itself is good to 1e-3 (E1).  A cylinder also reports a wall hit's
+                    // height wrongly by up to 2e-3 of the height difference to the camera (E2, relative error of t) -- its box
+                    // grows by four times that -- and from within two radii of its axis by more than any padding covers.
                     Entry e;
                     e.group = false;
-                    known = known && (o.kind == RTC_SPHERE || o.kind == RTC_CUBE || o.kind == RTC_CYLINDER) && world_extent(o, e.lo, e.hi);
+                    float orgf[4];
+                    const float zero4[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+                    mat_vec4(cam->inv, zero4, orgf);
+                    double oc[3], e1 = 0.0;
+                    for (int r = 0; r < 3; r++) {
+                        oc[r] = (double)o.inv[4 * r] * orgf[0] + (double)o.inv[4 * r + 1] * orgf[1] + (double)o.inv[4 * r + 2] * orgf[2] + (double)o.inv[4 * r + 3];
+                        e1 = std::fmax(e1, std::fabs((double)o.inv[4 * r] * orgf[0]) + std::fabs((double)o.inv[4 * r + 1] * orgf[1]) +
+                                               std::fabs((double)o.inv[4 * r + 2] * orgf[2]) + std::fabs((double)o.inv[4 * r + 3]));
+                    }
+                    const double U = 5.9604644775390625e-8;  // 2^-24
+                    const double oo = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2], oo_xz = oc[0] * oc[0] + oc[2] * oc[2];
+                    bool well = 3.0 * U * e1 <= 1e-3;
+                    double grow_y = 0.0;
+                    if (o.kind == RTC_SPHERE) well = well && 32.0 * U * oo <= 0.02;
+                    else if (o.kind == RTC_CYLINDER) {
+                        well = well && 32.0 * U * oo_xz <= 0.02 && oo_xz >= 4.0;
+                        grow_y = 8e-3 * (std::fabs(oc[1]) + std::fmax(std::fabs((double)o.min_y), std::fabs((double)o.max_y)));
+                    }
+                    known = known && well && (o.kind == RTC_SPHERE || o.kind == RTC_CUBE || o.kind == RTC_CYLINDER) && world_extent(o, e.lo, e.hi, grow_y);
                     entries.push_back(e);
                 }
                 i++;
@@ -1100,14 +1142,33 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
         if ((st = check_tuple(l.u_vec, 0.0f, "light.u_vec")) != RTC_OK) return st;
         if ((st = check_tuple(l.v_vec, 0.0f, "light.v_vec")) != RTC_OK) return st;
         if (l.u_steps <= 0 || l.v_steps <= 0) return fail(RTC_ERR_INVALID_ARG, "light steps must be positive");
-        if (l.jitter_mode != RTC_JITTER_CONSTANT && l.jitter_mode != RTC_JITTER_HASHED)
+        if (l.jitter_mode != RTC_JITTER_CONSTANT && l.jitter_mode != RTC_JITTER_HASHED && l.jitter_mode != RTC_JITTER_SEQUENCE)
             return fail(RTC_ERR_UNSUPPORTED, "jitter mode %d cannot run on the device (closures are host-only)", l.jitter_mode);
+        if (l.jitter_mode == RTC_JITTER_SEQUENCE) {
+            // test/utils.rs:19-24: the cycle is state carried across every question a light is asked -- across pixels, in the
+            // reference's serial loop.  Only one call on a fresh light is defined without that order: the batched
+            // rtc_intensity_at / rtc_point_on_light (cam == nullptr and allow_sequence).
+            if (cam || !allow_sequence)
+                return fail(RTC_ERR_UNSUPPORTED, "sequence jitter (hardcoded_jitter) is serial across pixels and rays: only rtc_intensity_at and "
+                                                 "rtc_point_on_light accept it");
+            if (l.jitter_seq_len < 1 || l.jitter_seq_len > RTC_JITTER_SEQUENCE_MAX)
+                return fail(RTC_ERR_INVALID_ARG, "sequence jitter: %u values (1 .. %d)", l.jitter_seq_len, RTC_JITTER_SEQUENCE_MAX);
+        }
         hdr->u_steps = l.u_steps;
         hdr->v_steps = l.v_steps;
         hdr->cells_f = (float)(l.u_steps * l.v_steps);
         hdr->jitter_mode = l.jitter_mode;
         hdr->jitter_const = l.jitter_const;
         hdr->jitter_seed = l.jitter_seed;
+        if (l.jitter_mode == RTC_JITTER_SEQUENCE) {
+            hdr->jitter_seq_len = l.jitter_seq_len;
+            bool unit = true;  // light-cone culling needs every sample inside the parallelogram: all values in [0, 1]
+            for (uint32_t k = 0; k < RTC_JITTER_SEQUENCE_MAX; k++) {
+                hdr->jitter_seq[k] = l.jitter_seq[k % l.jitter_seq_len];
+                unit = unit && l.jitter_seq[k % l.jitter_seq_len] >= 0.0f && l.jitter_seq[k % l.jitter_seq_len] <= 1.0f;
+            }
+            hdr->jitter_const = unit ? 0.5f : 2.0f;  // (what light_cull_mask looks at for a source that is not the hash)
+        }
         // light-cone culling inputs: the parallelogram's corners in every object's space, and its y range
         const float su = (float)l.u_steps, sv = (float)l.v_steps;
         float cw[4][3];
@@ -1118,6 +1179,17 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
             y_lo = fminf(y_lo, cw[k][1]);
             y_hi = fmaxf(y_hi, cw[k][1]);
             y_abs += fabsf(cw[k][1]);
+        }
+        {   // classify_cells (ERROR_BUDGET.md B10): half a cell's diagonal -- the longer one -- padded
+            double d1 = 0.0, d2 = 0.0, lmax = 0.0;
+            for (int a = 0; a < 3; a++) {
+                d1 += ((double)l.u_vec[a] + l.v_vec[a]) * ((double)l.u_vec[a] + l.v_vec[a]);
+                d2 += ((double)l.u_vec[a] - l.v_vec[a]) * ((double)l.u_vec[a] - l.v_vec[a]);
+                for (int k = 0; k < 4; k++) lmax = std::fmax(lmax, std::fabs((double)cw[k][a]));
+            }
+            const double hd = 0.5 * std::sqrt(std::fmax(d1, d2)) * 1.01 + 8.0 * 5.9604644775390625e-8 * lmax;
+            const bool unit_jitter = l.jitter_mode == RTC_JITTER_HASHED || (hdr->jitter_const >= 0.0f && hdr->jitter_const <= 1.0f);
+            hdr->cell_hd = (unit_jitter && std::isfinite(hd) && hd > 0.0) ? (float)hd : 0.0f;
         }
         const float ym = 1e-5f * y_abs + 1e-30f;  // far above the sample points' rounding error
         hdr->light_y_lo = y_lo - ym;
@@ -1132,6 +1204,46 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
             rec[0] = make_float4(c[0][0], c[0][1], c[0][2], c[1][0]);
             rec[1] = make_float4(c[1][1], c[1][2], c[2][0], c[2][1]);
             rec[2] = make_float4(c[2][2], c[3][0], c[3][1], c[3][2]);
+            // ERROR_BUDGET.md E1 for light_cull_mask: E bounds, in the object's own units, how far the pyramid the cull reasons
+            // about (apex: the computed object-space shade point o; base: these computed corners) can sit from the rays the
+            // exact test traces (same apex, direction M (sample - p)): |delta corner| + |delta o| <= 3 u (|M| (|L| + |p|) + 2 |t|),
+            // written with 4 u.  |M| |p| is bounded through o itself, which the cull only trusts within 100 radii:
+            // componentwise |g_k p_k| <= |o_k| + |t_k| for a scale+translate object, |M| |p| <= |M|_inf |F|_inf (|o|_inf + |t|_inf)
+            // otherwise (F: the forward transform).  A plane's rule looks at o.y alone and has no distance limit: the constant
+            // holds what does not depend on p, and for a plane that is not scale+translate only the kernel adds errB * |p|_inf.
+            const rtc_object& ob = scene->objects[i];
+            const double U4 = 4.0 * 5.9604644775390625e-8;
+            double Lmax = 0.0, tinf = 0.0, minf = 0.0;
+            for (int k = 0; k < 4; k++)
+                for (int a = 0; a < 3; a++) Lmax = std::fmax(Lmax, std::fabs((double)cw[k][a]));
+            double rows[3];
+            for (int r = 0; r < 3; r++) {
+                rows[r] = std::fabs((double)m[4 * r]) + std::fabs((double)m[4 * r + 1]) + std::fabs((double)m[4 * r + 2]);
+                minf = std::fmax(minf, rows[r]);
+                tinf = std::fmax(tinf, std::fabs((double)m[4 * r + 3]));
+            }
+            const bool diag = m[1] == 0.0f && m[2] == 0.0f && m[4] == 0.0f && m[6] == 0.0f && m[8] == 0.0f && m[9] == 0.0f;
+            double E, errB = 0.0;
+            if (ob.kind == RTC_PLANE) {
+                E = U4 * (2.0 * std::fabs((double)m[7]) + rows[1] * Lmax);
+                if (!diag) errB = U4 * rows[1];
+            } else {
+                double hy = 1.0;
+                if (ob.kind == RTC_CYLINDER) hy = std::fmax(std::fabs((double)ob.min_y), std::fabs((double)ob.max_y));
+                const double rad = 103.0 * std::sqrt(ob.kind == RTC_CUBE ? 3.0 : 1.0 + (ob.kind == RTC_CYLINDER ? hy * hy : 0.0));  // |o| where the cull still decides
+                if (diag) {
+                    E = U4 * (rad + 2.0 * tinf + minf * Lmax);
+                } else {
+                    double F[9], f[3], finf = INFINITY;
+                    if (forward_affine(m, F, f)) {
+                        finf = 0.0;
+                        for (int r = 0; r < 3; r++) finf = std::fmax(finf, std::fabs(F[3 * r]) + std::fabs(F[3 * r + 1]) + std::fabs(F[3 * r + 2]));
+                    }
+                    E = U4 * (minf * finf * (rad + tinf) + tinf + minf * Lmax);
+                }
+            }
+            (*soa)[18 * (size_t)np + i].w = std::isfinite(E) ? (float)E : INFINITY;  // trn.w
+            (*soa)[3 * (size_t)np + i].w = (float)errB;                             // off2.w
         }
     } else if (l.kind != RTC_LIGHT_POINT) {
         return fail(RTC_ERR_UNSUPPORTED, "light kind %d", l.kind);
@@ -1139,7 +1251,7 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
     hdr->all_cast = 1;
     for (uint32_t i = 0; i < n; i++)
         if (!scene->objects[i].casts_shadow) hdr->all_cast = 0;
-    hdr->cull_flags = (P.light_cull ? CULL_ENABLED : 0u) | (P.dark ? CULL_DARK : 0u) | (P.fast_shadow ? CULL_FAST_SHADOW : 0u);
+    hdr->cull_flags = (P.light_cull ? CULL_ENABLED : 0u) | (P.dark ? CULL_DARK : 0u) | (P.fast_shadow ? CULL_FAST_SHADOW : 0u) | (P.cell_cull ? CULL_CELLS : 0u);
     hdr->uvrec_off = (uint32_t)soa->size();
     soa->insert(soa->end(), uvrec.begin(), uvrec.end());
     if (cam) {
@@ -2403,6 +2515,14 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     // RTC_STACK_DEPTH_BASE levels.  Deeper than that, the scene's kernel is compiled once more with a longer stack -- 16, 32,
     // ... RTC_MAX_DEPTH levels of per-lane scratch -- on first use, and kept with the context.
     hipFunction_t spec_fn = c->spec_fn;
+    // (a world in which nothing reflects or transmits -- an empty world among them, which the reference renders black at any
+    // depth -- never suspends a shade_hit: whatever the depth asked for, the base kernels trace it as they trace depth 8)
+    bool recurses = false;
+    for (uint32_t i = 0; i < c->hdr.n_objects && !recurses; i++) {
+        const float4 mb = c->soa_host[5 * (size_t)padded_count(c->hdr.n_objects) + i], mc = c->soa_host[6 * (size_t)padded_count(c->hdr.n_objects) + i];
+        recurses = !(mb.w == 0.0f) || !(mc.x == 0.0f);  // reflective, transparency (NaN: recurses)
+    }
+    if (depth > RTC_STACK_DEPTH_BASE && !recurses) depth = RTC_STACK_DEPTH_BASE;
     if (depth > RTC_STACK_DEPTH_BASE && rows > 0u) {
         rtc_status dst = deep_kernel(c, depth, &spec_fn);
         if (dst != RTC_OK) return dst;
@@ -2878,13 +2998,13 @@ struct DevBuf {
     }
     hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
 };
-rtc_status begin_batch(const rtc_scene* scene, int32_t device, SceneHdr* hdr, DevBuf* soa_buf, DevBuf* tex_buf) {
+rtc_status begin_batch(const rtc_scene* scene, int32_t device, SceneHdr* hdr, DevBuf* soa_buf, DevBuf* tex_buf, bool allow_sequence = false) {
     int n = usable_devices();
     if (n <= 0) return fail(RTC_ERR_NO_DEVICE, "no HIP device visible; librtc_amd has no CPU fallback");
     if (device < 0 || device >= n) return fail(RTC_ERR_INVALID_ARG, "device %d out of range (have %d)", device, n);
     std::vector<float4> soa;
     std::vector<float> texels;
-    rtc_status st = flatten(Policy::from_env(), scene, nullptr, hdr, &soa, &texels);
+    rtc_status st = flatten(Policy::from_env(), scene, nullptr, hdr, &soa, &texels, nullptr, nullptr, allow_sequence);
     if (st != RTC_OK) return st;
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(soa_buf->alloc(soa.size() * sizeof(float4)));
@@ -2926,7 +3046,7 @@ rtc_status rtc_intensity_at(const rtc_scene* scene, const float* points, uint32_
     if (n == 0) return RTC_OK;
     SceneHdr hdr;
     DevBuf soa, tex, d_p, d_out;
-    rtc_status st = begin_batch(scene, device, &hdr, &soa, &tex);
+    rtc_status st = begin_batch(scene, device, &hdr, &soa, &tex, /*allow_sequence=*/true);
     if (st != RTC_OK) return st;
     HIP_TRY(d_p.alloc((size_t)n * 16));
     HIP_TRY(d_out.alloc((size_t)n * 4));
@@ -2949,6 +3069,30 @@ rtc_status rtc_intensity_at(const rtc_scene* scene, const float* points, uint32_
                            soa_view((const float4*)soa.p, hdr, (const float*)tex.p), (const float4*)d_p.p, n, (float*)d_out.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
+rtc_status rtc_point_on_light(const rtc_light* light, const int32_t* cells_uv, uint32_t n, int32_t device, float* out) {
+    if (!light || !cells_uv || !out) return fail(RTC_ERR_INVALID_ARG, "rtc_point_on_light: null argument");
+    if (light->kind != RTC_LIGHT_RECT) return fail(RTC_ERR_INVALID_ARG, "rtc_point_on_light: not a rectangle light");
+    if (n == 0) return RTC_OK;
+    for (uint32_t i = 0; i < n; i++)
+        if (cells_uv[2 * i] < 0 || cells_uv[2 * i] >= light->u_steps || cells_uv[2 * i + 1] < 0 || cells_uv[2 * i + 1] >= light->v_steps)
+            return fail(RTC_ERR_INVALID_ARG, "rtc_point_on_light: cell %u (%d, %d) outside the light's %d x %d", i, cells_uv[2 * i], cells_uv[2 * i + 1],
+                        light->u_steps, light->v_steps);
+    rtc_scene sc;
+    std::memset(&sc, 0, sizeof(sc));
+    sc.light = light;
+    SceneHdr hdr;
+    DevBuf soa, tex, d_c, d_out;
+    rtc_status st = begin_batch(&sc, device, &hdr, &soa, &tex, /*allow_sequence=*/true);
+    if (st != RTC_OK) return st;
+    HIP_TRY(d_c.alloc((size_t)n * 8));
+    HIP_TRY(d_out.alloc((size_t)n * 16));
+    HIP_TRY(hipMemcpy(d_c.p, cells_uv, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(point_on_light_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, hdr, (const int2*)d_c.p, n, (float4*)d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 16, hipMemcpyDeviceToHost));
     return RTC_OK;
 }
 

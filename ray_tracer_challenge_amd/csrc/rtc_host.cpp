@@ -511,7 +511,7 @@ rtc_status rtc_rectangle_light(const float intensity[3], const float corner[4], 
                                uint32_t jitter_seed, rtc_light* out) {
     if (!out || !intensity || !corner || !u_vec || !v_vec) return fail(RTC_ERR_INVALID_ARG, "rtc_rectangle_light: null argument");
     if (u_steps <= 0 || v_steps <= 0) return fail(RTC_ERR_INVALID_ARG, "rtc_rectangle_light: steps must be positive");
-    if (jitter_mode != RTC_JITTER_CONSTANT && jitter_mode != RTC_JITTER_HASHED)
+    if (jitter_mode != RTC_JITTER_CONSTANT && jitter_mode != RTC_JITTER_HASHED && jitter_mode != RTC_JITTER_SEQUENCE)
         return fail(RTC_ERR_UNSUPPORTED, "rtc_rectangle_light: jitter mode %d cannot run on the device", jitter_mode);
     std::memset(out, 0, sizeof(*out));
     out->kind = RTC_LIGHT_RECT;
@@ -528,6 +528,18 @@ rtc_status rtc_rectangle_light(const float intensity[3], const float corner[4], 
     out->jitter_mode = jitter_mode;
     out->jitter_const = jitter_const;
     out->jitter_seed = jitter_seed;
+    return RTC_OK;
+}
+
+// test/utils.rs:19-24 hardcoded_jitter
+rtc_status rtc_light_set_jitter_sequence(rtc_light* light, const float* values, uint32_t n) {
+    if (!light || !values) return fail(RTC_ERR_INVALID_ARG, "rtc_light_set_jitter_sequence: null argument");
+    if (light->kind != RTC_LIGHT_RECT) return fail(RTC_ERR_INVALID_ARG, "rtc_light_set_jitter_sequence: not a rectangle light");
+    if (n < 1 || n > RTC_JITTER_SEQUENCE_MAX)
+        return fail(RTC_ERR_INVALID_ARG, "rtc_light_set_jitter_sequence: %u values (1 .. %d)", n, RTC_JITTER_SEQUENCE_MAX);
+    light->jitter_mode = RTC_JITTER_SEQUENCE;
+    light->jitter_seq_len = n;
+    for (uint32_t i = 0; i < RTC_JITTER_SEQUENCE_MAX; i++) light->jitter_seq[i] = i < n ? values[i] : 0.0f;
     return RTC_OK;
 }
 

@@ -322,8 +322,18 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
         plan.n_chunks = plan.chunk_rows = 0u;
         RTC_TRY(ctx_render_slot(S.ctx, depth, &part, S.d_out, S.s_render, 0u, &plan, quantize));
         sh.reports = plan.n_chunks != 0u;
-        sh.n_chunks = sh.rows == 0u ? 0u : sh.reports ? plan.n_chunks : 1u;
-        sh.chunk_rows = sh.reports ? plan.chunk_rows : sh.rows;
+        if (sh.reports) {
+            sh.n_chunks = sh.rows == 0u ? 0u : plan.n_chunks;
+            sh.chunk_rows = plan.chunk_rows;
+        } else {
+            // a launch that cannot report (block lists, scene rectangles, several blocks per workgroup) is complete when its stream
+            // is: its rows still leave in the same ~4 MB chunks -- chunk_ready() answers true for every one of them once
+            // stream_done is set -- so that the transfers and the unstaging copies pipeline and the pinned staging stays two
+            // chunks, not two whole shares (C5 8192^2 f32: 2 x 805 MB)
+            const uint32_t want = std::min<uint32_t>(plan.want_chunks, (uint32_t)PROGRESS_MAX_CHUNKS);
+            sh.chunk_rows = sh.rows == 0u ? 0u : (sh.rows + want - 1u) / want;
+            sh.n_chunks = sh.rows == 0u ? 0u : (sh.rows + sh.chunk_rows - 1u) / sh.chunk_rows;
+        }
         if (staged && sh.rows) {
             const size_t need = (size_t)std::min(sh.rows, sh.chunk_rows) * row_out;
             if (need > S.stage_cap) {

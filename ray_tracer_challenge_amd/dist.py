@@ -50,16 +50,19 @@ class BandGather:
     collective is the same dist.gather.  bench.py picks E from a measured gather / render ratio."""
 
     def __init__(self, height, width, channels, dtype, device, rank, world_size, dst=0, band_rows=BAND_ROWS,
-                 slots=2, extra_parts=0):
+                 slots=2, extra_parts=0, force_collective=False):
         if world_size == 1:
             extra_parts = 0
+        # force_collective: a job of ONE rank still goes through dist.gather (bench.py --force-dist: the whole RCCL path --
+        # communicator, communication stream, stream hand-off in finish() -- on a box with a single GPU)
+        self.collective = world_size > 1 or force_collective
         self.rank, self.world_size, self.dst, self.slots = rank, world_size, dst, slots
         self.height, self.width, self.channels = height, width, channels
         self.extra_parts, self.n_parts = extra_parts, world_size + extra_parts
         self.rows, self.max_rows, perm = band_layout(height, self.n_parts, band_rows)
         self.local_rows = self.rows[rank]
         self.work = [None] * slots
-        if rank == dst and world_size > 1:
+        if rank == dst and self.collective:
             # one buffer per slot holding every part: [0, N) filled by the gather, [N, N+E) rendered here
             self.all = [torch.zeros((self.n_parts, self.max_rows, width, channels), dtype=dtype, device=device)
                         for _ in range(slots)]
@@ -87,7 +90,7 @@ class BandGather:
 
     def start(self, slot=0):
         """Enqueue the gather of `slot` (after whatever filled it on the current stream); returns immediately."""
-        if self.world_size == 1:
+        if not self.collective:
             return
         if self.rank == self.dst:
             self.work[slot] = dist.gather(self.send[slot], [self.all[slot][r] for r in range(self.world_size)],
@@ -97,7 +100,7 @@ class BandGather:
 
     def finish(self, slot=0):
         """Complete the gather of `slot`; returns the assembled image on dst, None elsewhere."""
-        if self.world_size == 1:
+        if not self.collective:
             return self.send[slot][: self.height]
         if self.work[slot] is not None:
             self.work[slot].wait()  # NCCL: the current stream waits for the comm stream, the host does not block

@@ -65,3 +65,23 @@ def test_the_drivers_launcher_form_still_works():
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["parity_check"]["rows_checked_bit_exact_vs_oracle"] and line["multi_gpu"]["calibration"]
+
+
+def test_the_rccl_branch_runs_with_one_rank():
+    """`--force-dist` with the default backend: init_process_group("nccl", device_id=...) -- RCCL loads and a communicator is
+    created --, the band gather through dist.gather on the communication stream, work.wait()'s stream hand-off, the
+    calibration and the other wire format, all with ONE rank on the one GPU this box has.  The gathered frame's rows are
+    compared with the oracle like any other line's."""
+    line = _bench(["--force-dist", "--size", "512", "--steps", "3", "--warmup", "2", "--cpu-seconds", "0", "--no-one-shot"])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    mg = line["multi_gpu"]
+    assert mg["backend"] == "nccl (RCCL)" and mg["ranks"] == 1 and mg["forced_with_one_rank"] is True and mg["wire"] == "f32"
+    assert mg["calibration"]["gather_ms_even_share_unoverlapped"] > 0
+    assert mg["wire_format_gather"]["equals_quantised_f32_frame"] is True
+    assert line["render_only"]["value"] >= line["value"] * 0.5
+    assert line["parity_check"]["rows_checked_bit_exact_vs_oracle"]  # rows of the frame dist.gather delivered
+    # ... and with the bytes Canvas::to_ppm prints as the measured wire format
+    u8 = _bench(["--force-dist", "--wire", "u8", "--size", "512", "--steps", "3", "--warmup", "2", "--cpu-seconds", "0", "--no-one-shot"])
+    assert u8["multi_gpu"]["wire"] == "u8" and u8["multi_gpu"]["wire_format_gather"]["equals_quantised_f32_frame"] is True
+    assert u8["parity_check"]["rows_checked_bit_exact_vs_oracle"]
+    assert u8["config"]["rays_per_frame"] == line["config"]["rays_per_frame"]

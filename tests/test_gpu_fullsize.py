@@ -50,7 +50,7 @@ def _check_whole_frame(image, rays, world, camera, depth, what):
 @pytest.fixture
 def cull_env():
     """Sets / restores the light-cone culling switches (read by the library when a scene is set)."""
-    saved = {k: os.environ.get(k) for k in ("RTC_AMD_LIGHT_CULL", "RTC_AMD_DARK", "RTC_AMD_FAST_SHADOW")}
+    saved = {k: os.environ.get(k) for k in ("RTC_AMD_LIGHT_CULL", "RTC_AMD_DARK", "RTC_AMD_FAST_SHADOW", "RTC_AMD_CELL_CULL")}
 
     def set_(**kw):
         for k, v in kw.items():
@@ -126,28 +126,33 @@ def test_light_cone_cull_changes_nothing_whole_frame(torch, cull_env, config):
     jitter = ("hashed", scenes.DEFAULT_SEED) if config.endswith("hashed") else ("constant", 0.5)
     world, camera, depth = scenes.soft_shadows(*size, jitter=jitter)
     frames = {}
-    for name, env in (("on", dict(RTC_AMD_LIGHT_CULL=None, RTC_AMD_DARK=None, RTC_AMD_FAST_SHADOW=None)),
-                      ("off", dict(RTC_AMD_LIGHT_CULL="0", RTC_AMD_DARK=None, RTC_AMD_FAST_SHADOW="0")),
-                      ("no_dark", dict(RTC_AMD_LIGHT_CULL=None, RTC_AMD_DARK="0", RTC_AMD_FAST_SHADOW=None)),
-                      ("no_fast", dict(RTC_AMD_LIGHT_CULL=None, RTC_AMD_DARK=None, RTC_AMD_FAST_SHADOW="0")),
-                      ("fast_only", dict(RTC_AMD_LIGHT_CULL="0", RTC_AMD_DARK=None, RTC_AMD_FAST_SHADOW=None))):
+    for name, env in (("on", dict(RTC_AMD_LIGHT_CULL=None, RTC_AMD_DARK=None, RTC_AMD_FAST_SHADOW=None, RTC_AMD_CELL_CULL=None)),
+                      ("off", dict(RTC_AMD_LIGHT_CULL="0", RTC_AMD_DARK=None, RTC_AMD_FAST_SHADOW="0", RTC_AMD_CELL_CULL=None)),
+                      ("no_dark", dict(RTC_AMD_LIGHT_CULL=None, RTC_AMD_DARK="0", RTC_AMD_FAST_SHADOW=None, RTC_AMD_CELL_CULL=None)),
+                      ("no_fast", dict(RTC_AMD_LIGHT_CULL=None, RTC_AMD_DARK=None, RTC_AMD_FAST_SHADOW="0", RTC_AMD_CELL_CULL=None)),
+                      ("fast_only", dict(RTC_AMD_LIGHT_CULL="0", RTC_AMD_DARK=None, RTC_AMD_FAST_SHADOW=None, RTC_AMD_CELL_CULL=None)),
+                      ("no_cells", dict(RTC_AMD_LIGHT_CULL=None, RTC_AMD_DARK=None, RTC_AMD_FAST_SHADOW=None, RTC_AMD_CELL_CULL="0")),
+                      ("cells_exact", dict(RTC_AMD_LIGHT_CULL=None, RTC_AMD_DARK="0", RTC_AMD_FAST_SHADOW="0", RTC_AMD_CELL_CULL=None))):
         cull_env(**env)
         r = _renderer(world, camera)
         img = r.render(depth).cpu().numpy()
         frames[name] = (img, r.stats(), r.kernel_name)
         r.close()
-    on, off, no_dark, no_fast, fast_only = (frames[k] for k in ("on", "off", "no_dark", "no_fast", "fast_only"))
-    assert on[2] == off[2] == no_dark[2] == no_fast[2]  # the same kernel: the switches are run-time data
+    on, off, no_dark, no_fast, fast_only, no_cells, cells_exact = (frames[k] for k in ("on", "off", "no_dark", "no_fast", "fast_only", "no_cells", "cells_exact"))
+    assert on[2] == off[2] == no_dark[2] == no_fast[2] == no_cells[2]  # the same kernel: the switches are run-time data
+    assert no_cells[1]["culled_shadow_rays"] <= on[1]["culled_shadow_rays"]  # (the cells decide what the whole-light cull left)
     for other, what in ((off, "every shortcut off"), (no_dark, "dark off"), (no_fast, "fast sample decision off"),
-                        (fast_only, "cull off, fast sample decision on")):
+                        (fast_only, "cull off, fast sample decision on"), (no_cells, "cell cones off"),
+                        (cells_exact, "cell cones with exact samples")):
         assert np.array_equal(on[0], other[0]), (config, what, int((on[0] != other[0]).sum()))
         for key in ("rays", "shaded_hits", "pixels"):
             assert on[1][key] == other[1][key], (config, what, key)
     assert off[1]["culled_shadow_rays"] == 0 and on[1]["culled_shadow_rays"] > 0
     assert no_dark[1]["culled_shadow_rays"] <= on[1]["culled_shadow_rays"]
-    print("\n%s: kernel ms all shortcuts %.3f, dark off %.3f, fast sample decision off %.3f, cull off (fast on) %.3f, all off %.3f; "
-          "%d of %d rays answered by the cull" % (config, on[1]["kernel_ms"], no_dark[1]["kernel_ms"], no_fast[1]["kernel_ms"],
-                                                    fast_only[1]["kernel_ms"], off[1]["kernel_ms"], on[1]["culled_shadow_rays"], on[1]["rays"]))
+    print("\n%s: kernel ms all shortcuts %.3f, cell cones off %.3f, dark off %.3f, fast sample decision off %.3f, cull off (fast on) %.3f, all off %.3f; "
+          "%d of %d rays answered without a sample (%d without the cell cones)" % (
+              config, on[1]["kernel_ms"], no_cells[1]["kernel_ms"], no_dark[1]["kernel_ms"], no_fast[1]["kernel_ms"],
+              fast_only[1]["kernel_ms"], off[1]["kernel_ms"], on[1]["culled_shadow_rays"], on[1]["rays"], no_cells[1]["culled_shadow_rays"]))
 
 
 def test_c2_single_sphere_1024_full_image(torch):

@@ -1,0 +1,61 @@
+"""The reference's own golden vectors for RectangleLight (light/rectangle_light.rs:114-166) on the HIP path (-m gpu).
+
+Both tests drive the light with test/utils.rs hardcoded_jitter -- a list of values handed out in a cycle, state the closure
+carries from call to call.  Each case builds a NEW light and asks it one question, which is what the batched entry points
+stand for: rtc_point_on_light (the first two values of the cycle) and rtc_intensity_at (draw k of the call = value k mod n, two
+draws per cell in the loop's order).  The vectors are the reference's, from tests/golden/reference_kat.json; rendering with such
+a light is refused (the cycle is serial across pixels)."""
+import numpy as np
+import pytest
+
+import ray_tracer_challenge_amd as P
+from tests import kat as K
+
+f32 = np.float32
+
+
+@pytest.mark.gpu
+def test_point_on_light_with_the_references_cycle(kat):  # rectangle_light.rs:114-140
+    c, p = kat["rectangle_light"]["construction"], kat["rectangle_light"]["point_on_light"]
+    light = P.RectangleLight(P.color(1, 1, 1), K.point(c["corner"]), K.vector(c["u"]), 4, K.vector(c["v"]), 2, ("cycle", p["jitter_cycle"]))
+    cells = [[u_i, v_i] for u_i, v_i, _ in p["cases"]]
+    got = light.point_on_light(cells)
+    for (u_i, v_i, expected), g in zip(p["cases"], got):
+        K.assert_exact(g, expected)  # assert_eq! in the reference
+
+
+@pytest.mark.gpu
+def test_intensity_at_with_the_references_cycle(kat):  # rectangle_light.rs:142-166: 0.0 / 0.5 / 0.75 / 0.75 / 1.0
+    c = kat["rectangle_light"]["intensity_at"]
+    w = P.default_world()
+    w.light = P.RectangleLight(P.color(1, 1, 1), K.point(c["corner"]), K.vector(c["u"]), c["steps"], K.vector(c["v"]), c["steps"],
+                               ("cycle", c["jitter_cycle"]))
+    pts = np.array([K.point(pt) for pt, _ in c["cases"]], dtype=f32)
+    got = w.intensity_at(pts)
+    for (pt, expected), g in zip(c["cases"], got):
+        assert g == f32(K.val(expected) if isinstance(expected, str) else expected), (pt, g, expected)
+    # the same five points in one batch and one at a time: every point is answered as by a freshly built light
+    for i in range(len(pts)):
+        assert w.intensity_at(pts[i:i + 1])[0] == got[i]
+    # ... against the oracle on a few hundred more points and longer cycles (its 'cycle' source restarted per point)
+    from tests import helpers as H
+    rng = np.random.default_rng(5)
+    for cyc in ([0.25], [0.0, 1.0, 0.5], list(rng.uniform(0, 1, 7)), list(rng.uniform(0, 1, 16))):
+        w.light = P.RectangleLight(P.color(1, 1, 1), K.point(c["corner"]), K.vector(c["u"]), 3, K.vector(c["v"]), 4, ("cycle", cyc))
+        more = np.concatenate([rng.uniform(-3, 3, (200, 3)), np.ones((200, 1))], axis=1).astype(f32)
+        got = w.intensity_at(more)
+        for i in range(len(more)):
+            own = H.oracle_world(w)  # a fresh light: the cycle starts over
+            assert got[i] == own.intensity_at(more[i]), (cyc, i)
+
+
+def test_rendering_with_a_cycle_is_refused():
+    """The cycle persists across pixels in the reference's serial loop (camera.rs:80-85): no device order reproduces it."""
+    w = P.default_world()
+    w.light = P.RectangleLight(P.color(1, 1, 1), P.point(-0.5, -0.5, -5), P.vector(1, 0, 0), 2, P.vector(0, 1, 0), 2, ("cycle", [0.7, 0.3]))
+    cam = P.Camera(8, 8, 1.0, P.view_transform(P.point(0, 0, -5), P.point(0, 0, 0), P.vector(0, 1, 0)))
+    with pytest.raises(P.RtcError) as e:
+        w.validate(cam)
+    assert "sequence jitter" in str(e.value)
+    with pytest.raises(P.RtcError):
+        P.RectangleLight(P.color(1, 1, 1), P.point(0, 0, 0), P.vector(1, 0, 0), 2, P.vector(0, 1, 0), 2, ("cycle", [0.5] * 17))._c()

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(L.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert P.lib().rtc_abi_version() == 7
+    assert P.lib().rtc_abi_version() == 8
 
 
 @pytest.mark.parametrize("name", ["soft_shadows", "first_scene", "first_plane", "glass_and_mirror", "shapes_medley",

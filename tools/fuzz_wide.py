@@ -17,7 +17,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SWITCHES = ["RTC_AMD_LIGHT_CULL", "RTC_AMD_DARK", "RTC_AMD_FAST_SHADOW", "RTC_AMD_PRUNE", "RTC_AMD_TRI_PRECULL", "RTC_AMD_BVH",
+SWITCHES = ["RTC_AMD_CELL_CULL", "RTC_AMD_LIGHT_CULL", "RTC_AMD_DARK", "RTC_AMD_FAST_SHADOW", "RTC_AMD_PRUNE", "RTC_AMD_TRI_PRECULL", "RTC_AMD_BVH",
             "RTC_AMD_SCENE_BOX", "RTC_AMD_GATES", "RTC_AMD_CLUSTERS", "RTC_AMD_SCENE_RECT"]
 
 
