@@ -2123,7 +2123,8 @@ DI V3 point_on_light(V3 corner, V3 uvec, V3 vvec, float a, float b) {
 // block meets a caster: its four samples are LIT -- total += 4, four rays counted, no jitter hashed.  In cosines, multiplied
 // through by |c| |w|:  c . w < sqrt(cc - hd2x^2) sqrt(ww - R^2) - hd2x R.  The decision is taken by the WAVE (a vote): the blocks some
 // lane cannot call lit are sampled by every lane exactly as before, so the loop stays the loop it was -- one cell at a time, the
-// same cell in every lane.  (Round 4 first built the finer thing -- cells decided one by one, LIT and BLOCKED, every lane sampling
+// same cell in every lane.  (The same vote for single cells inside a block that failed: 6 % fewer samples, and 20 % slower -- the
+// loop body doubles.  Round 4 first built the finer thing -- cells decided one by one, LIT and BLOCKED, every lane sampling
 // its own list of undecided cells: 3.5 times fewer samples on C3, and slower: lanes that sample different cells share no hash
 // schedule, no uniform branches, and nearly every round has some lane on the exact path.  LABNOTES.md "Round 4".)
 // Everything is evaluated in the sphere's own space, where the exact test lives: o (the exact test's own object-space shade
@@ -2136,6 +2137,7 @@ DI V3 point_on_light(V3 corner, V3 uvec, V3 vvec, float a, float b) {
 template <int NOBJ>
 DI bool blocks_usable(const SceneHdr& H, const SceneSoA& S, uint32_t skip) {  // wave-uniform
     if (!(H.cull_flags & CULL_CELLS) || !(H.cell_hd > 0.0f) || ((H.u_steps | H.v_steps) & 1) != 0) return false;
+    if (spec_jitter_mode(H.jitter_mode) == RTC_JITTER_SEQUENCE) return false;  // (its draws are numbered in the reference's cell order: the plain loop)
     bool ok = true;
 #pragma unroll
     for (uint32_t i = 0; i < (uint32_t)(NOBJ > 0 ? NOBJ : 1); i++) {
@@ -3239,6 +3241,10 @@ DI void render_body(const RenderArgs& A) {
 #ifdef RTC_DEBUG_STEPS  // group tests | exact tests << 20, leaf box tests, entries the WAVE stepped through
         col = v3(__uint_as_float(dbg_steps()[0] | dbg_steps()[2] << 20), __uint_as_float(dbg_steps()[1]), __uint_as_float(dbg_steps()[3]));
 #endif
+        // The canvas store (canvas.rs:26-43: row-major RGB): three dword stores per lane at a 12-byte stride.  (Round 4 measured the
+        // obvious alternative -- the wave's 8 x 8 tile transposed through LDS and stored as 48 sixteen-byte pieces, six per row: C3 +3 %,
+        // C5 +3 %, first_plane +6 %, profiles/r04_ab_wide_stores.txt.  The memory system merges the partial lines; the transpose costs
+        // an LDS round trip and registers in front of every wave's exit.)
         if (cnt.lead()) {
             const bool through = A.progress != nullptr;  // wave-uniform: write-through stores (RenderArgs::progress)
             const Where ws = where(rep);

@@ -52,6 +52,27 @@ def main(args):
     own = (groups + leaves).astype(np.float64)
     print("lane's own steps / wave's steps: %.3f (1 = every lane needs every step its wave takes)" % (own[busy].sum() / wave[busy].sum()))
     print("per ray: wave steps %.1f, lane steps %.1f, exact tests %.2f" % (wave.sum() / st["rays"], own.sum() / st["rays"], exact.sum() / st["rays"]))
+    # Per WAVE (8 x 8 pixel tiles: one lane per pixel): the entries the wave stepped through -- the union of its lanes' paths, which
+    # every lane of the packet walk pays for -- against the entries its BUSIEST lane needed for itself.  union / busiest = 1: the
+    # packet costs what the longest path costs alone; 2: the lanes' paths differ enough to double the walk.
+    H8, W8 = (h - 1) // 8 * 8, (w - 1) // 8 * 8
+    tile = lambda a: a[:H8, :W8].reshape(H8 // 8, 8, W8 // 8, 8)
+    union = tile(wave).max(axis=(1, 3)).astype(np.float64)      # (the same number in every lane of the wave)
+    busiest = tile(own).max(axis=(1, 3))
+    mean_lane = tile(own).mean(axis=(1, 3))
+    walked = union > 0
+    ratio = union[walked] / np.maximum(busiest[walked], 1.0)
+    print("per wave (%d of %d tiles walked): union / busiest lane -- mean %.2f, weighted by the union's size %.2f; union / mean lane %.2f" % (
+        walked.sum(), walked.size, ratio.mean(), union[walked].sum() / busiest[walked].sum(), union[walked].sum() / np.maximum(mean_lane[walked].sum(), 1.0)))
+    edges = [1.0, 1.1, 1.2, 1.3, 1.5, 1.75, 2.0, 2.5, 3.0, 4.0, 6.0, 1e9]
+    hist, _ = np.histogram(ratio, bins=edges)
+    wsum = [union[walked][(ratio >= lo) & (ratio < hi)].sum() for lo, hi in zip(edges[:-1], edges[1:])]
+    print("  union / busiest   waves      share of waves   share of all wave steps")
+    for (lo, hi), n_w, ws in zip(zip(edges[:-1], edges[1:]), hist, wsum):
+        print("  %4.2f .. %-8s %8d %14.1f %% %18.1f %%" % (lo, ("%.2f" % hi) if hi < 1e8 else "", n_w, 100.0 * n_w / max(1, walked.sum()), 100.0 * ws / max(1.0, union[walked].sum())))
+    # the longest waves decide a frame: the same ratio among the 1 % of waves with the largest unions
+    top = union[walked] >= np.quantile(union[walked], 0.99)
+    print("  the longest 1 %% of waves (union >= %.0f entries): union / busiest %.2f" % (np.quantile(union[walked], 0.99), union[walked][top].sum() / busiest[walked][top].sum()))
 
 
 if __name__ == "__main__":
