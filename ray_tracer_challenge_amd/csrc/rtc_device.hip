@@ -27,6 +27,7 @@
 #include <sstream>
 #include <string>
 #include <utility>
+#include <set>
 #include <vector>
 
 #include "rtc_internal.h"
@@ -266,6 +267,7 @@ struct Policy {
     int specialise = 2;  // RTC_AMD_SPECIALIZE: 0 never, 1 always (a failed compile is an error), 2 by frame size
     bool light_cull = true, dark = true, fast_shadow = true, cell_cull = true;  // RTC_AMD_LIGHT_CULL / _DARK / _FAST_SHADOW / _CELL_CULL (SceneHdr::cull_flags)
     bool bvh = true, scene_box = true, gates = true, tri_precull = true, block_list = true, quiet = false;
+    bool scene_tiles = true;  // RTC_AMD_SCENE_TILES: a sparse bounded scene's frames as zero-fill + its own tiles (rtc_ctx::scene_tile_mask)
     bool prune = true;    // RTC_AMD_PRUNE: groups / nodes a ray enters beyond what it still wants are left closed (for_each_object, ERROR_BUDGET.md B6)
     int clusters = -1;    // RTC_AMD_CLUSTERS: nodes over long triangle runs -- 0 never, 1 always, -1 by frame size
     int share_log2 = -1;  // RTC_AMD_SHARE_LOG2 = 0..3: lanes per pixel (log2) pinned for every frame; -1: by frame size
@@ -279,7 +281,7 @@ struct Policy {
     std::string jit_source, jit_flags;  // RTC_AMD_JIT_SOURCE=<path of rtc_kernel_core.h>, RTC_AMD_JIT_FLAGS="-D... -m..."
     bool jit_print = false, cluster_stats = false, tri_naive = false, block_order = true;
     int tree_waves = 6, reg_levels = 0, blocks_y = 0, block_s = -1, block_s_top = -1;  // (0 / -1: the library's own choice)
-    uint32_t fill_wgs = 0u, cluster_min_run = 0u, cluster_leaf = 0u, area_share_waves = 0u, feedback_pct = 85u, feedback_down_pct = 40u, feedback_passes = 2u, feedback_max_s = 4u;
+    uint32_t fill_wgs = 0u, tile_fill_wgs = 0u, cluster_min_run = 0u, cluster_leaf = 0u, area_share_waves = 0u, feedback_pct = 85u, feedback_down_pct = 40u, feedback_passes = 2u, feedback_max_s = 4u;
     double cluster_gmax = -1.0;
 
     static Policy from_env() {
@@ -296,6 +298,7 @@ struct Policy {
         p.gates = flag(std::getenv("RTC_AMD_GATES"), true);
         p.tri_precull = flag(std::getenv("RTC_AMD_TRI_PRECULL"), true);
         p.prune = flag(std::getenv("RTC_AMD_PRUNE"), true);
+        p.scene_tiles = flag(std::getenv("RTC_AMD_SCENE_TILES"), true);
         p.block_list = flag(std::getenv("RTC_AMD_BLOCK_LIST"), true);
         p.block_feedback = flag(std::getenv("RTC_AMD_BLOCK_FEEDBACK"), true);
         p.grid_feedback = flag(std::getenv("RTC_AMD_GRID_FEEDBACK"), true);
@@ -323,6 +326,7 @@ struct Policy {
         if (const char* e = RTC_DEV_ENV("RTC_AMD_AREA_SHARE_WAVES")) p.area_share_waves = (uint32_t)std::atoi(e);
         if (const char* e = RTC_DEV_ENV("RTC_AMD_FEEDBACK_MAX_S")) p.feedback_max_s = std::min(4u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_FILL_WGS")) p.fill_wgs = std::max(1u, (uint32_t)std::atoi(e));
+        if (const char* e = RTC_DEV_ENV("RTC_AMD_TILE_FILL_WGS")) p.tile_fill_wgs = std::max(1u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_CLUSTER_MIN_RUN")) p.cluster_min_run = std::max(3u, (uint32_t)std::atoi(e));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_CLUSTER_LEAF")) p.cluster_leaf = std::min(64u, std::max(2u, (uint32_t)std::atoi(e)));
         if (const char* e = RTC_DEV_ENV("RTC_AMD_CLUSTER_GMAX")) p.cluster_gmax = std::atof(e);
@@ -723,6 +727,7 @@ static void no_distance_pruning(std::vector<float4>* trav) {
 struct SceneRegion {
     bool known = false, has_box = false;
     double box[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<float> entry_boxes;  // the padded boxes of the bounded top-level entries one by one (HEAVY_BOX_FLOATS each; `box` is their union)
     std::vector<std::array<double, 4>> planes;  // the plane's object-space y of a world point p: r[0] p.x + r[1] p.y + r[2] p.z + r[3]
 };
 static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_camera* cam, SceneHdr* hdr, std::vector<float4>* soa,
@@ -1015,10 +1020,11 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
     // bounded -- groups by their boxes (a ray that misses a group's box is turned away whatever is inside), leaves of the
     // kinds whose hits lie within their bounds (not cones: stray roots; not triangles: ill-conditioned near their plane).
     // Padding: a group's box only needs what the approximate test's rounding needs (the reference's own test of that box
-    // is exact about it): 1e-4 of the coordinates.  A leaf is padded by 10 % of its own half extent plus 0.6 % of the
-    // camera's distance to the farthest corner of the scene: a ray that misses passes the object at >= 6e-3 of its own
-    // length, where the sphere / cylinder quadratic (error ~ 8 eps (D/r)^2, i.e. a miss distance of 1.4e-3 D) and the
-    // slab tests report a miss with a margin of 4x and more.
+    // is exact about it): 1e-4 of the coordinates.  A leaf is padded by 10 % of its own half extent: ERROR_BUDGET.md B8 --
+    // a leaf only counts as bounded when the camera is within ~100 of its own units, where the reference's quadratic reports
+    // nothing beyond 1 % of the radius (E2) -- the guards below.  (Up to round 3 the padding also carried 0.6 % of the camera's
+    // distance to the scene's far corner, an E2 allowance in world units that the object-space guard makes redundant, and
+    // that made the boxes of C5's spheres half as large again as the spheres.)
     if (cam && n > 0) {
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};  // union of the padded entries
         double raw_lo[3] = {INFINITY, INFINITY, INFINITY}, raw_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -1096,11 +1102,17 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
                 far2 += d * d;
             }
             const double far = std::sqrt(far2);
-            for (const Entry& e : entries)
+            std::vector<float> padded;
+            for (const Entry& e : entries) {
+                float pb[6];
                 for (int a = 0; a < 3; a++) {
-                    const double pad = (e.group ? 0.0 : 0.05 * (e.hi[a] - e.lo[a]) + 6e-3 * far) + 1e-4 * (std::fabs(e.lo[a]) + std::fabs(e.hi[a]) + far);
+                    const double pad = (e.group ? 0.0 : 0.05 * (e.hi[a] - e.lo[a])) + 1e-4 * (std::fabs(e.lo[a]) + std::fabs(e.hi[a]) + far);
                     lo[a] = std::fmin(lo[a], e.lo[a] - pad), hi[a] = std::fmax(hi[a], e.hi[a] + pad);
+                    pb[a] = (float)std::nextafter((float)(e.lo[a] - pad), -INFINITY), pb[3 + a] = (float)std::nextafter((float)(e.hi[a] + pad), INFINITY);
                 }
+                padded.insert(padded.end(), pb, pb + 6);
+                padded.push_back(1.0f);
+            }
             bool ok = std::isfinite(far);
             float box[6];
             for (int a = 0; a < 3 && ok; a++) {
@@ -1115,6 +1127,7 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
             if (region && ok) {
                 region->has_box = true;
                 for (int a = 0; a < 6; a++) region->box[a] = box[a];
+                region->entry_boxes = padded;
             }
             known = known && ok;
         }
@@ -1335,11 +1348,27 @@ struct rtc_ctx {
     std::map<std::array<uint32_t, 5>, BlockList> block_lists;
     float scene_box_coverage = 1.0f;  // share of the image the scene's box projects to (1: unknown / all of it)
     uint32_t scene_rect[4] = {0u, 0u, 0u, 0u};  // the 16 x 16 tiles outside which no primary ray sees anything: [x0, x1) x [y0, y1); empty: unknown
+    // Scene tiles: of a bounded world whose entries project to a small part of the frame (C5: 64 spheres, 7 % of 8192^2), the 16 x 16
+    // tiles some entry's padded box projects to.  Frames of such a scene are a zero-fill of the canvas and one workgroup per
+    // listed tile (ctx_render_slot), instead of the bounding rectangle of them all.  Empty: not known / not worth it.
+    std::vector<uint8_t> scene_tile_mask;
+    uint32_t scene_tiles_w = 0u, scene_tiles_h = 0u;
+    struct SceneTileList {
+        uint32_t* d = nullptr;
+        size_t n = 0;
+        unsigned long long traced_pixels = 0ull;  // traced pixels (x < w - 1, y < h - 1) inside the listed tiles
+        uint2* d_fill = nullptr;  // the runs of tiles that are NOT listed, at most 64 tiles each: {x0 | n << 16, local row} (fill_tiles_kernel)
+        size_t n_fill = 0;
+    };
+    hipStream_t fill_stream = nullptr;  // the zero-fill of a tile launch runs beside the render kernel (fork / join by events)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::map<std::array<uint32_t, 3>, SceneTileList> scene_tile_lists;  // per partition {band_rows, n_parts, part}
     float scene_rect_coverage = 1.0f;           // ... and its share of the frame
     std::string kernel_id;            // rtc_ctx_kernel_id(): names the code object (source + options + compiler), not the scene
     std::string jit_note;             // why spec_fn is null although the policy wanted one (rtc_ctx_jit_status)
     // the scene as last uploaded: an identical one (rtc_render_ex called again for the next frame) is not uploaded twice
     std::vector<float4> soa_host;
+    std::set<std::pair<const void*, const void*>> warmed;  // (kernel, stream) pairs that have been launched once (ctx_render_slot)
     std::vector<float> texels_host;
     uint4* d_block_counts = nullptr;
     size_t block_cap = 0;
@@ -1412,6 +1441,13 @@ static void restart_block_lists(rtc_ctx* c) {
     }
 }
 // every block list of the context, with what its feedback holds (the caller knows that no launch is reading them)
+static void drop_scene_tile_lists(rtc_ctx* c) {
+    for (auto& tl : c->scene_tile_lists) {
+        if (tl.second.d) (void)hipFree(tl.second.d);
+        if (tl.second.d_fill) (void)hipFree(tl.second.d_fill);
+    }
+    c->scene_tile_lists.clear();
+}
 static void drop_block_lists(rtc_ctx* c) {
     for (auto& bl : c->block_lists) {
         if (bl.second.d) (void)hipFree(bl.second.d);
@@ -1700,6 +1736,10 @@ void rtc_ctx_destroy(rtc_ctx* c) {
     if (c->d_ppm_rows) (void)hipFree(c->d_ppm_rows);
     if (c->d_ppm_bits) (void)hipFree(c->d_ppm_bits);
     drop_block_lists(c);
+    drop_scene_tile_lists(c);
+    if (c->fill_stream) (void)hipStreamDestroy(c->fill_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->h_feedback) (void)hipHostFree(c->h_feedback);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.first);
@@ -2147,6 +2187,8 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     // less than a quarter of the image
     c->scene_box_coverage = 1.0f;
     c->scene_rect[0] = c->scene_rect[1] = c->scene_rect[2] = c->scene_rect[3] = 0u;
+    c->scene_tile_mask.clear();
+    drop_scene_tile_lists(c);  // (nothing is in flight: the synchronisation above)
     if (hdr.has_scene_box && camera && P.block_list) {
         std::vector<uint8_t> covered;
         uint32_t tw = 0, th = 0;
@@ -2184,6 +2226,21 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         if (P.jit_print)
             std::fprintf(stderr, "librtc_amd: scene rectangle tiles [%u, %u) x [%u, %u) of %u x %u: %.3f of the frame\n", x0, x1, y0, y1, tw, th,
                          c->scene_rect_coverage);
+        // ... and entry by entry (ERROR_BUDGET.md B8 holds for each padded box as it does for their union): where the entries
+        // together cover under a third of the frame and under two thirds of their bounding rectangle, frames are drawn tile by tile
+        c->scene_tile_mask.clear();
+        if (P.scene_tiles && region.planes.empty() && !region.entry_boxes.empty() && x0 < x1 && y0 < y1) {
+            std::vector<uint8_t> each;
+            uint32_t ew = 0, eh = 0;
+            project_heavy_boxes(P, region.entry_boxes, camera, &each, &ew, &eh);
+            size_t n_each = 0;
+            for (uint8_t b : each) n_each += b ? 1u : 0u;
+            if (ew == tw && eh == th && n_each > 0 && 3u * n_each < (size_t)tw * th && 3u * n_each < 2u * (size_t)(x1 - x0) * (y1 - y0)) {
+                c->scene_tile_mask = each;
+                c->scene_tiles_w = tw, c->scene_tiles_h = th;
+            }
+            if (P.jit_print) std::fprintf(stderr, "librtc_amd: scene tiles: %zu of %u x %u%s\n", n_each, tw, th, c->scene_tile_mask.empty() ? " (not used)" : "");
+        }
     }
     c->spec_blocks_y = c->scene_box_coverage < 0.25f || P.blocks_y != 0;
     const std::string share_def = std::string("-DRTC_SPEC_SHARE=") + (c->spec_shares ? "1" : "0");
@@ -2649,7 +2706,76 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     unsigned long long extra_rays = 0ull;
     uint32_t fill_wg_rows = 0u, fill_rows = 0u, fill_period = 1u, fill_rect[4] = {0u, 0u, 0u, 0u};
     bool rect_launch = false;
-    if (d_tiles == nullptr && share_log2 == 0u && rows > 0u && c->scene_rect[0] < c->scene_rect[1] && c->scene_rect_coverage < P.scene_rect_threshold() &&
+    // Scene tiles (rtc_ctx::scene_tile_mask): the canvas is zero-filled at memory speed (805 MB of an 8192^2 frame: 0.12 ms) and
+    // only the tiles some entry of the world projects to get a workgroup -- C5: 18 k of 262 k, where the bounding rectangle of
+    // them all has 60 k, and a frame of such short waves costs what starting them costs (0.78 waves per ns).  The pixels of
+    // the other tiles are one ray each that sees nothing (sum_counts_kernel's extra_rays).
+    bool tile_launch = false;
+    const uint2* fill_jobs = nullptr;
+    size_t n_fill_jobs = 0;
+    if (d_tiles == nullptr && share_log2 == 0u && rows > 0u && !c->scene_tile_mask.empty() && (q.band_rows & 15u) == 0u &&
+        c->hdr.width <= 65532u && rows <= 131068u) {
+        const std::array<uint32_t, 3> key = {q.band_rows, q.n_parts, q.part};
+        auto it = c->scene_tile_lists.find(key);
+        if (it == c->scene_tile_lists.end()) {
+            std::vector<uint32_t> list;
+            std::vector<uint2> fill;
+            rtc_ctx::SceneTileList tl;
+            const uint32_t n_bands = (c->hdr.height + q.band_rows - 1) / q.band_rows;
+            uint32_t cursor = 0u;
+            for (uint32_t b = q.part; b < n_bands; b += q.n_parts) {
+                const uint32_t y0 = b * q.band_rows, y1 = std::min(c->hdr.height, y0 + q.band_rows);
+                for (uint32_t ty = y0 / 16u; ty * 16u < y1; ty++) {
+                    const uint32_t yl = cursor + (ty * 16u - y0);
+                    uint32_t run0 = 0u, run = 0u;  // the current run of unlisted tiles: [run0, run0 + run)
+                    auto close_run = [&]() {
+                        for (uint32_t k = 0; k < run; k += 64u) fill.push_back(make_uint2((run0 + k) | (std::min(64u, run - k) << 16), yl));
+                        run = 0u;
+                    };
+                    for (uint32_t tx = 0; tx < c->scene_tiles_w; tx++) {
+                        if (!c->scene_tile_mask[(size_t)ty * c->scene_tiles_w + tx]) {
+                            if (run == 0u) run0 = tx;
+                            run++;
+                            continue;
+                        }
+                        close_run();
+                        list.push_back(tile_word(0u, tx * 16u, yl));
+                        const uint32_t px1 = std::min(c->hdr.width - 1u, tx * 16u + 16u), py1 = std::min(std::min(c->hdr.height - 1u, y1), ty * 16u + 16u);
+                        if (px1 > tx * 16u && py1 > ty * 16u) tl.traced_pixels += (unsigned long long)(px1 - tx * 16u) * (py1 - ty * 16u);
+                    }
+                    close_run();
+                }
+                cursor += y1 - y0;
+            }
+            tl.n = list.size();
+            tl.n_fill = fill.size();
+            if (tl.n) {
+                HIP_TRY(hipMalloc((void**)&tl.d, tl.n * sizeof(uint32_t)));
+                HIP_TRY(hipMemcpyAsync(tl.d, list.data(), tl.n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                if (tl.n_fill) {
+                    HIP_TRY(hipMalloc((void**)&tl.d_fill, tl.n_fill * sizeof(uint2)));
+                    HIP_TRY(hipMemcpyAsync(tl.d_fill, fill.data(), tl.n_fill * sizeof(uint2), hipMemcpyHostToDevice, stream));
+                }
+                HIP_TRY(hipStreamSynchronize(stream));  // (the host vectors go out of scope)
+            }
+            it = c->scene_tile_lists.emplace(key, tl).first;
+        }
+        const rtc_ctx::SceneTileList& tl = it->second;
+        if (tl.n) {
+            if (!c->fill_stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            fill_jobs = tl.d_fill, n_fill_jobs = tl.n_fill;
+            d_tiles = tl.d;
+            grid = dim3((uint32_t)tl.n, 1);
+            blocks_y = 1u;
+            extra_rays = c->last_pixels - tl.traced_pixels;
+            tile_launch = true;
+        }
+    }
+    if (!tile_launch && d_tiles == nullptr && share_log2 == 0u && rows > 0u && c->scene_rect[0] < c->scene_rect[1] && c->scene_rect_coverage < P.scene_rect_threshold() &&
         (spec_fn == nullptr || c->spec_rect)) {
         // local rows of this partition whose global row lies in the rectangle's rows, and the traced ones among them
         const uint32_t gy0 = c->scene_rect[2] * 16u, gy1 = std::min(c->hdr.height, c->scene_rect[3] * 16u);
@@ -2825,7 +2951,43 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
         }
     }
     auto& ev = c->events[c->events_used++];
+    // The FIRST launch of a code object on a queue pays what is not the kernel's: the runtime moves the code to the device and
+    // sizes the queue's scratch for it -- 6 to 11 ms in a fresh process for these kernels (tools/first_frame_probe.py: C3's first
+    // frame 0.95 ms cold, 0.71 once any context of the process has launched the same code; mesh 11.2 / 3.4).  It is paid once per
+    // process and queue, here: one workgroup of the same kernel over zero rows (it finds no pixel of its own and writes only
+    // the counters the real launch overwrites), in front of the events that time the frame.
+    {
+        const void* fn_key = spec_fn ? (const void*)spec_fn : (const void*)(uintptr_t)(0x1000u + (c->hdr.n_trav ? 1u : c->n_objects <= 4 ? 2u : c->n_objects <= 8 ? 4u : 6u) + (c->simple ? 1u : 0u));
+        const auto key = std::make_pair(fn_key, (const void*)stream);
+        if (!c->warmed.count(key)) {
+            c->warmed.insert(key);
+            RenderArgs w = a;
+            w.rows = 0u, w.tiles = nullptr, w.wave_ticks = nullptr, w.progress = nullptr, w.done = nullptr, w.fill_wg_rows = 0u, w.swizzle = 0u, w.blocks_y = 1u;
+            const dim3 one(1, 1);
+            if (spec_fn) {
+                void* wp[] = {&w};
+                HIP_TRY(hipModuleLaunchKernel(spec_fn, 1, 1, 1, block.x, 1, 1, 0, stream, wp, nullptr));
+            } else if (c->hdr.n_trav) hipLaunchKernelGGL((render_kernel<-1, false>), one, block, 0, stream, w);
+            else if (c->n_objects <= 4 && c->simple) hipLaunchKernelGGL((render_kernel<4, true>), one, block, 0, stream, w);
+            else if (c->n_objects <= 4) hipLaunchKernelGGL((render_kernel<4, false>), one, block, 0, stream, w);
+            else if (c->n_objects <= 8 && c->simple) hipLaunchKernelGGL((render_kernel<8, true>), one, block, 0, stream, w);
+            else if (c->n_objects <= 8) hipLaunchKernelGGL((render_kernel<8, false>), one, block, 0, stream, w);
+            else hipLaunchKernelGGL((render_kernel<0, false>), one, block, 0, stream, w);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     HIP_TRY(hipEventRecord(ev.first, stream));
+    if (tile_launch && n_fill_jobs) {  // the zero-fill of the unlisted tiles runs beside the render kernel: memory-bound work under arithmetic
+        HIP_TRY(hipEventRecord(c->ev_fork, stream));
+        HIP_TRY(hipStreamWaitEvent(c->fill_stream, c->ev_fork, 0));
+        // 96 workgroups share the jobs: enough to move 690 MB in the time C5's tiles take to render, few enough to leave the chip's wave
+        // slots to the render kernel (C5 8192^2, whole frame: 0.84 / 0.46 / 0.33 / 0.294 / 0.30 / 0.36 / 0.38 ms with 16 / 32 / 64 / 96 /
+        // 128 / 512 / 4096 of them; the bounding rectangle with its interleaved fill: 0.335; profiles/r04_c5_tile_fill.txt)
+        const uint32_t fill_wgs = P.tile_fill_wgs ? P.tile_fill_wgs : 96u;
+        hipLaunchKernelGGL(fill_tiles_kernel, dim3((uint32_t)std::min<size_t>(n_fill_jobs, fill_wgs)), dim3(256), 0, c->fill_stream, fill_jobs,
+                           (uint32_t)n_fill_jobs, (uint8_t*)d_out_rgb, c->hdr.width, rows, out_u8 ? 3u : 12u);
+        HIP_TRY(hipEventRecord(c->ev_join, c->fill_stream));
+    }
     if (timed_list) HIP_TRY(hipEventRecord(timed_list->ev0, stream));
     // instantiation: <= 4 / <= 8 objects get fully unrolled object loops (SIMPLE: all of them
     // scale+translate-only, no cylinder); anything larger takes the generic loop
@@ -2838,6 +3000,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     else if (c->n_objects <= 8 && c->simple) hipLaunchKernelGGL((render_kernel<8, true>), grid, block, 0, stream, a);
     else if (c->n_objects <= 8) hipLaunchKernelGGL((render_kernel<8, false>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, 0, stream, a);
+    if (tile_launch && n_fill_jobs) HIP_TRY(hipStreamWaitEvent(stream, c->ev_join, 0));
     HIP_TRY(hipEventRecord(ev.second, stream));
     if (timed_list) {
         HIP_TRY(hipEventRecord(timed_list->ev1, stream));

@@ -2205,15 +2205,17 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
     if constexpr (SIMPLE && NOBJ > 0 && !Counters::SHARE_LANES) {
         if (blocks_usable<NOBJ>(H, S, skip)) {  // wave-uniform: block cones (see above)
             constexpr int N = NOBJ;
-            float S_lit[N], T_lit[N];
+            float S_lit[N];
             const float hd = 2.0f * H.cell_hd, hd2 = hd * hd;  // a block's cone: the cells' whole diagonal
+            // hd R, with the largest R any lane may use: 1.03 sqrt(1 + 32 u oo) at oo = 2.5e5 (500 radii; beyond, a lane calls nothing lit).
+            // The same for every lane and sphere -- a scalar, where the exact product would be a register per sphere.
+            const float T_lit = hd * 1.2535f;
 #pragma unroll
             for (int i = 0; i < N; i++) {
                 const uint32_t bits = spec_bits(i, __float_as_uint(S.geo[i].w));
                 if ((bits & SHAPE_KIND_MASK) != RTC_SPHERE || !(bits & SHAPE_CASTS) || ((skip >> i) & 1u)) continue;  // wave-uniform
                 const float oo = pre[i].c + 1.0f, R2 = 1.0609f * (1.0f + 1.9073486e-6f * oo);
-                S_lit[i] = oo > 1.001f * R2 ? __builtin_amdgcn_sqrtf(oo - R2) : RTC_NAN;  // (NaN: no comparison holds -- this lane calls nothing lit)
-                T_lit[i] = hd * __builtin_amdgcn_sqrtf(R2);
+                S_lit[i] = (oo > 1.001f * R2 && oo < 2.5e5f) ? __builtin_amdgcn_sqrtf(oo - R2) : RTC_NAN;  // (NaN: no comparison holds -- this lane calls nothing lit)
             }
             const V3 base = corner + uvec + vvec - p;  // centre of block (0, 0) as seen from p
             for (int vb = 0; vb < H.v_steps; vb += 2) {
@@ -2228,7 +2230,7 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
                         if ((bits & SHAPE_KIND_MASK) != RTC_SPHERE || !(bits & SHAPE_CASTS) || ((skip >> i) & 1u)) continue;
                         const float dot = __builtin_fmaf(c.x, pre[i].o.x, __builtin_fmaf(c.y, pre[i].o.y, c.z * pre[i].o.z));
                         const float d = S.geo[i].x < 0.0f ? dot : -dot;  // -sign(g) (c . o)   (wave-uniform choice)
-                        lit = lit & (d < __builtin_fmaf(sq, S_lit[i], -T_lit[i]));
+                        lit = lit & (d < __builtin_fmaf(sq, S_lit[i], -T_lit));
                     }
                     if (__all(lit)) {  // four rays the reference casts and finds lit
                         total += 4.0f;
@@ -3364,6 +3366,30 @@ __global__ __launch_bounds__(1024) void sum_counts_kernel(const uint4* __restric
         atomicAdd(&total[1], sh);
         atomicAdd(&total[2], cu);
     }
+}
+
+// Scene tiles (rtc_device.hip ctx_render_slot): the tiles of the canvas no entry of the world projects to are black.  One
+// workgroup per job {x0 | n << 16 (tiles), local row y0}: sixteen rows of n tiles' columns, zeroed with 16-byte stores where rows are
+// aligned to that (f32 rows of widths that are multiples of four; byte rows always start on a multiple of 48 columns' worth).
+__global__ __launch_bounds__(256) void fill_tiles_kernel(const uint2* __restrict__ jobs, uint32_t n_jobs, uint8_t* __restrict__ out, uint32_t width, uint32_t rows,
+                                                         uint32_t bytes_per_pixel) {
+  for (uint32_t j = blockIdx.x; j < n_jobs; j += gridDim.x) {  // (a few hundred workgroups share the jobs: they leave the chip's wave slots to the render kernel)
+    const uint2 job = jobs[j];
+    const uint32_t x0 = (job.x & 0xffffu) * 16u, x1 = min(width, x0 + (job.x >> 16) * 16u), y0 = job.y, y1 = min(rows, y0 + 16u);
+    if (x0 >= x1) continue;
+    const size_t row_bytes = (size_t)width * bytes_per_pixel;
+    const uint32_t span = (x1 - x0) * bytes_per_pixel;  // bytes per row of this job
+    const bool wide = (row_bytes & 15u) == 0u && ((unsigned long)out & 15ul) == 0ul && ((x0 * bytes_per_pixel) & 15u) == 0u && (span & 15u) == 0u;
+    for (uint32_t y = y0; y < y1; y++) {
+        uint8_t* dst = out + (size_t)y * row_bytes + (size_t)x0 * bytes_per_pixel;
+        if (wide) {
+            float4* d4 = (float4*)dst;
+            for (uint32_t i = threadIdx.x; i < span / 16u; i += 256u) d4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        } else {
+            for (uint32_t i = threadIdx.x; i < span; i += 256u) dst[i] = 0;
+        }
+    }
+  }
 }
 
 // canvas.rs:39-43

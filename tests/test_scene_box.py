@@ -40,7 +40,7 @@ CAMERAS = {
 
 
 def _render(world, camera, depth, env, monkeypatch, parts=None):
-    for k in ("RTC_AMD_SCENE_BOX", "RTC_AMD_SCENE_RECT"):
+    for k in ("RTC_AMD_SCENE_BOX", "RTC_AMD_SCENE_RECT", "RTC_AMD_SCENE_TILES"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -79,15 +79,17 @@ def test_scene_box_and_rectangle_change_nothing(cam, specialise, monkeypatch):
     base, base_counts = _render(world, camera, 3, {"RTC_AMD_SCENE_BOX": "0", "RTC_AMD_SCENE_RECT": "0"}, monkeypatch)
     H.assert_images_equal(base, exp, "%s: no shortcuts" % cam)
     assert base_counts[0] == rays
-    for name, env in (("box only", {"RTC_AMD_SCENE_RECT": "0"}), ("default", {}), ("rectangle whatever its size", {"RTC_AMD_SCENE_RECT": "2"})):
+    for name, env in (("box only", {"RTC_AMD_SCENE_RECT": "0", "RTC_AMD_SCENE_TILES": "0"}), ("default", {}), ("no tile lists", {"RTC_AMD_SCENE_TILES": "0"}),
+                      ("rectangle whatever its size", {"RTC_AMD_SCENE_RECT": "2", "RTC_AMD_SCENE_TILES": "0"})):
         img, counts = _render(world, camera, 3, env, monkeypatch)
         H.assert_images_equal(img, exp, "%s: %s" % (cam, name))
         assert counts == base_counts, (cam, name)
     # the multi-GPU split: rows dealt out in bands, every part launches its own share of the rectangle
     for parts in ((3, 16), (2, 64), (5, 48)):
-        img, counts = _render(world, camera, 3, {"RTC_AMD_SCENE_RECT": "2"}, monkeypatch, parts=parts)
-        H.assert_images_equal(img, exp, "%s: %d parts of %d-row bands" % ((cam,) + parts))
-        assert counts == base_counts, (cam, parts)
+        for env in ({"RTC_AMD_SCENE_RECT": "2", "RTC_AMD_SCENE_TILES": "0"}, {}):  # (the rectangle per part; tile lists per part where the scene has them)
+            img, counts = _render(world, camera, 3, env, monkeypatch, parts=parts)
+            H.assert_images_equal(img, exp, "%s: %d parts of %d-row bands %s" % ((cam,) + parts + (env,)))
+            assert counts == base_counts, (cam, parts, env)
 
 
 PLANE_CAMERAS = {
@@ -136,11 +138,14 @@ def test_rectangle_with_the_librarys_own_hierarchy(monkeypatch):
     world, _, depth = scenes.sphere_grid(64, 64)
     camera = P.Camera(517, 389, float(np.pi / 3), P.view_transform(P.point(0, 30, -40), P.point(4, 0, 7), P.vector(0, 1, 0)))
     exp, rays = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=8)
-    off, off_counts = _render(world, camera, depth, {"RTC_AMD_SCENE_RECT": "0"}, monkeypatch)
+    off, off_counts = _render(world, camera, depth, {"RTC_AMD_SCENE_RECT": "0", "RTC_AMD_SCENE_TILES": "0"}, monkeypatch)
+    rect, rect_counts = _render(world, camera, depth, {"RTC_AMD_SCENE_TILES": "0"}, monkeypatch)
     on, on_counts = _render(world, camera, depth, {}, monkeypatch)
     H.assert_images_equal(off, exp, "whole grid")
-    H.assert_images_equal(on, exp, "rectangle")
-    assert on_counts == off_counts and on_counts[0] == rays
-    img, counts = _render(world, camera, depth, {}, monkeypatch, parts=(4, 32))
-    H.assert_images_equal(img, exp, "rectangle, 4 parts")
-    assert counts == on_counts
+    H.assert_images_equal(rect, exp, "rectangle")
+    H.assert_images_equal(on, exp, "tile list (zero-fill + the tiles the spheres project to)")
+    assert on_counts == off_counts == rect_counts and on_counts[0] == rays
+    for parts in ((4, 32), (3, 64), (2, 16)):
+        img, counts = _render(world, camera, depth, {}, monkeypatch, parts=parts)
+        H.assert_images_equal(img, exp, "tile lists, %d parts of %d-row bands" % parts)
+        assert counts == on_counts
