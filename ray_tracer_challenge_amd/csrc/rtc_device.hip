@@ -1257,6 +1257,13 @@ static rtc_status flatten(const Policy& P, const rtc_scene* scene, const rtc_cam
             }
             (*soa)[18 * (size_t)np + i].w = std::isfinite(E) ? (float)E : INFINITY;  // trn.w
             (*soa)[3 * (size_t)np + i].w = (float)errB;                             // off2.w
+            if (ob.kind == RTC_SPHERE) {
+                // light_cull_mask's cone pre-test: half the parallelogram's longer diagonal in this sphere's space, 0.1 % up
+                double d02 = 0.0, d13 = 0.0;
+                for (int r = 0; r < 3; r++) d02 += ((double)c[0][r] - c[2][r]) * ((double)c[0][r] - c[2][r]), d13 += ((double)c[1][r] - c[3][r]) * ((double)c[1][r] - c[3][r]);
+                const double hdl = 0.5 * std::sqrt(std::fmax(d02, d13)) * 1.001;
+                (*soa)[3 * (size_t)np + i].w = std::isfinite(hdl) && hdl > 0.0 ? (float)hdl : 0.0f;
+            }
         }
     } else if (l.kind != RTC_LIGHT_POINT) {
         return fail(RTC_ERR_UNSUPPORTED, "light kind %d", l.kind);

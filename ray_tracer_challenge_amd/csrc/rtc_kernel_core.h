@@ -1795,6 +1795,24 @@ DI uint32_t light_cull_mask(const SceneHdr& H, const SceneSoA& S, V3 p, bool& da
             const float oo = o.x * o.x + o.y * o.y + o.z * o.z;
             auto edge = [&](int k) { return corner(k) - o; };  // object-space vector from the shade point to corner k
             const V3 m = edge(0) + edge(2);                    // towards the parallelogram's centre: inside the pyramid
+#ifndef RTC_NO_CONE_PRETEST  // development: A/B
+            if (kind == RTC_SPHERE) {
+                // B1 (cone first).  Most shade points see the light far from the sphere: there the cone around the direction to the
+                // light's centre that holds the whole parallelogram (half its longer diagonal, off2.w from the host, plus what E1 can
+                // move it by) misses the inflated sphere -- theta > alpha + beta, in cosines c . w < sqrt(cc - hd^2) sqrt(oo - R^2) - hd R
+                // -- and the four face planes of the pyramid (a hundred operations) need not be formed.  Decided by the wave.
+                grow2 = fmaxf(grow2, 1.0f + 1.9073486e-6f * oo);  // (B5, `reach`: also for a sphere this test removes)
+                const float R2 = LIGHT_CULL_INFLATE2 * (1.0f + 1.9073486e-6f * oo), ro = __builtin_amdgcn_sqrtf(oo);
+                const float hd = ob.off2.w + 2.0f * E + 7.2e-7f * ro;  // (4 u |o|, three times over: o's own rounding beyond E's 103 radii)
+                const V3 c = m * 0.5f;
+                const float cc = dot3(c, c);
+                const float rhs = hd * __builtin_amdgcn_sqrtf(R2) - __builtin_amdgcn_sqrtf(cc - hd * hd) * __builtin_amdgcn_sqrtf(oo - R2);  // NaN: inside, or too close
+                if (__all(oo > 1.001f * R2 && oo < 1e12f && dot3(c, o) > rhs && ob.off2.w > 0.0f)) {
+                    mask |= 1u << i;
+                    return;
+                }
+            }
+#endif
             bool narrow = true, outside = false, leaving = true, entering = true;
             const float c_own = oo - 1.0f;  // the sphere quadratic's constant term, as the exact test computes it
             // Cubes and bounded cylinders: their own box [-1, 1] x [min_y, max_y] x [-1, 1] instead of the sphere around it
