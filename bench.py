@@ -407,7 +407,9 @@ def main(argv=None):
                        "partition": "64-row bands round-robin over %d part(s)%s" % (
                            world_size + extra_parts, (", rank 0 renders %d of them; RCCL gather of f32 rows to rank 0"
                                                       % (extra_parts + 1)) if world_size > 1 else "")},
-            "tested_rays_per_s": round((rays - culled) / (elapsed / args.steps), 1),
+            # three significant digits: how many rays the cull answers is decided wave by wave (votes over 64 lanes), and which pixels
+            # share a wave follows the frame's schedule -- the count moves in its fourth digit from run to run, the image and `rays` never
+            "tested_rays_per_s": float("%.3g" % ((rays - culled) / (elapsed / args.steps))),
             "schedule": {"blocks": "16x16-pixel blocks; first frame of a scene in image order permuted within four block rows (each XCD "
                                    "along half a row), later frames longest first by the work counts (rays, shade points) of the frame "
                                    "before -- every frame traces every ray",

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the per-scene rocprofv3 evidence of one round (on the GPU box, from the repo root):
 #   bash profiles/run_all.sh r03        -> gpurun_out/prof_r03_<scene>/ ; summarise each with profiles/summarize.py <tag>_<scene>
-TAG=${1:-r03}
+TAG=${1:-r04}
 bash profiles/run_profile.sh ${TAG}_c3
 bash profiles/run_profile.sh ${TAG}_c4 "--workload C4"
 bash profiles/run_profile.sh ${TAG}_c5 "--workload C5"

@@ -352,7 +352,7 @@ static uint32_t choose_share_log2(const SceneHdr& hdr, uint32_t rows, const Poli
     if (!area && !runs) return 0u;
     if (P.share_log2 >= 0) return (uint32_t)P.share_log2;
     const uint64_t waves = ((uint64_t)hdr.width * rows + 63) / 64;
-    // measured (tools/sweep_block_s.sh), ms with 2 / 4 / 8 lanes per pixel in the mesh tiles: here_be_dragons 1000 x 400 (6 k
+    // measured (tools/ab_env.py over RTC_AMD_BLOCK_S, round 3), ms with 2 / 4 / 8 lanes per pixel in the mesh tiles: here_be_dragons 1000 x 400 (6 k
     // waves) 1.33 / 0.93 / 0.77, 2000 x 800 (25 k) 1.61 / 1.41 / 1.50, 4000 x 1600 (100 k) 3.25 / 3.57 / 4.80; mesh 512 x 384
     // (3 k) 3.81 / 2.54 / 2.05, 1024^2 (16 k) 3.12 / 2.58 / 3.13, 2048^2 (65 k) 3.65 / 4.37 / 5.86, 4096^2 (262 k) 8.5 / 11.1 / 16.8
     if (runs) return choose_share_log2_runs(waves);
@@ -1552,7 +1552,7 @@ rtc_status jit_get(const Policy& P, int device, const std::vector<std::string>& 
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
     for (const auto& d : defines) opts.push_back(d);
     // occupancy target of the specialised kernel: measured 4 -> 3.39, 5 -> 3.42, 6 -> 3.24, 7 -> 3.17, 8 -> 3.17 ms (C3) before
-    // light-cone culling; with it (more state per shade point) 5 -> 0.98, 6 -> 0.97, 7 -> 0.95, 8 -> 1.02 ms (tools/ab_waves.sh)
+    // light-cone culling; with it (more state per shade point) 5 -> 0.98, 6 -> 0.97, 7 -> 0.95, 8 -> 1.02 ms (tools/ab_env.py over -DRTC_WAVES_PER_SIMD)
     bool waves_given = false;
     for (const auto& d : defines) waves_given = waves_given || d.rfind("-DRTC_WAVES_PER_SIMD=", 0) == 0;
     if (!waves_given) opts.push_back("-DRTC_WAVES_PER_SIMD=7");
@@ -1881,7 +1881,7 @@ static void build_block_list(const Policy& P, const rtc_ctx_tiles& T, uint32_t w
 // run to 3.4.  The first launch of a list therefore times its waves (RenderArgs::wave_ticks), and the list of every later frame
 // of this scene and partition is made from those times: a 16 x 16 tile whose longest wave ran more than half of the frame's
 // throughput time (the sum of all waves' times over the wave slots of the device) gets more lanes per pixel, each doubling
-// taken to shorten its waves to 0.7 (measured: tools/sweep_block_s.sh), and the tiles start in the order of their predicted
+// taken to shorten its waves to 0.7 (measured: tools/ab_env.py over RTC_AMD_BLOCK_S), and the tiles start in the order of their predicted
 // longest wave.  Which lanes trace a pixel and when changes nothing about its value (tests/test_gpu_fullsize.py compares first
 // and later frames with the oracle).
 static void refine_block_list(const std::vector<uint32_t>& list, const uint32_t* ticks /* [4 list.size()] */, uint32_t width, uint32_t rows, double wave_slots,

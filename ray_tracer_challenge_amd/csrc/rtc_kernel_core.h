@@ -2141,8 +2141,8 @@ DI V3 point_on_light(V3 corner, V3 uvec, V3 vvec, float a, float b) {
 // block meets a caster: its four samples are LIT -- total += 4, four rays counted, no jitter hashed.  In cosines, multiplied
 // through by |c| |w|:  c . w < sqrt(cc - hd2x^2) sqrt(ww - R^2) - hd2x R.  The decision is taken by the WAVE (a vote): the blocks some
 // lane cannot call lit are sampled by every lane exactly as before, so the loop stays the loop it was -- one cell at a time, the
-// same cell in every lane.  (The same vote for single cells inside a block that failed: 6 % fewer samples, and 20 % slower -- the
-// loop body doubles.  Round 4 first built the finer thing -- cells decided one by one, LIT and BLOCKED, every lane sampling
+// same cell in every lane.  (The same vote for single cells inside a block that failed: 6 % fewer samples, and 20 - 28 % slower, rolled
+// or unrolled.  Round 4 first built the finer thing -- cells decided one by one, LIT and BLOCKED, every lane sampling
 // its own list of undecided cells: 3.5 times fewer samples on C3, and slower: lanes that sample different cells share no hash
 // schedule, no uniform branches, and nearly every round has some lane on the exact path.  LABNOTES.md "Round 4".)
 // Everything is evaluated in the sphere's own space, where the exact test lives: o (the exact test's own object-space shade

@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 3, final evidence set in one GPU call: profiles (kernel trace + PMC) of eight scenes, timelines, configuration table, whole-frame verification, bench line
-TAG=${1:-r03}
+# a round's final evidence set (bash tools/final_evidence.sh r04): profiles (kernel trace + PMC) of eight scenes, timelines, configuration table, whole-frame verification, bench line
+TAG=${1:-r04}
 mkdir -p gpurun_out/$TAG
 bash profiles/run_all.sh $TAG > gpurun_out/$TAG/run_all.log 2>&1
 for s in c3 c4 c5 hexagons mesh dragons reflect_refract first_textures; do python profiles/summarize.py ${TAG}_$s > gpurun_out/$TAG/summary_$s.json 2> gpurun_out/$TAG/summary_$s.err || echo "summarize $s failed"; done
