@@ -2235,10 +2235,10 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
                 const float oo = pre[i].c + 1.0f, R2 = 1.0609f * (1.0f + 1.9073486e-6f * oo);
                 S_lit[i] = (oo > 1.001f * R2 && oo < 2.5e5f) ? __builtin_amdgcn_sqrtf(oo - R2) : RTC_NAN;  // (NaN: no comparison holds -- this lane calls nothing lit)
             }
-            const V3 base = corner + uvec + vvec - p;  // centre of block (0, 0) as seen from p
             for (int vb = 0; vb < H.v_steps; vb += 2) {
-                V3 c = base + vvec * (float)vb;
                 for (int ub = 0; ub < H.u_steps; ub += 2) {
+                    // the block's centre as seen from p (formed anew per block from the loop counters: two vectors less to keep across the samples)
+                    const V3 c = point_on_light(corner, uvec, vvec, (float)(ub + 1), (float)(vb + 1)) - p;
                     const float cc = __builtin_fmaf(c.x, c.x, __builtin_fmaf(c.y, c.y, c.z * c.z));
                     const float sq = __builtin_amdgcn_sqrtf(cc - hd2);  // NaN when the shade point is within the cone's base radius of the centre
                     bool lit = true;
@@ -2270,7 +2270,6 @@ DI float intensity_at(const SceneHdr& H, const SceneSoA& S, V3 p, uint32_t pixel
                             if (!sample_blocked<NOBJ, SIMPLE>(H, S, pre, lp, p, cnt, skip, fast)) total += 1.0f;
                         }
                     }
-                    c = c + uvec * 2.0f;
                 }
             }
             return total / H.cells_f;

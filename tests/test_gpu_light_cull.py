@@ -51,8 +51,8 @@ def _random_world(rng, n_objects, jitter):
     u = axes[0] / max(np.linalg.norm(axes[0]), 1e-6) * rng.uniform(0.3, 3)
     v = axes[1] / max(np.linalg.norm(axes[1]), 1e-6) * rng.uniform(0.3, 3)
     # 3..5 steps each way: the cull is only attempted for lights of >= 8 cells
-    light = P.RectangleLight(P.color(1.2, 1.1, 1.0), P.point(*corner), P.vector(*u), int(rng.integers(3, 6)), P.vector(*v),
-                             int(rng.integers(3, 6)), jitter)
+    light = P.RectangleLight(P.color(1.2, 1.1, 1.0), P.point(*corner), P.vector(*u), int(rng.integers(3, 7)), P.vector(*v),
+                             int(rng.integers(3, 7)), jitter)
     return P.World(objs, light)
 
 
@@ -311,3 +311,48 @@ def test_fast_sample_decision_changes_nothing_on_random_simple_scenes(seed, monk
         for key in ("rays", "shaded_hits"):
             assert frames["1"][1][key] == frames["0"][1][key], (seed, spec, key)
         assert frames["1"][1]["rays"] == rays
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_block_cones_call_blocks_lit_and_change_nothing(seed, monkeypatch):
+    """ERROR_BUDGET.md B10: for shade points the whole-light cull leaves, 2 x 2 blocks of the light's cells whose cone misses every casting
+    sphere are called lit by the wave without a sample.  Worlds of uniformly scaled casting spheres over a floor under lights with even
+    step counts (the only ones the blocks apply to), tiny to huge, near and far: the image and the ray count are the oracle's with the
+    blocks on and off, and with them on more rays are answered without a sample."""
+    from ray_tracer_challenge_amd.renderer import Renderer
+    rng = np.random.default_rng(900 + seed)
+    S = float(10.0 ** rng.uniform(-1.5, 1.5))
+    objs = [P.Plane(P.translation(0.0, float(-1.0 * S), 0.0), P.Material(color=(0.9, 0.9, 0.8), specular=0.0))]
+    for _ in range(int(rng.integers(1, 4))):
+        r = S * float(10.0 ** rng.uniform(-1.0, 0.0))
+        if rng.random() < 0.15:
+            r = -r  # a mirrored sphere: the sign of g
+        objs.append(P.Sphere(P.chain(P.translation(*[float(v) for v in rng.uniform(-2, 2, 3) * S]), P.scaling(r, r, r)),
+                             P.Material(color=tuple(rng.uniform(0.2, 1, 3)), reflective=float(rng.choice([0.0, 0.4])), specular=0.0)))
+    us, vs = [(4, 4), (10, 10), (2, 8), (6, 4)][seed % 4]
+    if rng.random() < 0.5:
+        u, v = np.array([rng.uniform(0.5, 3) * S, 0, 0]), np.array([0, 0, rng.uniform(0.5, 3) * S])
+    else:
+        u = rng.normal(size=3)
+        v = np.cross(u, rng.normal(size=3))
+        u, v = u / np.linalg.norm(u) * rng.uniform(0.5, 3) * S, v / np.linalg.norm(v) * rng.uniform(0.5, 3) * S
+    light = P.RectangleLight(P.color(1.2, 1.1, 1.0), P.point(*[float(x) for x in (rng.uniform(-2, 2, 3) + np.array([0, 5, 0])) * S]), P.vector(*[float(x) for x in u]), us,
+                             P.vector(*[float(x) for x in v]), vs, ("hashed", seed) if seed % 3 else ("constant", float(rng.choice([0.0, 0.5, 1.0]))))
+    world = P.World(objs, light)
+    far = float(10.0 ** rng.uniform(0.7, 2.2))
+    cam = P.Camera(120, 88, float(min(1.2, 6.0 / far * 2.0)), P.view_transform(P.point(*[float(x) for x in (np.array([0.3, 0.6, -1.0]) * far * S)]), P.point(0, 0, 0), P.vector(0, 1, 0)))
+    exp, rays = H.oracle_camera(cam).render(H.oracle_world(world), 3, threads=8)
+    culled = {}
+    for cells in ("1", "0"):
+        for spec in ("0", "1"):
+            monkeypatch.setenv("RTC_AMD_CELL_CULL", cells)
+            monkeypatch.setenv("RTC_AMD_SPECIALIZE", spec)
+            r = Renderer(world, cam, device=0)
+            got = r.render(3).cpu().numpy()
+            st = r.stats()
+            r.close()
+            H.assert_images_equal(got, exp, "seed %d blocks %s specialise %s" % (seed, cells, spec))
+            assert st["rays"] == rays
+            culled[(cells, spec)] = st["culled_shadow_rays"]
+    assert culled[("1", "1")] >= culled[("0", "1")] and culled[("1", "0")] >= culled[("0", "0")], culled
+

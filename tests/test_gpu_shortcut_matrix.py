@@ -107,7 +107,7 @@ def test_samples_grazing_a_caster(kind, r, off):
         u = _perp(rng, up) * ls * r
         v = np.cross(up, u / np.linalg.norm(u)) * ls * r
         corner = c + up * (rho0 * ld + 0.0) - 0.5 * (u + v) if ld > 1.5 else c + up * rho0 * ld
-        steps = (4, 3)
+        steps = [(4, 4), (4, 3), (6, 2)][int(rng.integers(0, 3))]  # (even counts both ways: the block cones, B10; otherwise the plain loop)
         world = P.World([shape], _area_light(corner, u / steps[0], v / steps[1], steps, jitter))
         light_pts = [corner + u * a + v * b for a in (0.0, 0.5, 1.0) for b in (0.0, 0.5, 1.0)]
         pts = []
@@ -134,7 +134,8 @@ def test_shade_points_on_and_just_off_a_sphere(r, off, uniform):
         u = _perp(rng, up) * ls * r
         v = np.cross(up, u / np.linalg.norm(u)) * ls * r
         corner = c + up * r * ld - 0.5 * (u + v)
-        world = P.World([sphere], _area_light(corner, u / 4, v / 3, (4, 3), jitter))
+        steps = [(4, 4), (4, 3), (2, 6)][int(rng.integers(0, 3))]
+        world = P.World([sphere], _area_light(corner, u / steps[0], v / steps[1], steps, jitter))
         pts = []
         for eps in [1e-7, 1e-6, 1e-5, 9e-5, 1.1e-4, 1e-3, 1.2e-3, 1e-2, 0.09, 0.11, 0.2, 0.25]:
             for _ in range(14):
@@ -172,7 +173,8 @@ def test_a_non_caster_just_in_front_of_or_behind_a_caster(r, off):
         w = _perp(rng, axis)
         u, v = w * r, np.cross(axis, w) * r
         corner = p0 + axis * (near + 3.0 * r) - 0.5 * (u + v)
-        world = P.World([caster, shade], _area_light(corner, u / 3, v / 3, (3, 3), ("hashed", 11)))
+        steps = (4, 4) if rng.random() < 0.5 else (3, 3)
+        world = P.World([caster, shade], _area_light(corner, u / steps[0], v / steps[1], steps, ("hashed", 11)))
         pts = [p0 + (w * rng.uniform(-1.2, 1.2) + np.cross(axis, w) * rng.uniform(-1.2, 1.2)) * r for _ in range(40)]
         _check_intensity(world, pts, "non-caster (%s) at %+g of the caster's far side, r=%g offset=%g, %g radii away" % (kind, gap, r, off, dr))
 
@@ -197,7 +199,8 @@ def test_planes_at_the_lights_own_height(scale, off):
         plane_y = c[1] + dy * S
         floor = P.Plane(P.translation(0.0, float(plane_y), 0.0), _mat())
         ball = P.Sphere(P.chain(P.translation(*[float(x) for x in (c + np.array([0.0, 0.4 * S, 1.0 * S]))]), P.scaling(0.2 * S, 0.2 * S, 0.2 * S)), _mat())
-        world = P.World([floor, ball], _area_light(corner, u / 4, v / 3, (4, 3), jitter))
+        steps = (4, 4) if rng.random() < 0.5 else (4, 3)
+        world = P.World([floor, ball], _area_light(corner, u / steps[0], v / steps[1], steps, jitter))
         pts = []
         for h in [1.2e-3 * S, -1.2e-3 * S, 1e-6 * S, -1e-6 * S, 0.0, 0.3 * S, -0.3 * S, 1e-2 * S]:
             for _ in range(12):

@@ -97,7 +97,7 @@ def _leaf(api, rng, at, size, rotate, thin=False, kinds=("sphere", "sphere", "cu
     return (api.Cylinder if kind == "cylinder" else api.Cone)(t, m, casts_shadow=casts, **kw)
 
 
-def _light(api, rng, seed, at, size, area=None, steps=(3, 6), aligned=None):
+def _light(api, rng, seed, at, size, area=None, steps=(2, 7), aligned=None):
     """A point light at `at`, or an area light of edge ~`size` whose corner is `at`."""
     if area is None:
         area = rng.random() < 0.65
@@ -216,7 +216,7 @@ def world(seed, api):
             if rng.random() < 0.7:
                 g.divide(int(rng.integers(1, 4)))
             objs.append(g)
-        light = _light(api, rng, seed, C + (rng.uniform(-3, 3, 3) + np.array([0.0, 6.0, -3.0])) * S, S * _lu(rng, 0.05, 2.0), steps=(2, 5))
+        light = _light(api, rng, seed, C + (rng.uniform(-3, 3, 3) + np.array([0.0, 6.0, -3.0])) * S, S * _lu(rng, 0.05, 2.0), steps=(2, 7))
         camera = _camera(api, rng, C + (rng.uniform(-2, 2, 3) + np.array([0.0, 1.5, -10.0])) * S, C)
     elif style == 5:
         for k in range(int(rng.integers(1, 3))):
@@ -228,7 +228,7 @@ def world(seed, api):
             objs.append(g)
         if rng.random() < 0.5:
             objs.append(_floor(api, rng, C, S))
-        light = _light(api, rng, seed, C + (rng.uniform(-3, 3, 3) + np.array([0.0, 6.0, -3.0])) * S, S * _lu(rng, 0.05, 2.0), area=rng.random() < 0.3, steps=(2, 4))
+        light = _light(api, rng, seed, C + (rng.uniform(-3, 3, 3) + np.array([0.0, 6.0, -3.0])) * S, S * _lu(rng, 0.05, 2.0), area=rng.random() < 0.3, steps=(2, 7))
         far = _lu(rng, 6.0, 300.0)
         camera = _camera(api, rng, C + _unit(rng) * np.array([1.0, 0.5, 1.0]) * far * S, C + rng.uniform(-0.5, 0.5, 3) * S, fov=min(1.2, 4.0 / far))
         depth = int(rng.integers(0, 6))
@@ -236,7 +236,7 @@ def world(seed, api):
         for k in range(int(rng.integers(16, 40))):
             objs.append(_leaf(api, rng, C + rng.uniform(-4, 4, 3) * S, S * _lu(rng, 0.01, 1.0) if rng.random() < 0.85 else size_of(), rotate,
                               kinds=("sphere", "sphere", "cube"), uniform=rng.random() < 0.7))
-        light = _light(api, rng, seed, C + (rng.uniform(-3, 3, 3) + np.array([0.0, 7.0, -4.0])) * S, S * _lu(rng, 0.05, 2.0), area=rng.random() < 0.3, steps=(2, 4))
+        light = _light(api, rng, seed, C + (rng.uniform(-3, 3, 3) + np.array([0.0, 7.0, -4.0])) * S, S * _lu(rng, 0.05, 2.0), area=rng.random() < 0.3, steps=(2, 7))
         far = _lu(rng, 5.0, 300.0)
         camera = _camera(api, rng, C + _unit(rng) * far * S, C + rng.uniform(-1, 1, 3) * S, fov=min(1.3, 10.0 / far))
     else:  # grazing
@@ -262,5 +262,5 @@ def world(seed, api):
             rim = at + np.array([view[0], 0.0, view[2]]) * (-far * _lu(rng, 1.0, 100.0))  # towards the horizon
         window = r * _lu(rng, 1e-4, 0.3)  # what the image spans at the object
         camera = _camera(api, rng, frm, rim, fov=max(2.0 * np.arctan(0.5 * window / far), 1e-4))  # (pixels stay apart in f32 directions)
-        light = _light(api, rng, seed, C + (rng.uniform(-3, 3, 3) + np.array([0.0, 5.0, 0.0])) * S, S * _lu(rng, 0.05, 2.0), steps=(2, 5))
+        light = _light(api, rng, seed, C + (rng.uniform(-3, 3, 3) + np.array([0.0, 5.0, 0.0])) * S, S * _lu(rng, 0.05, 2.0), steps=(2, 7))
     return api.World(objs, light), camera, depth, STYLE_NAMES[style]
