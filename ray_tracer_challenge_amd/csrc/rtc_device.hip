@@ -2384,7 +2384,10 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
             // 0.198 -> 0.188, first_plane / first_patterns -2 %, first_scene +1 % (profiles/r03_ab_point_light_policy.txt)
             defs.push_back("-DRTC_SPEC_STASH=0");
             if (any_refl || any_refr) defs.push_back("-DRTC_SPEC_LDS_FRAMES=5");
-            defs.push_back("-DRTC_WAVES_PER_SIMD=5");
+            // ... and FOUR where the world both reflects and transmits and has five objects or more (round 4): reflect_refract's
+            // kernel spills 20 registers at five waves (96 VGPRs) and none at four (128) -- 0.874 -> 0.775 ms; skybox (two objects)
+            // and the scenes without glass lose up to 12 % at four (profiles/r04_ab_point_light_waves.txt)
+            defs.push_back((any_refl && any_refr && n >= 5u) ? "-DRTC_WAVES_PER_SIMD=4" : "-DRTC_WAVES_PER_SIMD=5");
         }
         spec_name = "render_kernel_spec[" + list.substr(16) + (c->simple ? ";simple" : "") + (hdr.has_patterns ? ";patterns" : "") + (hdr.n_gates ? ";gates" : "") + "]";
     } else if (n > 8) {
