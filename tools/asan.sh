@@ -18,4 +18,10 @@ for seed in list(range(0, 120)) + list(range(4000, 4040)) + list(range(9000, 904
     world.validate(P.Camera(*cam))
     world.validate(None)
 print("validate sweep clean")
+from tests import wide_worlds as W   # the wide generator: thin scalings, far offsets, many objects, meshes -- every host-side guard of ERROR_BUDGET.md
+for seed in range(0, 400):
+    world, cam, depth, style = W.world(seed, P)
+    world.validate(P.Camera(*cam))
+    world.validate(None)
+print("wide validate sweep clean")
 PY
