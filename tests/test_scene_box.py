@@ -149,3 +149,32 @@ def test_rectangle_with_the_librarys_own_hierarchy(monkeypatch):
         img, counts = _render(world, camera, depth, {}, monkeypatch, parts=parts)
         H.assert_images_equal(img, exp, "tile lists, %d parts of %d-row bands" % parts)
         assert counts == on_counts
+
+
+@pytest.mark.parametrize("specialise", ["0", "1"])
+def test_thin_discs_seen_from_thousands_of_their_own_units(specialise, monkeypatch):
+    """ERROR_BUDGET.md B8 / E2: a sphere scaled 1e-2 .. 1e-3 across, seen from twenty units, is thousands of its OWN units from the
+    camera, and the reference's f32 quadratic reports hits for lines that pass radii away from it -- two thirds of this frame's lit
+    pixels lie outside the discs' true silhouettes.  A world-space padding cannot hold those (round 4's wide fuzz found three such
+    worlds, all cured by RTC_AMD_SCENE_BOX=0); the box, the rectangle and the tile list now stand down for a leaf the camera
+    is more than ~100 of its own units from.  Whatever is switched on or off, the frame is the oracle's."""
+    m = P.Material(color=(0.3, 0.9, 0.3), ambient=0.3, diffuse=0.7, specular=0.0)
+    objs = [P.Sphere(P.chain(P.translation(0.0, 0.0, 0.0), P.rotation_y(0.9), P.rotation_x(0.4), P.scaling(0.6, 0.6, 0.007)), m),
+            P.Sphere(P.chain(P.translation(2.5, 1.0, 1.0), P.rotation_x(1.2), P.scaling(0.6, 0.0024, 0.6)), m),
+            P.Cube(P.chain(P.translation(-2.5, -1.0, 0.5), P.rotation_y(0.3), P.scaling(0.6, 0.55, 0.007)), m)]
+    world = P.World(objs, P.PointLight(P.point(-5, 8, -20), P.color(1, 1, 1)))
+    camera = P.Camera(160, 120, 0.7, P.view_transform(P.point(-5, 5, -20), P.point(0, 0, 0), P.vector(0, 1, 0)))
+    monkeypatch.setenv("RTC_AMD_SPECIALIZE", specialise)
+    exp, rays = H.oracle_camera(camera).render(H.oracle_world(world), 1, threads=8)
+    assert (exp.sum(axis=2) > 0).sum() > 500  # (the discs' true silhouettes cover 176 pixels, the plate some 150)
+    for env in ({}, {"RTC_AMD_SCENE_BOX": "0", "RTC_AMD_SCENE_RECT": "0", "RTC_AMD_SCENE_TILES": "0"}, {"RTC_AMD_SCENE_RECT": "2"}):
+        img, counts = _render(world, camera, 1, env, monkeypatch)
+        H.assert_images_equal(img, exp, "thin discs %s" % env)
+        assert counts[0] == rays
+    # ... and the same discs many to a frame (the library's own hierarchy asks for a scene within 100 of its SMALLEST half-axis: not built)
+    many = [P.Sphere(P.chain(P.translation(float(i % 5) - 2.0, float(i // 5) - 1.5, 0.0), P.rotation_y(0.2 * i), P.scaling(0.3, 0.3, 0.004)), m) for i in range(20)]
+    world = P.World(many, world.light)
+    exp, rays = H.oracle_camera(camera).render(H.oracle_world(world), 1, threads=8)
+    img, counts = _render(world, camera, 1, {}, monkeypatch)
+    H.assert_images_equal(img, exp, "twenty thin discs")
+    assert counts[0] == rays
