@@ -59,3 +59,19 @@ def test_rendering_with_a_cycle_is_refused():
     assert "sequence jitter" in str(e.value)
     with pytest.raises(P.RtcError):
         P.RectangleLight(P.color(1, 1, 1), P.point(0, 0, 0), P.vector(1, 0, 0), 2, P.vector(0, 1, 0), 2, ("cycle", [0.5] * 17))._c()
+
+
+@pytest.mark.gpu
+def test_point_on_light_with_the_other_jitter_sources():
+    """rtc_point_on_light for the hashed and the constant source against the oracle's point_on_light (pixel 0, path 1: the key a
+    freshly built light's first question has), every cell of a slanted 5 x 4 light."""
+    from oracle import oracle as O
+    corner, u, v = (-1.25, 2.5, 0.75), (1.5, 0.25, -0.5), (0.1, 1.0, 0.6)
+    cells = [[a, b] for b in range(4) for a in range(5)]
+    for jitter in (("hashed", 12345), ("hashed", 0x5EED5EED), ("constant", 0.5), ("constant", 0.0), ("constant", 1.0)):
+        light = P.RectangleLight(P.color(1, 1, 1), P.point(*corner), P.vector(*u), 5, P.vector(*v), 4, jitter)
+        got = light.point_on_light(cells)
+        own = O.World([], O.RectangleLight(O.color(1, 1, 1), O.point(*corner), O.vector(*u), 5, O.vector(*v), 4, jitter))
+        own.set_pixel(0)
+        for (a, b), g in zip(cells, got):
+            assert np.array_equal(g, own.point_on_light(a, b)), (jitter, a, b, g, own.point_on_light(a, b))
