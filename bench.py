@@ -63,6 +63,9 @@ def parse(argv=None):
                     "(N+E)-way band split; -1 = from the measured gather/render ratio, 0 = even split")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not collect the roofline's counters live (three short child runs of this "
+                    "script under `rocprofv3 --pmc`, one counter group each); quote them from the committed profiles/*_pmc.json whose "
+                    "kernel id matches instead")
     ap.add_argument("--force-dist", action="store_true", help="N=1: run the multi-GPU code path all the same -- init_process_group, the "
                     "band gather through dist.gather on the communication stream, its calibration and the u8 wire pass -- with ONE "
                     "rank (proves on a one-GPU box that RCCL loads, a communicator is created and the stream hand-off is right)")
@@ -389,7 +392,13 @@ def main(argv=None):
         # roofline of the dominant kernel (render_kernel) on THIS rank: per-launch algorithmic bytes / mean duration
         algo_bytes = st["rays"] * n_obj * 64 + st["shaded_hits"] * 48 + st["pixels"] * 12
         achieved = algo_bytes / (st["kernel_ms"] * 1e-3) / 1e9 if st["kernel_ms"] > 0 else 0.0
-        pmc = matching_pmc_summary(renderer.kernel_id, args.scene, camera.width, camera.height) if world_size == 1 else None
+        pmc = None
+        if world_size == 1 and not args.no_live_pmc and not args.force_dist:
+            lp = live_pmc(args, renderer.kernel_id)
+            if lp is not None:
+                pmc = ("live", lp)
+        if pmc is None and world_size == 1:
+            pmc = matching_pmc_summary(renderer.kernel_id, args.scene, camera.width, camera.height)
         verify = None
         if not args.no_verify and image is not None and image.dtype == torch.float32:
             verify = verify_rows(image, world, camera, depth)  # (the GATHERED frame when the collectives ran)
@@ -483,6 +492,55 @@ def matching_pmc_summary(kernel_id, scene, width, height):
     return best
 
 
+def live_pmc(args, kernel_id):
+    """The dominant kernel's counters measured NOW: this script again, a few steps, as a child of `rocprofv3 --pmc <one group>` (never
+    combined with a trace domain; the program itself after `--`), once per group -- VALU instructions, then the two HBM-side byte
+    counters of MI355X_MICROARCH.md's recipe (separate passes; bytes = (2 FETCH_SIZE + WRITE_SIZE) x 1024).  Medians over the frames'
+    dispatches (the one-workgroup warm-up dispatch left out).  None if rocprofv3 is missing, fails, times out, or profiled another
+    kernel than the one this process timed: the caller falls back to the committed summary."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):  # (already under a profiler: not twice)
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--cpu-seconds", "0", "--no-verify", "--no-one-shot", "--no-live-pmc",
+             "--scene", args.scene, "--size", str(args.width), "--height", str(args.height_px)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="rtc_pmc_", dir="/tmp")
+    try:
+        for group in (["SQ_INSTS_VALU"], ["FETCH_SIZE"], ["WRITE_SIZE"]):
+            d = os.path.join(tmp, group[0])
+            r = subprocess.run([exe, "--pmc"] + group + ["--output-format", "csv", "-d", d, "--"] + child, env=env, cwd="/tmp", capture_output=True, text=True, timeout=180)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines or json.loads(lines[-1])["roofline"]["kernel_id"] != kernel_id:
+                return None
+            if os.environ.get("RTC_BENCH_PMC_DEBUG"):
+                print("live pmc child: %s\n%s" % (" ".join(child), lines[-1][:1500]), file=sys.stderr)
+            vals = {}
+            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "render_kernel" in row["Kernel_Name"] and int(row["Grid_Size"]) > 256:
+                        vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for name in group:
+                v = sorted(vals.get(name, []))
+                if not v:
+                    return None
+                out[name] = v[len(v) // 2]
+                if os.environ.get("RTC_BENCH_PMC_DEBUG"):
+                    print("live pmc %s: %s" % (name, v), file=sys.stderr)
+        return {"counters_mean_per_launch": {"SQ_INSTS_VALU": out["SQ_INSTS_VALU"]}, "hbm_bytes_per_launch": (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0,
+                "live": True}
+    except Exception:  # noqa: BLE001 -- informational: never costs the headline line
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def valu_roofline(pmc, kernel_ms, renderer):
     out = {"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_TOPS, 1), "unit": "Tlane-op/s", "frac": None, "traffic": None,
            "kernel": renderer.kernel_name, "kernel_id": renderer.kernel_id, "kernel_ms": round(kernel_ms, 4), "pmc_source": None}
@@ -495,8 +553,9 @@ def valu_roofline(pmc, kernel_ms, renderer):
     lane_ops = c["SQ_INSTS_VALU"] * 64.0
     tops = lane_ops / (kernel_ms * 1e-3) / 1e12
     out.update({"achieved": round(tops, 2), "frac": round(tops / VALU_PEAK_TOPS, 4), "traffic": m.get("hbm_bytes_per_launch"),
-                "valu_wave_insts_per_launch": c["SQ_INSTS_VALU"], "pmc_source": os.path.relpath(path, ROOT),
-                "profiled_kernel_ms": round(m.get("kernel_trace", {}).get("avg_ns", 0.0) / 1e6, 4),
+                "valu_wave_insts_per_launch": c["SQ_INSTS_VALU"],
+                "pmc_source": "live: child runs of this command under rocprofv3 --pmc, one counter group each" if m.get("live") else os.path.relpath(path, ROOT),
+                "profiled_kernel_ms": round(m.get("kernel_trace", {}).get("avg_ns", 0.0) / 1e6, 4) if not m.get("live") else None,
                 "note": "FP32 VALU issue: PMC SQ_INSTS_VALU x 64 lanes per launch / this run's mean HIP-event kernel time, against "
                         "256 CU x 4 SIMD x 32 lanes x 2.4 GHz; traffic = (2 FETCH_SIZE + WRITE_SIZE) x 1024 B per launch (separate "
                         "--pmc passes), to be read against the %.0f MB f32 canvas store" % (renderer.width * renderer.height * 12 / 1e6)})

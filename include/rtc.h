@@ -364,7 +364,7 @@ const char* rtc_ctx_kernel_name(rtc_ctx* ctx);
  * Compiled kernels are cached in <library dir>/jit_cache, or RTC_AMD_JIT_CACHE=<dir> (0: memory only). */
 const char* rtc_ctx_jit_status(rtc_ctx* ctx);
 /* Names the CODE the current scene is rendered with -- "spec_<hash of kernel source, compile options and compiler
- * version>" or "aot_<hash of the kernel source>" -- so that a measurement taken of one kernel (the profiles/ *_pmc.json summaries)
+ * version>.<checksum of the compiled code object>" or "aot_<hash of the kernel source>" -- so that a measurement taken of one kernel (the profiles/ *_pmc.json summaries)
  * is never quoted for another: bench.py prints instruction counts and HBM traffic only from a summary whose id matches. */
 const char* rtc_ctx_kernel_id(rtc_ctx* ctx);
 /* canvas.rs:39-43 scale_color on the device: n f32 channel values -> n bytes

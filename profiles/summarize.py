@@ -63,7 +63,7 @@ if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
     out["hbm_method"] = "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes"
 # the stamp: what bench.py said it ran, in the traced run and in every counter run (they must agree)
 stamps = set()
-for log in [os.path.join(src, "trace.log")] + glob.glob(os.path.join(src, "pmc_*.log")):
+for log in [os.path.join(src, "trace.log")] + glob.glob(os.path.join(src, "pmc_*.log")) + glob.glob(os.path.join(src, "precompile.log")):
     for line in open(log, errors="replace"):
         if line.startswith("{") and '"roofline"' in line:
             b = json.loads(line)

@@ -1486,7 +1486,7 @@ struct CacheHeader {
 struct JitModule {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
-    std::string id;  // "spec_<hash of source, options, compiler version>": names the code that runs (rtc_ctx_kernel_id)
+    std::string id;  // "spec_<hash of source, options, compiler version>.<checksum of the code object>": names the code that runs (rtc_ctx_kernel_id)
 };
 std::mutex g_jit_mutex;
 std::map<std::string, JitModule> g_jit_cache;  // key: "<device>|<defines>"
@@ -1573,6 +1573,11 @@ rtc_status jit_get(const Policy& P, int device, const std::vector<std::string>& 
     (void)hiprtcVersion(&rtc_major, &rtc_minor);
     opt_text += "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + " abi " + std::to_string(RTC_ABI_VERSION) +
                 " args " + std::to_string(sizeof(RenderArgs)) + "\n";
+    // (Not in the key: WHICH libhiprtc this process holds.  A Python process that imported torch first compiles with the wheel's
+    // bundled compiler, the same script under rocprofv3 -- which puts /opt/rocm/lib first in LD_LIBRARY_PATH -- with the system's;
+    // both report one hiprtcVersion and emit different, equally valid code for these kernels (same images, same speed:
+    // profiles/r04_ab_compilers.txt).  Sharing the entry is what lets a profiled run measure the very code object a plain run
+    // compiled -- profiles/run_profile.sh compiles first, plainly -- and the id below says which binary it was.)
     char name[64];
     snprintf(name, sizeof(name), "spec_%016llx.hsaco", (unsigned long long)fnv1a(opt_text, fnv1a(core)));
     const std::string cache_dir = jit_cache_dir(P), cache_path = cache_dir + "/" + name;
@@ -1645,7 +1650,13 @@ rtc_status jit_get(const Policy& P, int device, const std::vector<std::string>& 
         if (le == hipSuccess) le = hipModuleGetFunction(&m.fn, m.mod, "render_kernel_spec");
     }
     if (le != hipSuccess) return fail(RTC_ERR_DEVICE, "scene specialisation: the compiled kernel does not load: %s", hipGetErrorString(le));
-    m.id = std::string(name, std::strlen(name) - 6);  // without ".hsaco"
+    // The id names the code object itself: "spec_<hash of source, options, compiler>.<checksum of the compiled code>".  The second
+    // half is there because one source does not always give one binary: a hiprtc compile inside a process started under rocprofv3
+    // came out different from the same compile in a plain process (LABNOTES "Round 4": 436 against 484 B of scratch per lane, 421 M
+    // against 387 M VALU instructions a C3 frame), and a profile must never be quoted for a binary it did not measure.
+    char sum[16];
+    snprintf(sum, sizeof(sum), ".%08x", (unsigned)(fnv1a(code) & 0xffffffffu));
+    m.id = std::string(name, std::strlen(name) - 6) + sum;  // without ".hsaco"
     g_jit_cache[key] = m;
     *out = m.fn;
     *id = m.id;

@@ -23,7 +23,7 @@ def _bench(args, timeout=900):
 
 
 def test_one_gpu_line_and_self_launched_two_rank_line_agree():
-    one = _bench(["--size", "512", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-one-shot"])
+    one = _bench(["--size", "512", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-one-shot", "--no-live-pmc"])
     assert one["n_gpus"] == 1 and one["unit"] == "Mrays/s" and one["scaling"] == "strong" and one["dtype"] == "f32"
     assert one["parity_check"]["rows_checked_bit_exact_vs_oracle"]
     two = _bench(["--gpus", "2", "--backend", "gloo", "--size", "512", "--steps", "3", "--warmup", "1"])
@@ -43,7 +43,7 @@ def test_one_gpu_line_and_self_launched_two_rank_line_agree():
 
 
 def test_workload_selector_runs_c5_by_name():
-    line = _bench(["--workload", "C5", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-one-shot"])
+    line = _bench(["--workload", "C5", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-one-shot", "--no-live-pmc"])
     assert line["config"]["workload"].startswith("C5: sphere_grid 8192x8192") and line["config"]["pixels_per_frame"] == 8191 * 8191
     assert line["parity_check"]["rows_checked_bit_exact_vs_oracle"]
 
@@ -72,7 +72,7 @@ def test_the_rccl_branch_runs_with_one_rank():
     created --, the band gather through dist.gather on the communication stream, work.wait()'s stream hand-off, the
     calibration and the other wire format, all with ONE rank on the one GPU this box has.  The gathered frame's rows are
     compared with the oracle like any other line's."""
-    line = _bench(["--force-dist", "--size", "512", "--steps", "3", "--warmup", "2", "--cpu-seconds", "0", "--no-one-shot"])
+    line = _bench(["--force-dist", "--size", "512", "--steps", "3", "--warmup", "2", "--cpu-seconds", "0", "--no-one-shot", "--no-live-pmc"])
     assert line["n_gpus"] == 1 and line["value"] > 0
     mg = line["multi_gpu"]
     assert mg["backend"] == "nccl (RCCL)" and mg["ranks"] == 1 and mg["forced_with_one_rank"] is True and mg["wire"] == "f32"
@@ -81,7 +81,22 @@ def test_the_rccl_branch_runs_with_one_rank():
     assert line["render_only"]["value"] >= line["value"] * 0.5
     assert line["parity_check"]["rows_checked_bit_exact_vs_oracle"]  # rows of the frame dist.gather delivered
     # ... and with the bytes Canvas::to_ppm prints as the measured wire format
-    u8 = _bench(["--force-dist", "--wire", "u8", "--size", "512", "--steps", "3", "--warmup", "2", "--cpu-seconds", "0", "--no-one-shot"])
+    u8 = _bench(["--force-dist", "--wire", "u8", "--size", "512", "--steps", "3", "--warmup", "2", "--cpu-seconds", "0", "--no-one-shot", "--no-live-pmc"])
     assert u8["multi_gpu"]["wire"] == "u8" and u8["multi_gpu"]["wire_format_gather"]["equals_quantised_f32_frame"] is True
     assert u8["parity_check"]["rows_checked_bit_exact_vs_oracle"]
     assert u8["config"]["rays_per_frame"] == line["config"]["rays_per_frame"]
+
+
+def test_the_roofline_counters_are_collected_live():
+    """Without --no-live-pmc the one-GPU line measures its own counters (child runs under rocprofv3 --pmc, one group each): the
+    VALU instruction count and the HBM-side bytes belong to the kernel that was timed, whatever profiles/ holds."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("no rocprofv3 on this box")
+    line = _bench(["--size", "1024", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-one-shot"])
+    roof = line["roofline"]
+    assert roof["pmc_source"].startswith("live"), roof
+    pixels = 1023 * 1023
+    assert roof["valu_wave_insts_per_launch"] > pixels / 64 * 100  # (hundreds of VALU instructions per pixel at the least)
+    assert roof["traffic"] >= 0.5 * pixels * 12 and roof["traffic"] < 40 * pixels * 12  # the canvas store, and not absurdly more
+    assert 0 < roof["frac"] < 1
