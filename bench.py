@@ -515,8 +515,18 @@ def live_pmc(args, kernel_id):
     try:
         for group in (["SQ_INSTS_VALU"], ["FETCH_SIZE"], ["WRITE_SIZE"]):
             d = os.path.join(tmp, group[0])
-            r = subprocess.run([exe, "--pmc"] + group + ["--output-format", "csv", "-d", d, "--"] + child, env=env, cwd="/tmp", capture_output=True, text=True, timeout=180)
-            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            # (its own session: if it outlives its two minutes the whole group goes, the profiled program with the profiler's launcher)
+            proc = subprocess.Popen([exe, "--pmc"] + group + ["--output-format", "csv", "-d", d, "--"] + child, env=env, cwd="/tmp", stdout=subprocess.PIPE,
+                                    stderr=subprocess.DEVNULL, text=True, start_new_session=True)
+            try:
+                stdout, _ = proc.communicate(timeout=120)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                return None
+            r = proc
+            lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not lines or json.loads(lines[-1])["roofline"]["kernel_id"] != kernel_id:
                 return None
             if os.environ.get("RTC_BENCH_PMC_DEBUG"):
