@@ -267,8 +267,6 @@ struct Policy {
     int specialise = 2;  // RTC_AMD_SPECIALIZE: 0 never, 1 always (a failed compile is an error), 2 by frame size
     bool light_cull = true, dark = true, fast_shadow = true, cell_cull = true;  // RTC_AMD_LIGHT_CULL / _DARK / _FAST_SHADOW / _CELL_CULL (SceneHdr::cull_flags)
     bool bvh = true, scene_box = true, gates = true, tri_precull = true, block_list = true, quiet = false;
-    bool first_redo = true;   // RTC_AMD_FIRST_REDO: a mesh world's first frame runs on a budget per wave; what gives up is traced again with sixteen lanes per pixel
-    uint32_t first_budget_us = 500u, first_redo_cap = 16384u;  // (development: RTC_AMD_FIRST_BUDGET_US, RTC_AMD_FIRST_REDO_CAP)
     bool scene_tiles = true;  // RTC_AMD_SCENE_TILES: a sparse bounded scene's frames as zero-fill + its own tiles (rtc_ctx::scene_tile_mask)
     bool prune = true;    // RTC_AMD_PRUNE: groups / nodes a ray enters beyond what it still wants are left closed (for_each_object, ERROR_BUDGET.md B6)
     int clusters = -1;    // RTC_AMD_CLUSTERS: nodes over long triangle runs -- 0 never, 1 always, -1 by frame size
@@ -301,9 +299,6 @@ struct Policy {
         p.tri_precull = flag(std::getenv("RTC_AMD_TRI_PRECULL"), true);
         p.prune = flag(std::getenv("RTC_AMD_PRUNE"), true);
         p.scene_tiles = flag(std::getenv("RTC_AMD_SCENE_TILES"), true);
-        p.first_redo = flag(std::getenv("RTC_AMD_FIRST_REDO"), true);
-        if (const char* e = RTC_DEV_ENV("RTC_AMD_FIRST_BUDGET_US")) p.first_budget_us = std::max(1u, (uint32_t)std::atoi(e));
-        if (const char* e = RTC_DEV_ENV("RTC_AMD_FIRST_REDO_CAP")) p.first_redo_cap = std::max(16u, (uint32_t)std::atoi(e));
         p.block_list = flag(std::getenv("RTC_AMD_BLOCK_LIST"), true);
         p.block_feedback = flag(std::getenv("RTC_AMD_BLOCK_FEEDBACK"), true);
         p.grid_feedback = flag(std::getenv("RTC_AMD_GRID_FEEDBACK"), true);
@@ -1311,8 +1306,6 @@ struct BlockList {  // RenderArgs::tiles of one partition (build_block_list), re
     // feedback (refine_block_list): the list as built, where its first launch leaves its waves' running times, and how far it is
     std::vector<uint32_t> host;
     size_t d_cap = 0, ticks_cap = 0;  // bytes behind d / d_ticks: grown, never shrunk (hipMalloc / hipFree cost the animation's frames milliseconds)
-    uint32_t* d_redo = nullptr;   // a first frame on a budget: {blocks listed, tickets taken, -, -} + the second launch's list (RenderArgs::redo_count)
-    size_t redo_cap_bytes = 0;
     uint32_t* d_ticks = nullptr;  // [4 n] wave times -- or, for kernels that do not time their waves, [4 n] uint4 work counts (a copy of block_counts)
     bool counts = false, swizzled = false, listed = false;  // (listed: a grid whose frames run from `d`, its blocks in order)
     // IDLE (regular grids): a scene's first frame -- nothing is measured before a second frame of the SAME scene shows that frames repeat
@@ -1466,7 +1459,6 @@ static void drop_block_lists(rtc_ctx* c) {
     for (auto& bl : c->block_lists) {
         if (bl.second.d) (void)hipFree(bl.second.d);
         if (bl.second.d_ticks) (void)hipFree(bl.second.d_ticks);
-        if (bl.second.d_redo) (void)hipFree(bl.second.d_redo);
         if (bl.second.ev0) (void)hipEventDestroy(bl.second.ev0);
         if (bl.second.ev1) (void)hipEventDestroy(bl.second.ev1);
     }
@@ -2027,10 +2019,6 @@ static rtc_status recut_block_list(rtc_ctx* c, BlockList& bl, uint32_t rows) {
     HIP_TRY(feedback_staging(c, 4u * bl.n * sizeof(uint32_t), &staging));
     const uint32_t* ticks = (const uint32_t*)staging;
     HIP_TRY(hipMemcpy(staging, bl.d_ticks, 4u * bl.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    // (a wave that gave up on its budget -- a first frame's, see RenderArgs::budget_ticks -- ran for that budget and would have run on:
-    // it counts as eight budgets, which gives its tile the lanes the second launch gave it; the next pass times the tile properly)
-    for (size_t i = 0; i < 4u * bl.n; i++)
-        if (((uint32_t*)staging)[i] == WAVE_GAVE_UP) ((uint32_t*)staging)[i] = 800u * P.first_budget_us;
     refine_block_list(bl.host, ticks, c->hdr.width, rows, 0.85 * 4.0 * compute_units(c) * P.tree_waves, 0.01 * P.feedback_pct, 0.01 * P.feedback_down_pct,
                       &refined, P.feedback_max_s, &throughput_ticks);
     if (P.jit_print) {
@@ -2637,8 +2625,6 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     const uint32_t* d_tiles = nullptr;
     uint32_t* d_ticks = nullptr;
     BlockList* timed_list = nullptr;  // a list whose own events bracket this launch
-    uint32_t* d_redo = nullptr;       // a first frame on a budget: see BlockList::d_redo
-    uint32_t redo_cap = 0u;
     void* copy_counts_to = nullptr;
     const bool mesh_list = spec_fn && c->spec_shares && !c->heavy_tiles.empty() && c->hdr.light_kind == RTC_LIGHT_POINT;
     // ... and frames that share an area light's cells between a pixel's lanes (small frames: choose_share_log2), when there is a
@@ -2692,13 +2678,6 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             d_ticks = bl.d_ticks;
             if (bl.state == BlockList::FRESH) {
                 bl.state = BlockList::TIMED;
-                // A mesh world's first frame: on a budget, with a second launch for the waves that give up (RenderArgs::budget_ticks)
-                if (mesh_list && P.first_redo && bl.passes == 0u) {
-                    redo_cap = P.first_redo_cap;
-                    HIP_TRY(grow(&bl.d_redo, &bl.redo_cap_bytes, (4u + (size_t)redo_cap) * sizeof(uint32_t)));
-                    HIP_TRY(hipMemsetAsync(bl.d_redo, 0, 4u * sizeof(uint32_t), stream));
-                    d_redo = bl.d_redo;
-                }
             } else {
                 if (bl.ev0 == nullptr) {
                     HIP_TRY(hipEventCreate(&bl.ev0));
@@ -2926,8 +2905,7 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
             grid = dim3((uint32_t)bl.n_listed, 1);
         }
     }
-    const size_t n_blocks_first = (size_t)grid.x * grid.y * 4;
-    const size_t n_blocks = n_blocks_first + 4u * (size_t)redo_cap;  // partial counts: one per wave (of both launches)
+    const size_t n_blocks = (size_t)grid.x * grid.y * 4;  // partial counts: one per wave
     if (n_blocks > c->block_cap) {  // grow-only workspace (first call / larger image only)
         if (c->d_block_counts) HIP_TRY(hipFree(c->d_block_counts));
         c->d_block_counts = nullptr;
@@ -2977,10 +2955,6 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     a.share_log2 = share_log2;
     a.tiles = d_tiles;
     a.wave_ticks = d_ticks;
-    a.budget_ticks = d_redo ? P.first_budget_us * 100u : 0u;  // (the clock runs at 100 MHz)
-    a.redo_count = nullptr;
-    a.redo_tickets = d_redo ? d_redo + 1 : nullptr;
-    a.redo_cap = redo_cap;
     a.blocks_y = blocks_y;
     a.swizzle = (swizzle && d_tiles == nullptr) ? 1u : 0u;
     a.block_x0 = block_x0;
@@ -3047,21 +3021,6 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
     else if (c->n_objects <= 8 && c->simple) hipLaunchKernelGGL((render_kernel<8, true>), grid, block, 0, stream, a);
     else if (c->n_objects <= 8) hipLaunchKernelGGL((render_kernel<8, false>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, 0, stream, a);
-    if (d_redo) {
-        // ... and the waves that gave up, once more: their pixels in blocks of 4 x 4 at sixteen lanes each.  The grid is the list's
-        // capacity; the workgroups beyond what was listed leave at once (their counts: zeroed here).
-        HIP_TRY(hipMemsetAsync(c->d_block_counts + n_blocks_first, 0, 4u * (size_t)redo_cap * sizeof(uint4), stream));
-        hipLaunchKernelGGL(redo_list_kernel, dim3((uint32_t)((n_blocks_first + 255u) / 256u)), dim3(256), 0, stream, d_ticks, d_tiles, grid.x, d_redo + 4, d_redo, redo_cap);
-        RenderArgs b = a;
-        b.tiles = d_redo + 4;
-        b.redo_count = d_redo;
-        b.wave_ticks = nullptr;
-        b.budget_ticks = 0u;
-        b.redo_tickets = nullptr;
-        b.block_counts = c->d_block_counts + n_blocks_first;
-        void* params[] = {&b};
-        HIP_TRY(hipModuleLaunchKernel(spec_fn, redo_cap, 1, 1, block.x, 1, 1, 0, stream, params, nullptr));
-    }
     if (tile_launch && n_fill_jobs) HIP_TRY(hipStreamWaitEvent(stream, c->ev_join, 0));
     HIP_TRY(hipEventRecord(ev.second, stream));
     if (timed_list) {

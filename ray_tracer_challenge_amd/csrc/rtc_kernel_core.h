@@ -991,24 +991,6 @@ struct Counters {
         shaded += n << 12;
 #endif
     }
-    // A first frame on a budget (render_body, RenderArgs::budget_ticks; lane-sharing kernels only): when the wave started, how long it
-    // may run (0: as long as it takes; wave-uniform), and whether color_at gave up because of it.
-    // Giving up takes a ticket: the second launch has room for redo_cap_ blocks, and a wave that finds none left runs on to its end.
-    uint32_t t0_, budget_, aborted_, redo_need_, redo_cap_;
-    uint32_t* redo_tickets_;
-    DI bool over_budget() {
-        if (!SHARE_LANES || budget_ == 0u) return false;
-        if ((uint32_t)wall_clock64() - t0_ <= budget_) return false;
-        uint32_t before = 0u;
-        if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) before = atomicAdd(redo_tickets_, redo_need_);
-        before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);  // (the first active lane is the one that asked)
-        if (before + redo_need_ > redo_cap_) {
-            budget_ = 0u;  // no room left: this wave finishes what it began
-            return false;
-        }
-        aborted_ = 1u;
-        return true;
-    }
     DI uint32_t shaded_count() const { return RTC_DEEP_STACK ? shaded : (shaded & 0xfffu); }
     DI uint32_t culled_count() const { return RTC_DEEP_STACK ? culled_deep_ : (shaded >> 12); }
 #if defined(RTC_SPEC_SHARE) && RTC_SPEC_SHARE
@@ -2830,9 +2812,6 @@ DI V3 color_at(const SceneHdr& H, const SceneSoA& S, V3 o, V3 d, int depth, uint
     V3 ret = v3(0.0f, 0.0f, 0.0f);
     for (;;) {
         // ---------------- color_at(ray(o, d), rem)
-        // (a wave over its first frame's budget stops between two rays -- all its lanes: the clock is one scalar -- and its pixels are
-        // traced again with sixteen lanes each, render_body)
-        if (cnt.over_budget()) return v3(0.0f, 0.0f, 0.0f);
         cnt.rays += cnt.lead();
         Hit h;
         float kt1 = 0.0f, kt2 = 0.0f;  // tree kernels: the ray's containers, from the same walk (nearest_hit_and_containers)
@@ -3080,16 +3059,6 @@ struct RenderArgs {
     // gridDim.x + blockIdx.x) leaves its own running time here, [4 b + w], in ticks of the 100 MHz clock: what the host orders
     // and cuts the NEXT frames' list by.  (The other kernels' lists are ordered by the waves' work counts, block_counts.)
     uint32_t* wave_ticks;
-    // A scene's FIRST frame has no frame before it to cut its list by (the reference renders one frame per process, camera.rs:76).  With
-    // wave_ticks and budget_ticks != 0, a wave of 64, 32 or 16 pixels that is still tracing after that many ticks gives up: it stores no
-    // pixel, counts nothing and leaves WAVE_GAVE_UP as its time.  The host then has redo_list_kernel list those waves' pixels as blocks
-    // of sixteen lanes per pixel and launches the kernel once more over that list -- redo_count: where the number of listed blocks
-    // is; workgroups beyond it leave at once -- so that the frame's few dear pixels (the middle of a glass mesh: a wave of them runs
-    // for longer than all the rest of the frame takes) are cut up in THIS frame, a budget late, instead of in the next one.
-    uint32_t budget_ticks;
-    const uint32_t* redo_count;
-    uint32_t* redo_tickets;  // budgeted launch: blocks of the second launch spoken for so far (a wave takes 4, 2 or 1), of redo_cap
-    uint32_t redo_cap;
     uint32_t blocks_y;  // regular grid: blocks rendered by one workgroup, stacked vertically (>= 1)
     // Regular grid, not 0: which block a workgroup renders is not (blockIdx.x, blockIdx.y) but a permutation of it within four
     // rows of the grid (an even number of columns, a multiple of four rows: the host pads).  Workgroups are started in index
@@ -3122,7 +3091,6 @@ struct RenderArgs {
     uint32_t chunk_block_rows, epoch;
 };
 constexpr uint32_t PROGRESS_STRIDE = 16;
-constexpr uint32_t WAVE_GAVE_UP = 0xffffffffu;  // RenderArgs::wave_ticks of a wave that ran out of budget_ticks
 
 // One of the launch's first workgroups (render_body): zero the part outside the scene rectangle of its share of the rows.
 // Memory-bound work running beside the arithmetic-bound rendering; 16-byte stores where rows and segments are aligned to
@@ -3223,15 +3191,12 @@ DI void render_body(const RenderArgs& A) {
         w.yl = by0 + ((wave >> 1) << th_log2) + (q >> tw_log2);
         return w;
     };
-    if (Counters::SHARE_LANES && A.redo_count != nullptr && blockIdx.x >= *A.redo_count) return;  // (wave-uniform; its counts were zeroed by the host)
     const Where w0 = where(0u);
     const uint32_t sl = w0.sl;
     Counters cnt = {0u, 0u, sl};
     const bool timed = Counters::SHARE_LANES && A.wave_ticks != nullptr;  // wave-uniform
     uint32_t ticks0 = 0u;
     if (timed) ticks0 = (uint32_t)wall_clock64();
-    // (waves of eight pixels or fewer are never cut off: the blocks that trace their pixels again are 4 x 4 pixels)
-    if (timed && sl <= 2u) cnt.t0_ = ticks0, cnt.budget_ = A.budget_ticks, cnt.redo_need_ = 4u >> sl, cnt.redo_cap_ = A.redo_cap, cnt.redo_tickets_ = A.redo_tickets;
 #ifdef RTC_DEBUG_TIMELINE  // development (tools/wave_timeline.py): the frame holds each wave's start / end / place instead of colours
     const uint32_t t_start = (uint32_t)wall_clock64();
 #endif
@@ -3299,7 +3264,7 @@ DI void render_body(const RenderArgs& A) {
         // obvious alternative -- the wave's 8 x 8 tile transposed through LDS and stored as 48 sixteen-byte pieces, six per row: C3 +3 %,
         // C5 +3 %, first_plane +6 %, profiles/r04_ab_wide_stores.txt.  The memory system merges the partial lines; the transpose costs
         // an LDS round trip and registers in front of every wave's exit.)
-        if (cnt.lead() && !(Counters::SHARE_LANES && __any((int)cnt.aborted_))) {
+        if (cnt.lead()) {
             const bool through = A.progress != nullptr;  // wave-uniform: write-through stores (RenderArgs::progress)
             const Where ws = where(rep);
             if (A.out_u8 != nullptr) {  // wave-uniform: scale_color on the way out (the arithmetic of quantize_kernel)
@@ -3330,8 +3295,6 @@ DI void render_body(const RenderArgs& A) {
     }
     // work statistics: wave reduce, then one partial per wave
     uint32_t rays = cnt.rays, shaded = cnt.shaded_count(), culled = cnt.culled_count();
-    const bool gave_up = Counters::SHARE_LANES && __any((int)cnt.aborted_);  // (every lane is here: wave-uniform)
-    if (gave_up) rays = shaded = culled = 0u;  // what it traced is traced again, and counted then
     for (int off = 32; off > 0; off >>= 1) {
         rays += __shfl_down(rays, off, 64);
         shaded += __shfl_down(shaded, off, 64);
@@ -3342,7 +3305,7 @@ DI void render_body(const RenderArgs& A) {
     // depth of recursion -- the edge of a glass ball -- the waiting waves were holding the slots of the next workgroup)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) A.total[threadIdx.x] = 0ull;  // for sum_counts_kernel's atomics
     if (lane == 0) A.block_counts[slot + wave] = make_uint4(rays, shaded, culled, 0u);
-    if (timed && lane == 0) A.wave_ticks[slot + wave] = gave_up ? WAVE_GAVE_UP : min((uint32_t)wall_clock64() - ticks0, WAVE_GAVE_UP - 1u);
+    if (timed && lane == 0) A.wave_ticks[slot + wave] = (uint32_t)wall_clock64() - ticks0;
     if (A.progress != nullptr) {  // see RenderArgs::progress
         // every store of this wave has been acknowledged -- and, being write-through, is in memory -- before the wave counts
         // itself done
@@ -3444,25 +3407,6 @@ __global__ __launch_bounds__(256) void fill_tiles_kernel(const uint2* __restrict
         }
     }
   }
-}
-
-// A first frame on a budget (RenderArgs::budget_ticks): one thread per wave of the budgeted launch.  The pixels of a wave that gave up
-// -- 8 x 8, 8 x 4 or 4 x 4 of them with 1, 2 or 4 lanes per pixel -- are listed as blocks of 4 x 4 pixels at sixteen lanes per pixel
-// (RenderArgs::tiles words), in whatever order the atomics hand out places: which block a workgroup traces changes no pixel.
-__global__ __launch_bounds__(256) void redo_list_kernel(const uint32_t* __restrict__ ticks, const uint32_t* __restrict__ tiles, uint32_t n_blocks,
-                                                        uint32_t* __restrict__ out, uint32_t* __restrict__ count, uint32_t cap) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= 4u * n_blocks || ticks[i] != WAVE_GAVE_UP) return;
-    const uint32_t t = tiles[i >> 2], wave = i & 3u;
-    const uint32_t sl = (t >> 30) | ((t >> 13) & 4u), bx0 = ((t >> 16) & 0x3fffu) << 2, by0 = (t & 0x7fffu) << 2;
-    const uint32_t tw_log2 = 3u - (sl >> 1), th_log2 = 3u - ((sl + 1u) >> 1);  // the wave's tile: 2^tw x 2^th pixels (render_body)
-    const uint32_t wx = bx0 + ((wave & 1u) << tw_log2), wy = by0 + ((wave >> 1) << th_log2);
-    const uint32_t nx = (1u << tw_log2) >> 2, ny = (1u << th_log2) >> 2;  // (>= 1 each: waves of 4 x 2 pixels and fewer never give up)
-    const uint32_t pos = atomicAdd(count, nx * ny);  // (<= cap in the end: every wave that gave up held tickets for its blocks)
-    for (uint32_t k = 0; k < nx * ny; k++) {
-        const uint32_t x0 = wx + 4u * (k % nx), y0 = wy + 4u * (k / nx);
-        if (pos + k < cap) out[pos + k] = (4u & 3u) << 30 | (x0 >> 2) << 16 | (4u >> 2) << 15 | (y0 >> 2);  // tile word: s = 4
-    }
 }
 
 // canvas.rs:39-43

@@ -20,8 +20,7 @@ def kat():
 
 DEV_ONLY_SWITCHES = ("RTC_AMD_JIT_SOURCE", "RTC_AMD_JIT_FLAGS", "RTC_AMD_JIT_PRINT", "RTC_AMD_TREE_WAVES", "RTC_AMD_REG_LEVELS",
                      "RTC_AMD_BLOCKS_Y", "RTC_AMD_BLOCK_S", "RTC_AMD_BLOCK_S_TOP", "RTC_AMD_BLOCK_ORDER", "RTC_AMD_FILL_WGS", "RTC_AMD_TILE_FILL_WGS",
-                     "RTC_AMD_CLUSTER_MIN_RUN", "RTC_AMD_CLUSTER_LEAF", "RTC_AMD_CLUSTER_GMAX", "RTC_AMD_CLUSTER_STATS", "RTC_AMD_TRI_NAIVE",
-                     "RTC_AMD_FIRST_BUDGET_US", "RTC_AMD_FIRST_REDO_CAP")
+                     "RTC_AMD_CLUSTER_MIN_RUN", "RTC_AMD_CLUSTER_LEAF", "RTC_AMD_CLUSTER_GMAX", "RTC_AMD_CLUSTER_STATS", "RTC_AMD_TRI_NAIVE")
 
 
 @pytest.fixture

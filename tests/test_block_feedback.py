@@ -200,35 +200,3 @@ def test_partitions_of_a_scene_that_changes(feedback_env, name, size):
             H.assert_images_equal(image, exp, "%s, two partitions, frame %d" % (name, frame))
         assert rays == exp_rays, (name, frame, rays, exp_rays)
     r.close()
-
-
-_EXPECTED = {}  # (scene, size) -> the oracle's frame and ray count
-
-
-@pytest.mark.parametrize("name,size", [("mesh", (320, 240)), ("mesh", (1024, 768)), ("here_be_dragons", (500, 200)), ("here_be_dragons", (1000, 400))])
-@pytest.mark.parametrize("budget_us,cap", [("1", None), ("1", "16"), ("1", "64"), ("30", None), ("150", None), (None, None)])
-def test_a_first_frame_on_a_budget(monkeypatch, dev_lib, name, size, budget_us, cap):
-    """A mesh world's first frame (rtc_device.hip ctx_render_slot, RenderArgs::budget_ticks): waves that run over their budget give up
-    and their pixels are traced again by a second launch with sixteen lanes each.  With a budget of a microsecond nearly every wave
-    asks to -- as many as the second launch has room for (16 384 blocks by default; 16 and 64 here: tickets run out at once) do, the
-    rest run on; with 30 and 150 us the dear ones.  No pixel and no count may change -- in that frame or in the ones cut from its times."""
-    for key, v in (("RTC_AMD_FIRST_BUDGET_US", budget_us), ("RTC_AMD_FIRST_REDO_CAP", cap)):
-        if v is None:
-            monkeypatch.delenv(key, raising=False)
-        else:
-            monkeypatch.setenv(key, v)
-    world, camera, depth = getattr(scenes, name)(*size)
-    if (name, size) not in _EXPECTED:
-        _EXPECTED[(name, size)] = H.oracle_camera(camera).render(H.oracle_world(world), depth, threads=THREADS)
-    exp, exp_rays = _EXPECTED[(name, size)]
-    for redo in ("1", "0"):
-        monkeypatch.setenv("RTC_AMD_FIRST_REDO", redo)
-        r = _renderer(world, camera)
-        for frame in range(4):
-            image = r.render(depth).cpu().numpy()
-            st = r.stats()
-            what = "%s %dx%d budget %s us cap %s redo=%s frame %d" % (name, size[0], size[1], budget_us, cap, redo, frame)
-            if not np.array_equal(image, exp):
-                H.assert_images_equal(image, exp, what)
-            assert st["rays"] == exp_rays, (what, st["rays"], exp_rays)
-        r.close()
