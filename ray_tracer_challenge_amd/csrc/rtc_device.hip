@@ -280,7 +280,7 @@ struct Policy {
     // development
     std::string jit_source, jit_flags;  // RTC_AMD_JIT_SOURCE=<path of rtc_kernel_core.h>, RTC_AMD_JIT_FLAGS="-D... -m..."
     bool jit_print = false, cluster_stats = false, tri_naive = false, block_order = true;
-    int tree_waves = 6, reg_levels = 0, blocks_y = 0, block_s = -1, block_s_top = -1;  // (0 / -1: the library's own choice)
+    int tree_waves = 0, reg_levels = 0, blocks_y = 0, block_s = -1, block_s_top = -1;  // (0 / -1: the library's own choice)
     uint32_t fill_wgs = 0u, tile_fill_wgs = 0u, cluster_min_run = 0u, cluster_leaf = 0u, area_share_waves = 0u, feedback_pct = 85u, feedback_down_pct = 40u, feedback_passes = 2u, feedback_max_s = 4u;
     double cluster_gmax = -1.0;
 
@@ -315,7 +315,7 @@ struct Policy {
         p.cluster_stats = flag(RTC_DEV_ENV("RTC_AMD_CLUSTER_STATS"), false);
         p.tri_naive = flag(RTC_DEV_ENV("RTC_AMD_TRI_NAIVE"), false);
         p.block_order = flag(RTC_DEV_ENV("RTC_AMD_BLOCK_ORDER"), true);
-        p.tree_waves = digit(RTC_DEV_ENV("RTC_AMD_TREE_WAVES"), 1, 8, 6);
+        p.tree_waves = digit(RTC_DEV_ENV("RTC_AMD_TREE_WAVES"), 1, 8, 0);  // (0: by the scene and the frame, rtc_ctx_set_scene)
         p.reg_levels = digit(RTC_DEV_ENV("RTC_AMD_REG_LEVELS"), 0, 8, 0);
         p.blocks_y = digit(RTC_DEV_ENV("RTC_AMD_BLOCKS_Y"), 1, 8, 0);
         p.block_s = digit(RTC_DEV_ENV("RTC_AMD_BLOCK_S"), 0, 3, -1);
@@ -1349,6 +1349,7 @@ struct rtc_ctx {
     std::string kernel_name;          // what rtc_ctx_render launches, for rtc_ctx_kernel_name()
     // Block list of the current scene (RenderArgs::tiles): which 16 x 16 pixel tiles of the image a mesh projects to
     // (row-major bitmap, empty: no block list), and the list last built -- for the partition it was built for
+    int tree_waves = 6;  // waves per SIMD the scene's tree kernel was compiled for (rtc_ctx_set_scene)
     std::vector<uint8_t> heavy_tiles;
     uint32_t heavy_w = 0, heavy_h = 0;
     // key: band_rows, n_parts, part, lanes per pixel (log2; ~0: a regular grid's order), depth (what a block costs depends on it)
@@ -2019,7 +2020,7 @@ static rtc_status recut_block_list(rtc_ctx* c, BlockList& bl, uint32_t rows) {
     HIP_TRY(feedback_staging(c, 4u * bl.n * sizeof(uint32_t), &staging));
     const uint32_t* ticks = (const uint32_t*)staging;
     HIP_TRY(hipMemcpy(staging, bl.d_ticks, 4u * bl.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    refine_block_list(bl.host, ticks, c->hdr.width, rows, 0.85 * 4.0 * compute_units(c) * P.tree_waves, 0.01 * P.feedback_pct, 0.01 * P.feedback_down_pct,
+    refine_block_list(bl.host, ticks, c->hdr.width, rows, 0.85 * 4.0 * compute_units(c) * c->tree_waves, 0.01 * P.feedback_pct, 0.01 * P.feedback_down_pct,
                       &refined, P.feedback_max_s, &throughput_ticks);
     if (P.jit_print) {
         size_t by_s[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};  // blocks by lanes per pixel (log2), before and after
@@ -2335,10 +2336,17 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
         const bool uniform = uniform_bits(&first);
         char b[16];
         snprintf(b, sizeof(b), "0x%x", first);
+        // Waves per SIMD, i.e. registers per lane (80 at six, 96 at five).  At six the walk's state does not fit and the hot loops spill:
+        // hexagons 4096 x 2048 moves 940 MB of HBM-side traffic for its 101 MB canvas at six and 557 MB at five, in the same 0.446 ms;
+        // here_be_dragons 1000 x 400 265 -> 151 MB and 0.565 -> 0.533 ms; mesh 1024^2 1.56 -> 1.46 ms, 512 x 384 1.48 -> 1.39; hexagons
+        // 1000 x 500, C5, grouped_grid: even.  Only the large frames of divided meshes, whose time is wave slots rather than their
+        // longest wave, want the sixth wave: mesh 2048^2 2.03 ms at six / 2.12 at five, here_be_dragons 4000 x 1600 1.71 / 1.83 (and
+        // 2000 x 800 0.91 / 0.87 the other way).  profiles/r04_tree_waves.txt.
+        c->tree_waves = P.tree_waves ? P.tree_waves : (!c->heavy_tiles.empty() && pixels >= 3000000ull) ? 6 : 5;
         defs = {std::string("-DRTC_SPEC_LIST=") + b,
                 uniform ? std::string("-DRTC_SPEC_UNIFORM_BITS=") + b : std::string("-DRTC_SPEC_RUNTIME_BITS=1"),
                 "-DRTC_SPEC_NOBJ=-1", "-DRTC_SPEC_SIMPLE=0",
-                reg_waves ? std::string(reg_waves) : "-DRTC_WAVES_PER_SIMD=" + std::to_string(P.tree_waves),
+                reg_waves ? std::string(reg_waves) : "-DRTC_WAVES_PER_SIMD=" + std::to_string(c->tree_waves),
                 std::string("-DRTC_SPEC_TBOX=") + std::to_string(hdr.has_tbox),
                 "-DRTC_SPEC_LIGHT_KIND=" + std::to_string(hdr.light_kind),
                 "-DRTC_SPEC_JITTER=" + std::to_string(hdr.jitter_mode),
