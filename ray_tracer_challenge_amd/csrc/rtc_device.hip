@@ -2407,6 +2407,12 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
             // kernel spills 20 registers at five waves (96 VGPRs) and none at four (128) -- 0.874 -> 0.775 ms; skybox (two objects)
             // and the scenes without glass lose up to 12 % at four (profiles/r04_ab_point_light_waves.txt)
             defs.push_back((any_refl && any_refr && n >= 5u) ? "-DRTC_WAVES_PER_SIMD=4" : "-DRTC_WAVES_PER_SIMD=5");
+        } else if (hdr.light_kind == RTC_LIGHT_RECT && !c->simple && !reg_waves) {
+            // An area light's kernel takes seven waves per SIMD (jit_get's default: C3 0.97 / 0.95 / 1.02 ms at 6 / 7 / 8).  With rotated
+            // objects, cylinders, patterns or gates the sample loop's state no longer fits 72 registers and spills: first_textures
+            // 4096 x 2048 moves 337 MB HBM-side for its 101 MB canvas at seven and 185 MB at six (84 registers) in the same 0.70 ms; 1024 x
+            // 512 and patterns_medley: even, first frames within 2 % either way (profiles/r04_ab_area_light_waves.txt).
+            defs.push_back("-DRTC_WAVES_PER_SIMD=6");
         }
         spec_name = "render_kernel_spec[" + list.substr(16) + (c->simple ? ";simple" : "") + (hdr.has_patterns ? ";patterns" : "") + (hdr.n_gates ? ";gates" : "") + "]";
     } else if (n > 8) {
