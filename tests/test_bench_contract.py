@@ -131,3 +131,23 @@ def test_self_launched_ranks_fail_loudly_without_a_gpu():
 def test_a_launcher_provided_world_size_must_match():
     r = _run_bench(["--gpus", "2", "--steps", "1"], env_extra={"WORLD_SIZE": "4", "RANK": "0"}, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_live_counters_are_tagged_and_never_collected_under_a_profiler(monkeypatch):
+    """Counters bench.py measured itself (child runs under rocprofv3 --pmc) are tagged `live`; a bench.py that is itself
+    running under rocprofv3 must not start profilers of its own."""
+    m = {"counters_mean_per_launch": {"SQ_INSTS_VALU": 387.4e6}, "hbm_bytes_per_launch": 235.0e6, "live": True}
+    r = bench.valu_roofline(("live", m), 0.56, _FakeRenderer())
+    assert r["pmc_source"].startswith("live") and r["profiled_kernel_ms"] is None and r["traffic"] == 235.0e6
+    assert abs(r["frac"] - 387.4e6 * 64 / 0.56e-3 / 1e12 / bench.VALU_PEAK_TOPS) < 1e-3
+    monkeypatch.setenv("ROCPROF_COUNTER_COLLECTION", "1")
+    assert bench.live_pmc(bench.parse(["--steps", "1"]), "spec_x.y") is None
+
+
+def test_kernel_ids_of_the_committed_summaries_name_the_code_object():
+    """Since round 4 a scene kernel's id ends in the checksum of its code object (two compilers gave two binaries for one source):
+    the summaries of the round carry that form."""
+    import re
+    for p in glob.glob(os.path.join(ROOT, "profiles", "r04_*_pmc.json")):
+        kid = json.load(open(p))["kernel_id"]
+        assert re.fullmatch(r"spec_[0-9a-f]{16}\.[0-9a-f]{8}", kid), (p, kid)
