@@ -36,6 +36,9 @@ def child(scene, w, h, variant):
         r0.close()
     r = Renderer(world, camera, device=0)
     out = r.alloc()
+    if variant == "touch_out":  # the frame's buffer written once before the first frame (its pages' translations, the memory-side cache)
+        out.zero_()
+        torch.cuda.synchronize()
     ts = []
     for _ in range(4):
         r.render(depth, out=out)
@@ -45,7 +48,7 @@ def child(scene, w, h, variant):
 
 def main():
     scene, w, h = (sys.argv[1:4] + ["soft_shadows", "4096", "4096"][len(sys.argv) - 1:])[:3]
-    for variant, env in (("cold", {}), ("busy", {}), ("valu", {}), ("other_ctx", {}), ("no_feedback", {"RTC_AMD_BLOCK_FEEDBACK": "0"})):
+    for variant, env in (("cold", {}), ("busy", {}), ("valu", {}), ("other_ctx", {}), ("touch_out", {}), ("no_feedback", {"RTC_AMD_BLOCK_FEEDBACK": "0"})):
         e = dict(os.environ)
         e.update(env)
         p = subprocess.run([sys.executable, __file__, "child", scene, w, h, variant], env=e, capture_output=True, text=True)
