@@ -57,3 +57,23 @@ def test_wide_worlds_at_a_size_that_takes_the_default_policies(seed):
         H.assert_images_equal(img, exp, "wide seed %d [%s] (%s) 512x384 frame %d" % (seed, style, r.kernel_name, frame))
         assert r.stats()["rays"] == rays
     r.close()
+
+
+@pytest.mark.parametrize("seed,size", [(s, None) for s in range(240, 280)] + [(s, (800, 400)) for s in (3, 12, 21, 30, 39, 45, 54, 63)])
+def test_wide_worlds_through_the_one_call_seam(seed, size):
+    """The same worlds through ONE rtc_render_ex call each (Camera.render, camera.rs:76): f32 rows into the caller's array and the
+    scale_color'd bytes (canvas.rs:39-43), on three band heights -- at their own size (ahead-of-time kernels) and at 800 x 400, where
+    the seam compiles the scene's kernel and its launch reports finished chunks of rows.  tools/fuzz_seam.py runs it over thousands."""
+    world, cam, depth, style = W.world(seed, P)
+    own, _, _, _ = W.world(seed, O)
+    camera = P.Camera(*cam) if size is None else P.Camera(size[0], size[1], cam[2], cam[3])
+    exp, rays = H.oracle_camera(camera).render(own, depth, threads=THREADS)
+    exp8 = O.quantize(exp)
+    for band in (0, 16, 48):
+        what = "wide seed %d [%s] through the seam, band_rows %d" % (seed, style, band)
+        got = camera.render(world, depth, band_rows=band).data
+        H.assert_images_equal(got, exp, what)
+        assert camera.last_stats["rays"] == rays, what
+        got8 = camera.render(world, depth, quantize=True, band_rows=band)
+        assert np.array_equal(got8, exp8), what + " (u8)"
+        assert camera.last_stats["rays"] == rays, what + " (u8)"
