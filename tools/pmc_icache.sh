@@ -6,6 +6,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 rocprofv3 -L > $OUT/counters.txt 2>&1
 BENCH="python3 tools/time_scene.py $@"
+$BENCH > $OUT/precompile.log 2>&1  # (compiled by a plain run first: under rocprofv3 the process holds another compiler -- LABNOTES "Round 4")
 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE --output-format csv -d $OUT/a -- $BENCH > $OUT/a.log 2>&1
 rocprofv3 --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE --output-format csv -d $OUT/b -- $BENCH > $OUT/b.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_IFETCH SQ_IFETCH_LEVEL --output-format csv -d $OUT/c -- $BENCH > $OUT/c.log 2>&1
