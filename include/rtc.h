@@ -321,7 +321,12 @@ rtc_status rtc_render(const rtc_scene* scene, const rtc_camera* camera, int32_t 
  * (rtc_render_release drops them), so a second frame costs the kernel plus the transfer.  stats: rays / shaded hits /
  * pixels summed over the devices, kernel_ms = the largest per-device sum of kernel times, gather_ms = wall time of
  * the render + transfer pipeline.  rtc_render(scene, camera, depth, device, out, stats) is rtc_render_ex with
- * opts = {devices = &device, n_devices = 1}. */
+ * opts = {devices = &device, n_devices = 1}.
+ * Which kernel: the reference renders one frame per process (camera.rs:76), and compiling a scene's own kernel takes 0.5 - 2 s
+ * where the frame it speeds up takes milliseconds.  These calls therefore render a scene with the ahead-of-time kernels the first time a
+ * process sees it -- unless its compiled kernel is already in the disk cache (<library dir>/jit_cache) -- and compile it when the same
+ * scene is rendered again, for that process and, through the cache, for every later one.  Same frames either way.
+ * RTC_AMD_SPECIALIZE=1 compiles at first sight, =0 never; the persistent contexts below (rtc_ctx_set_scene) always compile at once. */
 rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32_t depth, const rtc_opts* opts,
                          void* out, rtc_stats* stats);
 /* Frees everything rtc_render / rtc_render_ex keep between calls (all devices). */

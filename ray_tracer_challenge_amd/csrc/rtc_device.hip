@@ -1350,6 +1350,8 @@ struct rtc_ctx {
     // Block list of the current scene (RenderArgs::tiles): which 16 x 16 pixel tiles of the image a mesh projects to
     // (row-major bitmap, empty: no block list), and the list last built -- for the partition it was built for
     int tree_waves = 6;  // waves per SIMD the scene's tree kernel was compiled for (rtc_ctx_set_scene)
+    bool lazy_jit = false;      // a context of the one-call seam (rtc::ctx_mark_one_shot): see jit_get
+    bool jit_deferred = false;  // the resident scene's kernel was left uncompiled by its first sighting: the next render of this scene compiles it
     std::vector<uint8_t> heavy_tiles;
     uint32_t heavy_w = 0, heavy_h = 0;
     // key: band_rows, n_parts, part, lanes per pixel (log2; ~0: a regular grid's order), depth (what a block costs depends on it)
@@ -1533,7 +1535,13 @@ std::string jit_cache_dir(const Policy& P) {  // RTC_AMD_JIT_CACHE=<dir>, or 0 /
 }
 
 // Compiles (or fetches) the specialised kernel for `defines` on the current device.
-rtc_status jit_get(const Policy& P, int device, const std::vector<std::string>& defines, hipFunction_t* out, std::string* id) {
+// `lazy` (the one-call seam, rtc_render_ex: the reference renders ONE frame per process): a kernel that is neither in this process's
+// memory nor in the disk cache is not compiled the first time its scene is seen -- *out stays null and the frame is rendered by the
+// ahead-of-time kernel: a compile is 0.5 - 2 s, the frame it speeds up a few milliseconds (tools/first_call.py: C3's first call 693 ms
+// with the compile, 121 with a filled cache, 123 ahead-of-time).  The second time the process asks for the same kernel -- frames
+// repeat -- it is compiled, and cached on disk for every process after it.
+std::set<std::string> g_jit_seen;
+rtc_status jit_get(const Policy& P, int device, const std::vector<std::string>& defines, hipFunction_t* out, std::string* id, bool lazy = false) {
     std::string key = std::to_string(device) + "|";
     for (const auto& d : defines) key += d + " ";
     key += "|" + P.jit_source + "|" + P.jit_flags;  // (development builds: another source or other flags are another kernel)
@@ -1633,6 +1641,10 @@ rtc_status jit_get(const Policy& P, int device, const std::vector<std::string>& 
         std::memcpy(&h, code.data(), sizeof(h));
         code.erase(0, sizeof(h));
         cached = std::memcmp(h.magic, "RTCJIT1", 8) == 0 && h.size == code.size() && h.checksum == fnv1a(code);
+    }
+    if (!cached && lazy && g_jit_seen.insert(key).second) {  // (first sighting: see above)
+        *out = nullptr;
+        return RTC_OK;
     }
     if (!cached) {
         rtc_status st = compile(&code);
@@ -2143,7 +2155,26 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     if (c->has_scene && std::memcmp(&hdr, &c->hdr, sizeof(hdr)) == 0 && soa.size() == c->soa_host.size() &&
         texels.size() == c->texels_host.size() && std::memcmp(soa.data(), c->soa_host.data(), soa.size() * sizeof(float4)) == 0 &&
         (texels.empty() || std::memcmp(texels.data(), c->texels_host.data(), texels.size() * sizeof(float)) == 0))
-        return RTC_OK;  // the very scene that is resident (records, camera, light; the switches are the context's for life): nothing to replace
+    {   // the very scene that is resident (records, camera, light; the switches are the context's for life): nothing to replace --
+        // unless its kernel was left uncompiled the first time (jit_get, lazy): frames repeat, so now it pays
+        if (c->jit_deferred) {
+            c->jit_deferred = false;
+            HIP_TRY(hipDeviceSynchronize());  // (nothing of this context may be in flight while its kernel and lists change)
+            hipFunction_t fn = nullptr;
+            std::string id;
+            const rtc_status jst = jit_get(P, c->device, c->spec_defs, &fn, &id);
+            if (jst != RTC_OK) {
+                const rtc_status fst = jit_failed(c, P.specialise, jst);
+                if (fst != RTC_OK) return fst;
+            } else {
+                c->spec_fn = fn, c->kernel_id = id, c->kernel_name = c->spec_name;
+                drop_block_lists(c);  // (lists of the ahead-of-time launches: the scene's kernel takes other ones)
+                drop_scene_tile_lists(c);
+                c->deep_fn.clear();
+            }
+        }
+        return RTC_OK;
+    }
     // Renders are asynchronous on caller streams (torch's are non-blocking: the null-stream copies below do not order
     // against them), and a render still in flight reads the records and the counters this call replaces.  Wait for
     // everything the context has launched before touching them.  (rtc.h: one stream at a time per context.)
@@ -2439,12 +2470,16 @@ rtc_status rtc_ctx_set_scene(rtc_ctx* c, const rtc_scene* scene, const rtc_camer
     }
     c->spec_defs = defs;
     c->spec_name = spec_name;
+    c->jit_deferred = false;
     if (compile_now && !defs.empty()) {
-        rtc_status jst = jit_get(P, c->device, defs, &c->spec_fn, &c->kernel_id);
+        rtc_status jst = jit_get(P, c->device, defs, &c->spec_fn, &c->kernel_id, c->lazy_jit && policy == 2);
         if (jst != RTC_OK) {
             if ((jst = jit_failed(c, policy, jst)) != RTC_OK) return jst;
-        } else {
+        } else if (c->spec_fn != nullptr) {
             c->kernel_name = spec_name;
+        } else {
+            c->kernel_id = aot_kernel_id();  // (lazy: this frame by the ahead-of-time kernel, whose name kernel_name already holds)
+            c->jit_deferred = true;
         }
     }
     return RTC_OK;
@@ -3051,6 +3086,10 @@ rtc_status rtc::ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* 
 
 // After the caller has synchronised with every launch: counters summed over slots [0, n_slots), kernel_ms = the SUM
 // of the launches' HIP-event times since the last stats call (the launches of one frame run back to back).
+void rtc::ctx_mark_one_shot(rtc_ctx* c) {
+    if (c) c->lazy_jit = true;
+}
+
 rtc_status rtc::ctx_collect(rtc_ctx* c, uint32_t n_slots, rtc_stats* out) {
     std::memset(out, 0, sizeof(*out));
     if (n_slots > CTX_TOTAL_SLOTS) n_slots = CTX_TOTAL_SLOTS;

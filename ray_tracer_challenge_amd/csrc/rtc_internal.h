@@ -77,6 +77,9 @@ constexpr uint32_t PROGRESS_MAX_CHUNKS = 64;
 rtc_status ctx_render_slot(rtc_ctx* c, int32_t depth, const rtc_partition* part, void* d_out, void* stream, uint32_t slot,
                            ProgressPlan* plan = nullptr, bool out_u8 = false);
 rtc_status ctx_collect(rtc_ctx* c, uint32_t n_slots, rtc_stats* out);
+// A context of the one-call seam (rtc_render_ex): a scene whose kernel is neither in memory nor in the disk cache is rendered by the
+// ahead-of-time kernels the first time this process sees it and compiled when it is rendered again (rtc_device.hip jit_get).
+void ctx_mark_one_shot(rtc_ctx* c);
 
 }  // namespace rtc
 

@@ -283,7 +283,10 @@ rtc_status rtc_render_ex(const rtc_scene* scene, const rtc_camera* camera, int32
         }
         HIP_TRY(hipSetDevice(S.device));
         drain.touched.push_back(&S);
-        if (!S.ctx) RTC_TRY(rtc_ctx_create(S.device, &S.ctx));
+        if (!S.ctx) {
+            RTC_TRY(rtc_ctx_create(S.device, &S.ctx));
+            rtc::ctx_mark_one_shot(S.ctx);  // (a scene's kernel is compiled when the scene comes a second time, or is in the disk cache)
+        }
         if (!S.s_render) HIP_TRY(hipStreamCreateWithFlags(&S.s_render, hipStreamNonBlocking));
         for (hipStream_t& c : S.s_copy2)
             if (!c) HIP_TRY(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
